@@ -1,0 +1,138 @@
+"""Minimal BGZF/BAM *writer* used by the synthetic-input generator and the tests.
+
+This is tooling (fixtures, bench inputs), not the product's feed path: the product decodes BAM in
+C++ (breakid_amd/csrc/bam_reader.cc).  Format follows the SAM/BAM specification; the fields the
+reference consumes are the ones listed at /root/reference/thirdparty/.../htslib/sam.h:148-181.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+CIGAR_OPS = "MIDNSHP=X"
+_OP_CODE = {c: i for i, c in enumerate(CIGAR_OPS)}
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def parse_cigar(text: str) -> List[int]:
+    """'60M40S' -> BAM words (len<<4|op)."""
+    if text in ("", "*"):
+        return []
+    out, num = [], ""
+    for ch in text:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((int(num) << 4) | _OP_CODE[ch])
+            num = ""
+    return out
+
+
+def cigar_reflen(words: Sequence[int]) -> int:
+    n = 0
+    for w in words:
+        if (w & 15) in (0, 2, 3, 7, 8):
+            n += w >> 4
+    return n
+
+
+def reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+class BgzfWriter:
+    def __init__(self, path: str, level: int = 1):
+        self.f = open(path, "wb")
+        self.buf = bytearray()
+        self.level = level
+
+    def write(self, data: bytes) -> None:
+        self.buf += data
+        while len(self.buf) >= 0xFF00:
+            self._flush_block(bytes(self.buf[:0xFF00]))
+            del self.buf[:0xFF00]
+
+    def _flush_block(self, data: bytes) -> None:
+        c = zlib.compressobj(self.level, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        bsize = len(comp) + 25
+        hdr = struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize)
+        self.f.write(hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    def close(self) -> None:
+        if self.buf:
+            self._flush_block(bytes(self.buf))
+            self.buf.clear()
+        self.f.write(_BGZF_EOF)
+        self.f.close()
+
+
+def encode_record(qname: str, flag: int, tid: int, pos: int, mapq: int, cigar: Sequence[int],
+                  mtid: int, mpos: int, isize: int, aux: Sequence[Tuple[str, str]] = (),
+                  seq_len: int = 0) -> bytes:
+    """One BAM alignment record (pos/mpos 0-based).  aux = [(tag, string)] written as Z."""
+    name = qname.encode() + b"\0"
+    if flag & 4 or not cigar:
+        end = pos + 1
+    else:
+        end = pos + cigar_reflen(cigar)
+    b = reg2bin(max(pos, 0), max(end, pos + 1) if pos >= 0 else 1) if pos >= 0 else 4680
+    body = struct.pack("<iiBBHHHIiii", tid, pos, len(name), mapq, b, len(cigar), flag, seq_len, mtid, mpos, isize)
+    body += name
+    body += struct.pack("<%dI" % len(cigar), *cigar) if cigar else b""
+    if seq_len:
+        body += b"\x11" * ((seq_len + 1) // 2) + b"\x1e" * seq_len
+    for tag, val in aux:
+        body += tag.encode() + b"Z" + val.encode() + b"\0"
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path: str, contigs: Sequence[Tuple[str, int]], records: Iterable[bytes],
+              header_text: Optional[str] = None) -> None:
+    """records: iterable of encode_record() bytes, already coordinate sorted."""
+    if header_text is None:
+        header_text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join(
+            "@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in contigs)
+    w = BgzfWriter(path)
+    t = header_text.encode()
+    hdr = b"BAM\1" + struct.pack("<i", len(t)) + t + struct.pack("<i", len(contigs))
+    for n, l in contigs:
+        nb = n.encode() + b"\0"
+        hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    w.write(hdr)
+    chunk = bytearray()
+    for r in records:
+        chunk += r
+        if len(chunk) > (1 << 20):
+            w.write(bytes(chunk))
+            chunk.clear()
+    if chunk:
+        w.write(bytes(chunk))
+    w.close()
+
+
+def write_nib(path: str, seq: str) -> None:
+    """UCSC .nib as read by /root/reference/src/nibtools.cc:18-58 (T=0 C=1 A=2 G=3 N=4, high nibble first)."""
+    code = {"T": 0, "C": 1, "A": 2, "G": 3, "N": 4}
+    n = len(seq)
+    out = bytearray(struct.pack("<II", 0x6BE93D3A, n))
+    vals = [code.get(c, 4) for c in seq.upper()]
+    if n & 1:
+        vals.append(0)
+    for i in range(0, len(vals), 2):
+        out.append((vals[i] << 4) | vals[i + 1])
+    with open(path, "wb") as f:
+        f.write(bytes(out))

@@ -1,0 +1,257 @@
+"""Synthetic paired-end inputs shaped like BASELINE.json's configs.
+
+Two products:
+  * a *record table* (python/numpy) that can be written as a coordinate-sorted BAM (+ nib dir,
+    ref_names.txt, refGene.txt) for the reference / oracle / CLI, and
+  * the same records as the columnar SoA the C-ABI takes (see include/breakid_hip.h), so the bench
+    and the parity tests need no BAM round trip.
+
+Everything is seeded; nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import bamio
+
+HG19 = [("chr1", 249250621), ("chr2", 243199373), ("chr3", 198022430), ("chr4", 191154276),
+        ("chr5", 180915260), ("chr6", 171115067), ("chr7", 159138663), ("chr8", 146364022),
+        ("chr9", 141213431), ("chr10", 135534747), ("chr11", 135006516), ("chr12", 133851895),
+        ("chr13", 115169878), ("chr14", 107349540), ("chr15", 102531392), ("chr16", 90354753),
+        ("chr17", 81195210), ("chr18", 78077248), ("chr19", 59128983), ("chr20", 63025520),
+        ("chr21", 48129895), ("chr22", 51304566), ("chrX", 155270560), ("chrY", 59373566)]
+
+
+def fnv1a64(name: bytes) -> int:
+    """qname hash used for the qhash column (must match csrc/bam_reader.cc: bk_qname_hash)."""
+    h = 0xCBF29CE484222325
+    for b in name:
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    # final avalanche (splitmix64 finaliser) so that radix digits are well mixed
+    h ^= h >> 30
+    h = (h * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    h ^= h >> 27
+    h = (h * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    h ^= h >> 31
+    return h
+
+
+@dataclass
+class Rec:
+    qname: str
+    flag: int
+    tid: int
+    pos: int  # 0-based
+    mapq: int
+    cigar: str
+    mtid: int
+    mpos: int
+    isize: int
+    sa: str = ""
+    oc: str = ""
+
+
+@dataclass
+class Dataset:
+    contigs: List[Tuple[str, int]]
+    recs: List[Rec] = field(default_factory=list)
+
+    def sort(self) -> None:
+        big = 1 << 40
+        # coordinate order as `samtools sort` would give (unmapped tid=-1 last); stable on ties
+        self.recs.sort(key=lambda r: ((r.tid if r.tid >= 0 else big), r.pos))
+
+    # ---- BAM + side files -------------------------------------------------------------
+    def write_bam(self, path: str) -> None:
+        def gen():
+            for r in self.recs:
+                aux = []
+                if r.sa:
+                    aux.append(("SA", r.sa))
+                if r.oc:
+                    aux.append(("OC", r.oc))
+                yield bamio.encode_record(r.qname, r.flag, r.tid, r.pos, r.mapq, bamio.parse_cigar(r.cigar),
+                                          r.mtid, r.mpos, r.isize, aux)
+        bamio.write_bam(path, self.contigs, gen())
+
+    # ---- SoA ---------------------------------------------------------------------------
+    def to_soa(self) -> Dict[str, np.ndarray]:
+        n = len(self.recs)
+        soa = {
+            "tid": np.empty(n, np.int32), "pos": np.empty(n, np.int32), "mtid": np.empty(n, np.int32),
+            "mpos": np.empty(n, np.int32), "isize": np.empty(n, np.int32), "flag": np.empty(n, np.uint16),
+            "mapq": np.empty(n, np.uint8), "qhash": np.empty(n, np.uint64),
+            "cigar_off": np.zeros(n + 1, np.uint32), "aux_off": np.zeros(n + 1, np.uint32),
+        }
+        cig: List[int] = []
+        aux = bytearray()
+        for i, r in enumerate(self.recs):
+            soa["tid"][i] = r.tid
+            soa["pos"][i] = r.pos
+            soa["mtid"][i] = r.mtid
+            soa["mpos"][i] = r.mpos
+            soa["isize"][i] = r.isize
+            soa["flag"][i] = r.flag
+            soa["mapq"][i] = r.mapq
+            soa["qhash"][i] = fnv1a64(r.qname.encode())
+            cig.extend(bamio.parse_cigar(r.cigar))
+            soa["cigar_off"][i + 1] = len(cig)
+            aux += encode_aux(r.sa, r.oc)
+            soa["aux_off"][i + 1] = len(aux)
+        soa["cigar"] = np.asarray(cig, dtype=np.uint32)
+        soa["aux"] = np.frombuffer(bytes(aux), dtype=np.uint8).copy()
+        soa["target_len"] = np.asarray([l for _, l in self.contigs], dtype=np.uint32)
+        return soa
+
+
+def encode_aux(sa: str, oc: str) -> bytes:
+    """Per-record aux blob of the SoA: '' (no SA), SA text, or OC text + '\\t' + SA text.
+    Records without an SA tag carry nothing (the path never looks at OC then)."""
+    if not sa:
+        return b""
+    if oc:
+        return oc.encode() + b"\t" + sa.encode()
+    return sa.encode()
+
+
+# ----------------------------------------------------------------------------------------------
+def write_side_files(ds: Dataset, root: str, seed: int = 7, refgene_lines: Sequence[str] = ()) -> Dict[str, str]:
+    """nib dir (+ref_names.txt) and INSTALLDIR/ref_files/refGene.txt for the reference / CLI."""
+    nib = os.path.join(root, "nib")
+    inst = os.path.join(root, "install")
+    os.makedirs(nib, exist_ok=True)
+    os.makedirs(os.path.join(inst, "ref_files"), exist_ok=True)
+    rng = np.random.default_rng(seed)
+    with open(os.path.join(nib, "ref_names.txt"), "w") as f:
+        for name, _ in ds.contigs:
+            f.write(name + "\n")
+    for name, ln in ds.contigs:
+        p = os.path.join(nib, "hg19_%s.nib" % name)
+        if ln <= 5_000_000:
+            seq = "".join(np.array(list("ACGT"))[rng.integers(0, 4, ln)])
+            bamio.write_nib(p, seq)
+    with open(os.path.join(inst, "ref_files", "refGene.txt"), "w") as f:
+        for l in refgene_lines:
+            f.write(l + "\n")
+    return {"nib": nib, "install": inst}
+
+
+# ----------------------------------------------------------------------------------------------
+def _proper_pair(rng, i, tid, lo, hi, read_len, ins_mean, ins_sd, prefix="p"):
+    ins = max(read_len + 1, int(round(rng.normal(ins_mean, ins_sd))))
+    s = int(rng.integers(lo, max(lo + 1, hi - ins)))
+    e = s + ins - read_len
+    q = "%s%d" % (prefix, i)
+    c = "%dM" % read_len
+    return [Rec(q, 0x1 | 0x2 | 0x20 | 0x40, tid, s, 60, c, tid, e, ins),
+            Rec(q, 0x1 | 0x2 | 0x10 | 0x80, tid, e, 60, c, tid, s, -ins)]
+
+
+def _discordant_pair(q, ta, pa, tb, pb, read_len, rev_a=False, rev_b=True, mapq=60):
+    c = "%dM" % read_len
+    fa = 0x1 | 0x40 | (0x10 if rev_a else 0) | (0x20 if rev_b else 0)
+    fb = 0x1 | 0x80 | (0x10 if rev_b else 0) | (0x20 if rev_a else 0)
+    isz = 0 if ta != tb else (pb - pa + read_len)
+    return [Rec(q, fa, ta, pa, mapq, c, tb, pb, isz), Rec(q, fb, tb, pb, mapq, c, ta, pa, -isz)]
+
+
+def _split_pair(q, names, ta, bpa, tb, bpb, m1=60, m2=40, partner_flag=0x100):
+    """Primary m1M m2S ending at 1-based bpa on A; partner m1S m2M starting at 1-based bpb on B."""
+    pos_a = bpa - m1  # 0-based start so that 1-based end == bpa
+    pos_b = bpb - 1
+    c1 = "%dM%dS" % (m1, m2)
+    c2 = "%dS%dM" % (m1, m2)
+    sa1 = "%s,%d,+,%s,60,0;" % (names[tb], pos_b + 1, c2)
+    sa2 = "%s,%d,+,%s,60,0;" % (names[ta], pos_a + 1, c1)
+    prim = Rec(q, 0x1 | 0x2 | 0x40 | 0x20, ta, pos_a, 60, c1, ta, pos_a + 200, 300, sa=sa1)
+    part = Rec(q, 0x1 | 0x40 | 0x20 | partner_flag, tb, pos_b, 60, c2, ta, pos_a + 200, 0, sa=sa2)
+    mate = Rec(q, 0x1 | 0x2 | 0x80 | 0x10, ta, pos_a + 200, 60, "100M", ta, pos_a, -300)
+    return [prim, part, mate]
+
+
+def make_g1(partner_flag: int = 0x100, seed: int = 12345) -> Dataset:
+    """24 x 200 kb contigs, 6000 proper pairs, 12 discordant pairs chr1->chr2,
+    6 split reads (60M40S at chr1 / 0x100 partner 60S40M at chr2:80200)."""
+    rng = np.random.default_rng(seed)
+    names = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+    ds = Dataset([(n, 200_000) for n in names])
+    for i in range(6000):
+        tid = int(rng.integers(0, 24))
+        ds.recs += _proper_pair(rng, i, tid, 1000, 199_000, 100, 350, 40)
+    for i in range(12):
+        pa = 49_700 + int(rng.integers(0, 200))
+        pb = 80_050 + int(rng.integers(0, 150))
+        ds.recs += _discordant_pair("d%d" % i, 0, pa, 1, pb, 100)
+    for i in range(6):
+        ds.recs += _split_pair("s%d" % i, names, 0, 50_099, 1, 80_200, partner_flag=partner_flag)
+    ds.sort()
+    return ds
+
+
+G1_REFGENE = [
+    "0\tNM_000001\tchr1\t+\t40000\t60000\t40500\t59500\t3\t40000,50000,58000,\t41000,51000,60000,\t0\tGENEA\tcmpl\tcmpl\t0,0,0,",
+    "0\tNM_000002\tchr2\t-\t70000\t90000\t70500\t89500\t2\t70000,80100,\t71000,90000,\t0\tGENEB\tcmpl\tcmpl\t0,0,",
+]
+
+
+def make_cfg(seed: int, contigs: Sequence[Tuple[str, int]], n_records: int, n_loci: int, pairs_per_locus: int,
+             noise_pairs: int, split_every: int = 2, splits_per_locus: int = 8, jitter: int = 400,
+             read_len: int = 150, ins_mean: float = 350, ins_sd: float = 40, same_chr_frac: float = 0.3,
+             partner_flag: int = 0x100, dup_frac: float = 0.01, lowq_frac: float = 0.02) -> Dataset:
+    """BASELINE config-1 shape, scalable: `n_records` total, discordant mass concentrated in
+    `n_loci` loci x `pairs_per_locus` pairs (+- jitter) plus `noise_pairs` uniform pairs; split reads
+    (primary + `partner_flag` partner) at every `split_every`-th locus."""
+    rng = np.random.default_rng(seed)
+    names = [n for n, _ in contigs]
+    lens = [l for _, l in contigs]
+    nt = len(contigs)
+    ds = Dataset(list(contigs))
+    used = 0
+
+    def rand_site(margin=5000):
+        t = int(rng.integers(0, nt))
+        return t, int(rng.integers(margin, lens[t] - margin))
+
+    for li in range(n_loci):
+        ta, pa = rand_site()
+        if rng.random() < same_chr_frac:
+            tb = ta
+            pb = int(rng.integers(5000, lens[tb] - 5000))
+            if abs(pb - pa) < 20000:
+                pb = (pa + 50000) % (lens[tb] - 10000) + 5000
+        else:
+            tb, pb = rand_site()
+        rev_a, rev_b = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        for k in range(pairs_per_locus):
+            ja = pa + int(rng.integers(-jitter, jitter + 1))
+            jb = pb + int(rng.integers(-jitter, jitter + 1))
+            mq = 60
+            if rng.random() < lowq_frac:
+                mq = int(rng.integers(0, 20))
+            recs = _discordant_pair("L%d_%d" % (li, k), ta, ja, tb, jb, read_len, rev_a, rev_b, mq)
+            if rng.random() < dup_frac:
+                recs[0].flag |= 0x400
+            ds.recs += recs
+            used += 2
+        if split_every and li % split_every == 0:
+            for k in range(splits_per_locus):
+                ds.recs += _split_pair("S%d_%d" % (li, k), names, ta, pa + 30, tb, pb + 30, 90, 60, partner_flag)
+                used += 3
+    for i in range(noise_pairs):
+        ta, pa = rand_site()
+        tb, pb = rand_site()
+        ds.recs += _discordant_pair("N%d" % i, ta, pa, tb, pb, read_len, bool(rng.integers(0, 2)),
+                                    bool(rng.integers(0, 2)))
+        used += 2
+    n_prop = max(0, (n_records - used) // 2)
+    tids = rng.integers(0, nt, n_prop)
+    for i in range(n_prop):
+        t = int(tids[i])
+        ds.recs += _proper_pair(rng, i, t, 1000, lens[t] - 1000, read_len, ins_mean, ins_sd)
+    ds.sort()
+    return ds
