@@ -1,0 +1,164 @@
+/*
+ * breakid_hip.h — C ABI of libbreakid_hip.so, the MI355X (gfx950) implementation of BreakID's hot
+ * path: discordant-pair scan + clustering and the split-read (SA-tag / CIGAR) breakpoint scan.
+ *
+ * The reference (SinOncology/BreakID) has no plugin / FFI layer: its hot path is a chain of free
+ * functions called from main() (src/BreakID.cc:93-167).  Each entry point below replaces one link of
+ * that chain; the reference call it stands in for is cited next to it.  A reference maintainer binds
+ * them from main() as shown in INTEGRATION.md.
+ *
+ * Conventions: plain C, no exceptions across the boundary; every call returns BK_OK (0) or a negative
+ * error code and bk_last_error() gives the text.  The caller owns all inputs; the library owns every
+ * output until bk_free().  One host thread per context; the context owns one HIP stream (or uses the
+ * one given to bk_set_stream).  Record columns may live in host memory (copied to HBM by
+ * bk_upload_records) or already in HBM (BK_MEM_DEVICE: used in place, zero copy).
+ */
+#ifndef BREAKID_HIP_H
+#define BREAKID_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_OK 0
+#define BK_ERR_ARG (-1)       /* bad argument / call order */
+#define BK_ERR_HIP (-2)       /* HIP runtime error (text in bk_last_error) */
+#define BK_ERR_NO_DEVICE (-3) /* no gfx950 device / code object missing: the product never falls back to CPU */
+#define BK_ERR_UNSORTED (-4)  /* records are not coordinate sorted (the reference needs a .bai, i.e. a sorted BAM) */
+#define BK_ERR_CIGAR (-5)     /* the reference's "error cigar" exit(-1) (src/BreakID.cc:954-968) */
+#define BK_ERR_IO (-6)        /* BAM decode errors (bk_bam_*) */
+#define BK_ERR_LIMIT (-7)     /* an internal capacity was exceeded (text says which) */
+
+#define BK_MEM_HOST 0
+#define BK_MEM_DEVICE 1
+
+typedef struct bk_ctx bk_ctx;
+
+/* Columnar record table (structure of arrays).  One row per BAM alignment record, in file order.
+ * Field meaning = bam1_core_t (thirdparty/.../htslib/sam.h:148-181): pos/mpos 0-based.
+ *   cigar_off[i]..cigar_off[i+1]  BAM-encoded CIGAR words (len<<4|op) of record i
+ *   aux_off[i]..aux_off[i+1]      aux blob of record i: empty when the record has no SA:Z tag,
+ *                                 else the SA text, or  OC-text '\t' SA-text  when an OC:Z tag exists
+ *   qhash                         64-bit hash of the read name (bk_qname_hash) used for the qname joins
+ */
+typedef struct bk_soa {
+  uint64_t n;
+  const int32_t *tid, *pos, *mtid, *mpos, *isize;
+  const uint16_t *flag;
+  const uint8_t *mapq;
+  const uint64_t *qhash;
+  const uint32_t *cigar_off; /* n+1 */
+  const uint32_t *cigar;     /* cigar_off[n] words */
+  const uint32_t *aux_off;   /* n+1 */
+  const uint8_t *aux;        /* aux_off[n] bytes */
+  uint64_t n_cigar_words;    /* = cigar_off[n] (given so that device-resident tables need no read-back) */
+  uint64_t n_aux_bytes;      /* = aux_off[n] */
+} bk_soa;
+
+/* One discordant pair = the numeric content of `discordant_pair` (src/BreakID.h:39-58). */
+typedef struct bk_pair {
+  uint32_t x, y;             /* p1_chr_pos, p2_chr_pos (genome-wide, util_bam.cc:57-68) */
+  uint32_t p1_pos, p2_pos;   /* 1-based */
+  int32_t p1_tid, p2_tid;    /* chromosome of each side (-1 = "*") */
+  uint16_t p1_flag, p2_flag;
+  uint8_t p1_mapq, p2_mapq, p1_rev, p2_rev;
+  uint32_t rec;              /* index of the record that completed the pair (discovery order) */
+  uint32_t id;               /* "pair_No_<id>": index inside its group at add_enspan_point_id time */
+  int32_t cluster;           /* cluster number inside the group, -1 before clustering */
+  uint32_t group;            /* group ordinal, groups ordered like std::map<string> on "chrA_chrB" */
+} bk_pair;
+
+/* One split-read evidence tuple = numeric content of `split_align_pair` (src/BreakID.h:116-133).
+ * Chromosome names are interned (ids < n_targets are header names); CIGAR strings are carried as
+ * 64-bit hashes of their text because the reference only compares them for equality. */
+typedef struct bk_split {
+  uint32_t rec;
+  int32_t tid, pos, endpos;  /* of the record itself: 0-based pos, bam_endpos (sam.c:344-350) */
+  uint64_t qhash;
+  int32_t prim_chr, sec_chr;
+  uint32_t prim_start, prim_end, prim_bp, sec_start, sec_end, sec_bp;
+  uint64_t prim_cigar, sec_cigar;
+  uint32_t flags;            /* bit0 = secondary (flag & 0x100); bit1 = "error cigar" record */
+  uint32_t pad;
+} bk_split;
+
+#define BK_TYPE_DIFF_CHR 1u
+#define BK_TYPE_SAME_ORIENT 2u
+#define BK_TYPE_ABS_REVERSE 4u
+#define BK_TYPE_DEFAULT_ORIENT 8u
+
+/* One cluster = numeric content of `cluster_info` (src/BreakID.h:60-113) that the txt writer needs. */
+typedef struct bk_cluster {
+  uint32_t group;
+  int32_t id;
+  int32_t p1_tid, p2_tid;
+  uint32_t p1_mean, p2_mean, p1_min, p1_max, p2_min, p2_max;
+  uint32_t p1_exact;
+  int32_t p2_exact;
+  uint32_t n_drp, n_sr;
+  uint32_t depth1, depth2;
+  uint32_t type_mask;        /* BK_TYPE_* : drp_type_set */
+  uint32_t flags;            /* bit0 passed the near-diagonal filter (:348); bit1 valid (:446) */
+} bk_cluster;
+
+/* stage ids for bk_fetch */
+#define BK_STAGE_SCAN 0      /* bk_pair[]  after scan_discordant_pairs, grouped            */
+#define BK_STAGE_ISO 1       /* bk_pair[]  after remove_isolated_pairs                     */
+#define BK_STAGE_CLUSTERED 2 /* bk_pair[]  after find_cluster_pairs_enspan_{fast,ahc}      */
+#define BK_STAGE_SPLITS 3    /* bk_split[] every accepted split-evidence tuple, record order */
+#define BK_STAGE_CLUSTERS 4  /* bk_cluster[] every cluster that passed :348, group/id order */
+#define BK_STAGE_GROUP_KEYS 5 /* int32 pairs (p1_tid,p2_tid) per group ordinal               */
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* Replaces: samopen + header parsing (BreakID.cc:1391,1410).  target_name[i] NUL-terminated. */
+int bk_init(int device, const uint32_t *target_len, const char *const *target_name, int n_targets, bk_ctx **out);
+void bk_free(bk_ctx *ctx);
+const char *bk_last_error(const bk_ctx *ctx); /* ctx may be NULL: error of the failed bk_init */
+int bk_set_stream(bk_ctx *ctx, void *hip_stream); /* optional: run on the caller's hipStream_t */
+int bk_sync(bk_ctx *ctx);
+
+/* Replaces: the two sequential BAM passes' record access (BreakID.cc:1414, :1929). */
+int bk_upload_records(bk_ctx *ctx, const bk_soa *cols, int mem_space);
+
+/* ---- stages (call in this order) ------------------------------------------------------------ */
+/* get_mean_insert_size (BreakID.cc:1909-1954): bit-exact mean and sd. */
+int bk_isize_stats(bk_ctx *ctx, double *mean, double *sd);
+/* scan_discordant_pairs (BreakID.cc:1362-1515): filter, qname mate join, grouping. */
+int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, uint32_t *n_groups);
+/* remove_isolated_pairs (:1271) + find_cluster_pairs_enspan_fast (:1046) or _ahc (:1304), all groups. */
+int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered);
+/* per-read SA-tag/CIGAR evidence of find_sa_reads (:892-1030) for every record, once. */
+int bk_split_evidence(bk_ctx *ctx, uint64_t *n_tuples);
+/* findClusterBreakPointInfoSaTag summary part (:225-352). */
+int bk_cluster_summary(bk_ctx *ctx, double w, uint64_t *n_clusters);
+/* findEncompassingReadsAndBreakPointInfo (:390-490): region select, find_bp_pair, depth, type. */
+int bk_split_breakpoints(bk_ctx *ctx, double w, uint64_t *n_valid);
+
+/* Whole hot path = body of main() between BreakID.cc:98 and :167 (annotation excluded).
+ * w_out receives times*sqrt(times)*(mean+3sd) (:103). */
+int bk_run(bk_ctx *ctx, int mapq_min, int fast, double *w_out, uint64_t *n_valid);
+
+/* Copy a stage's result to library-owned host memory.  *data stays valid until the next bk_fetch
+ * of the same stage or bk_free.  group_off (may be NULL) receives n_groups+1 offsets for pair stages. */
+int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const uint64_t **group_off, uint32_t *n_groups);
+
+/* per-kernel timing of the last stage calls: name/ms pairs, for bench.py's roofline leg */
+int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const uint64_t **bytes, int *n);
+int bk_timing_enable(bk_ctx *ctx, int on);
+
+/* ---- host feed (C++ BGZF/BAM decoder -> pinned SoA); replaces htslib's reader for this path --- */
+typedef struct bk_bam bk_bam;
+uint64_t bk_qname_hash(const char *name, size_t len);
+int bk_bam_open(const char *path, bk_bam **out, char *err, size_t errlen);
+int bk_bam_header(const bk_bam *b, int *n_targets, const char *const **names, const uint32_t **lens);
+/* decode all records into a SoA owned by the bk_bam (pinned when a GPU is present) */
+int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen);
+void bk_bam_close(bk_bam *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
