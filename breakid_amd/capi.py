@@ -1,0 +1,229 @@
+"""ctypes binding of libbreakid_hip.so (include/breakid_hip.h).  The host-side mirror of the
+reference's stage functions: names and argument meaning follow BreakID.cc's free functions
+(get_mean_insert_size, scan_discordant_pairs, remove_isolated_pairs + find_cluster_pairs_enspan_*,
+findClusterBreakPointInfoSaTag).  There is NO CPU fallback: without the built extension or without a
+gfx950 device every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbreakid_hip.so")
+_LIB = None
+
+
+class BreakIDError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbreakid_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    r = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libbreakid_hip.so failed:\n" + (r.stdout or "")[-4000:] + (r.stderr or "")[-4000:])
+
+
+EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
+           "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
+           "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise BreakIDError(abi.BK_ERR_NO_DEVICE, "libbreakid_hip.so is not built (run __graft_entry__.build()); "
+                                                     "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, u64p, dp = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+        L.bk_init.argtypes = [C.c_int, vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
+        L.bk_free.argtypes = [vp]
+        L.bk_last_error.restype = C.c_char_p
+        L.bk_last_error.argtypes = [vp]
+        L.bk_set_stream.argtypes = [vp, vp]
+        L.bk_sync.argtypes = [vp]
+        L.bk_upload_records.argtypes = [vp, C.POINTER(abi.Soa), C.c_int]
+        L.bk_isize_stats.argtypes = [vp, dp, dp]
+        L.bk_discordant_pairs.argtypes = [vp, C.c_int, C.c_double, u64p, C.POINTER(C.c_uint32)]
+        L.bk_mask_and_cluster.argtypes = [vp, C.c_double, C.c_int, u64p]
+        L.bk_split_evidence.argtypes = [vp, u64p]
+        L.bk_cluster_summary.argtypes = [vp, C.c_double, u64p]
+        L.bk_split_breakpoints.argtypes = [vp, C.c_double, u64p]
+        L.bk_run.argtypes = [vp, C.c_int, C.c_int, dp, u64p]
+        L.bk_fetch.argtypes = [vp, C.c_int, C.POINTER(vp), u64p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
+        L.bk_timing.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
+                                C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]
+        L.bk_timing_enable.argtypes = [vp, C.c_int]
+        L.bk_qname_hash.restype = C.c_uint64
+        L.bk_qname_hash.argtypes = [C.c_char_p, C.c_size_t]
+        L.bk_bam_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.bk_bam_header.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint32))]
+        L.bk_bam_decode.argtypes = [vp, C.POINTER(abi.Soa), C.c_char_p, C.c_size_t]
+        L.bk_bam_close.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def w_from(mean, sd):
+    times = 2
+    return times * math.sqrt(times) * (mean + 3 * sd)  # BreakID.cc:103
+
+
+class Context:
+    """One GPU context = the state the reference keeps in main() between BreakID.cc:93 and :167."""
+
+    def __init__(self, contigs, device=0):
+        self.L = lib()
+        self.contigs = list(contigs)
+        lens = np.asarray([l for _, l in contigs], dtype=np.uint32)
+        names = (C.c_char_p * len(contigs))(*[n.encode() for n, _ in contigs])
+        h = C.c_void_p()
+        rc = self.L.bk_init(device, lens.ctypes.data, names, len(contigs), C.byref(h))
+        if rc != 0:
+            raise BreakIDError(rc, (self.L.bk_last_error(None) or b"").decode())
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.L.bk_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BreakIDError(rc, (self.L.bk_last_error(self.h) or b"").decode())
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self.L.bk_set_stream(self.h, C.c_void_p(hip_stream_handle)))
+
+    def sync(self):
+        self._check(self.L.bk_sync(self.h))
+
+    def upload(self, cols):
+        """cols: dict of numpy arrays (host) laid out as abi.SOA_COLS."""
+        cols = {k: np.ascontiguousarray(cols[k], dtype=dt) for k, dt in abi.SOA_COLS}
+        for k in ("cigar", "aux"):
+            if cols[k].size == 0:
+                cols[k] = np.zeros(1, cols[k].dtype)
+        soa = abi.soa_from_numpy(cols)
+        self._keep = (cols, soa)
+        self._check(self.L.bk_upload_records(self.h, C.byref(soa), abi.BK_MEM_HOST))
+
+    def attach_device(self, ptrs, n, n_cigar_words, n_aux_bytes):
+        """ptrs: dict name -> device pointer (int) of columns already resident in HBM."""
+        s = abi.Soa()
+        s.n = n
+        for name, _ in abi.SOA_COLS:
+            setattr(s, name, ptrs[name])
+        s.n_cigar_words = n_cigar_words
+        s.n_aux_bytes = n_aux_bytes
+        self._keep = (ptrs, s)
+        self._check(self.L.bk_upload_records(self.h, C.byref(s), abi.BK_MEM_DEVICE))
+
+    def isize_stats(self):
+        m, s = C.c_double(), C.c_double()
+        self._check(self.L.bk_isize_stats(self.h, C.byref(m), C.byref(s)))
+        return m.value, s.value
+
+    def discordant_pairs(self, qual, w):
+        n, g = C.c_uint64(), C.c_uint32()
+        self._check(self.L.bk_discordant_pairs(self.h, qual, w, C.byref(n), C.byref(g)))
+        return n.value, g.value
+
+    def mask_and_cluster(self, w, fast):
+        n = C.c_uint64()
+        self._check(self.L.bk_mask_and_cluster(self.h, w, int(fast), C.byref(n)))
+        return n.value
+
+    def split_evidence(self):
+        n = C.c_uint64()
+        self._check(self.L.bk_split_evidence(self.h, C.byref(n)))
+        return n.value
+
+    def cluster_summary(self, w):
+        n = C.c_uint64()
+        self._check(self.L.bk_cluster_summary(self.h, w, C.byref(n)))
+        return n.value
+
+    def split_breakpoints(self, w, count=True):
+        n = C.c_uint64()
+        self._check(self.L.bk_split_breakpoints(self.h, w, C.byref(n) if count else None))
+        return n.value
+
+    def run(self, qual=20, fast=True):
+        w, n = C.c_double(), C.c_uint64()
+        self._check(self.L.bk_run(self.h, qual, int(fast), C.byref(w), C.byref(n)))
+        return w.value, n.value
+
+    def fetch(self, stage):
+        def fn(h, st, d, c, g, ng):
+            return self.L.bk_fetch(h, st, d, c, g, ng)
+        try:
+            return abi.fetch_array(self.L, self.h, fn, stage)
+        except RuntimeError:
+            self._check(-1 if not self.L.bk_last_error(self.h) else abi.BK_ERR_ARG)
+            raise
+
+    def timing_enable(self, on=True):
+        self._check(self.L.bk_timing_enable(self.h, int(on)))
+
+    def timing(self):
+        names = C.POINTER(C.c_char_p)()
+        ms = C.POINTER(C.c_float)()
+        by = C.POINTER(C.c_uint64)()
+        n = C.c_int()
+        self._check(self.L.bk_timing(self.h, C.byref(names), C.byref(ms), C.byref(by), C.byref(n)))
+        return [(names[i].decode(), float(ms[i]), int(by[i])) for i in range(n.value)]
+
+
+def decode_bam(path):
+    """C++ BGZF/BAM decoder -> (contigs, SoA dict of numpy copies)."""
+    L = lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.bk_bam_open(path.encode(), C.byref(h), err, 512)
+    if rc != 0:
+        raise BreakIDError(rc, err.value.decode())
+    try:
+        nt = C.c_int()
+        names = C.POINTER(C.c_char_p)()
+        lens = C.POINTER(C.c_uint32)()
+        L.bk_bam_header(h, C.byref(nt), C.byref(names), C.byref(lens))
+        contigs = [(names[i].decode(), int(lens[i])) for i in range(nt.value)]
+        s = abi.Soa()
+        rc = L.bk_bam_decode(h, C.byref(s), err, 512)
+        if rc != 0:
+            raise BreakIDError(rc, err.value.decode())
+        n = s.n
+        sizes = {"cigar_off": n + 1, "aux_off": n + 1, "cigar": max(1, s.n_cigar_words), "aux": max(1, s.n_aux_bytes)}
+        cols = {}
+        for name, dt in abi.SOA_COLS:
+            cnt = sizes.get(name, n)
+            ptr = getattr(s, name)
+            if cnt == 0 or not ptr:
+                cols[name] = np.zeros(0, dt)
+                continue
+            buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
+            cols[name] = np.frombuffer(buf, dtype=dt, count=cnt).copy()
+        cols["cigar"] = cols["cigar"][: s.n_cigar_words]
+        cols["aux"] = cols["aux"][: s.n_aux_bytes]
+        return contigs, cols
+    finally:
+        L.bk_bam_close(h)

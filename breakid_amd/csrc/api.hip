@@ -1,0 +1,658 @@
+// C ABI of libbreakid_hip.so (include/breakid_hip.h): context, record upload, stage drivers, fetch.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "bk_common.h"
+#include "prims.h"
+#include "stream.h"
+#include "join.h"
+#include "cluster.h"
+#include "bp.h"
+#include "ahc.h"
+
+namespace
+{
+thread_local std::string g_init_error;
+
+uint64_t fnv64(const std::string &s)
+{
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (unsigned char c : s)
+  {
+    h ^= c;
+    h *= 0x100000001B3ull;
+  }
+  return h;
+}
+std::string chrom_id_to_name(int tid)  // util_bam.cc:128-142
+{
+  if (tid == 23) return "chrY";
+  if (tid == 22) return "chrX";
+  if (tid >= 0 && tid < 22) return "chr" + std::to_string(tid + 1);
+  return "";
+}
+
+struct StageTimer
+{
+  std::string name;
+  hipEvent_t a = nullptr, b = nullptr;
+  uint64_t bytes = 0;
+};
+}  // namespace
+
+struct bk_ctx
+{
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = true;
+  std::string err;
+  int nt = 0;
+  std::vector<uint32_t> tlen;
+  std::vector<std::string> tname;
+  std::vector<int32_t> hdr_id_host;
+  DevBuf d_tprefix, d_nhash, d_nid, d_own, d_hdr;
+  NameTableDev names{};
+
+  // records
+  bk_soa rec{};
+  DevBuf col[12];
+  bool have_records = false;
+
+  // stream pass
+  DevBuf d_counters, d_sd, d_cand, d_split_raw, d_split;
+  StreamCounters hc{};
+  SdState hsd{};
+  bool stream_done = false, splits_sorted = false;
+  int mapq_min = 20;
+  uint64_t cand_cap = 0, split_cap = 0;
+  SdBufs sdb;
+  double mean = 0, sd = 0;
+  bool stats_done = false;
+
+  // join
+  JoinBufs jb;
+  JoinResult jr;
+  std::vector<uint32_t> gkey_host, glex_host, lex_to_num;
+  std::vector<uint64_t> gstart_host;
+  DevBuf d_glex;
+
+  // mask + cluster
+  ClusterBufs cb;
+  PairList list;
+  DevBuf iso_idx, iso_goff, d_cluster;
+  uint64_t iso_n = 0;
+  bool clustered = false;
+  AhcBufs ab;
+
+  // summary + breakpoints
+  BpBufs bb;
+  DevBuf d_clusters;
+  uint64_t n_clusters = 0;
+
+  // fetch staging
+  std::vector<bk_pair> f_pairs[3];
+  std::vector<uint64_t> f_off[3];
+  std::vector<bk_split> f_splits;
+  std::vector<bk_cluster> f_clusters;
+  std::vector<int32_t> f_gkeys;
+
+  // timing
+  bool timing = false;
+  std::vector<StageTimer> timers;
+  Timing tout;
+
+  void tick(const char *name, uint64_t bytes, bool begin)
+  {
+    if (!timing) return;
+    if (begin)
+    {
+      StageTimer t;
+      t.name = name;
+      t.bytes = bytes;
+      HIP_CHECK(hipEventCreate(&t.a));
+      HIP_CHECK(hipEventCreate(&t.b));
+      HIP_CHECK(hipEventRecord(t.a, st));
+      timers.push_back(t);
+    }
+    else
+      HIP_CHECK(hipEventRecord(timers.back().b, st));
+  }
+};
+
+namespace
+{
+struct Scope
+{
+  bk_ctx *c;
+  Scope(bk_ctx *c, const char *name, uint64_t bytes = 0) : c(c) { c->tick(name, bytes, true); }
+  ~Scope()
+  {
+    try
+    {
+      c->tick("", 0, false);
+    }
+    catch (...)
+    {
+    }
+  }
+};
+
+template <class F> int guarded(bk_ctx *ctx, F &&f)
+{
+  if (!ctx) return BK_ERR_ARG;
+  try
+  {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    f();
+    return BK_OK;
+  }
+  catch (const bk_error &e)
+  {
+    ctx->err = e.msg;
+    return e.code;
+  }
+  catch (const std::exception &e)
+  {
+    ctx->err = e.what();
+    return BK_ERR_HIP;
+  }
+}
+
+void build_name_tables(bk_ctx *c)
+{
+  const int nt = c->nt;
+  std::map<std::string, int> ids;
+  for (int i = 0; i < nt; ++i)
+    if (!ids.count(c->tname[i])) ids[c->tname[i]] = i;
+  if (!ids.count("")) ids[""] = nt;
+  if (!ids.count("*")) ids["*"] = nt + 1;
+  for (int t = 0; t < 24; ++t)
+  {
+    std::string s = chrom_id_to_name(t);
+    if (!ids.count(s)) ids[s] = nt + 2 + t;
+  }
+  uint32_t cap = 64;
+  while (cap < ids.size() * 4) cap <<= 1;
+  std::vector<uint64_t> hash(cap, 0);
+  std::vector<int32_t> idv(cap, -1);
+  for (auto &kv : ids)
+  {
+    uint64_t h = fnv64(kv.first);
+    if (h == 0) h = 1;
+    uint32_t slot = (uint32_t) h & (cap - 1);
+    while (hash[slot] != 0 && hash[slot] != h) slot = (slot + 1) & (cap - 1);
+    if (hash[slot] == 0)
+    {
+      hash[slot] = h;
+      idv[slot] = kv.second;
+    }
+  }
+  std::vector<int32_t> own(std::max(nt, 1));
+  for (int t = 0; t < nt; ++t) own[t] = ids[chrom_id_to_name(t)];
+  c->hdr_id_host.assign(nt + 1, 0);
+  c->hdr_id_host[0] = ids["*"];
+  for (int t = 0; t < nt; ++t) c->hdr_id_host[t + 1] = ids[c->tname[t]];
+  std::vector<uint32_t> prefix(nt + 1, 0);
+  for (int t = 0; t < nt; ++t) prefix[t + 1] = prefix[t] + c->tlen[t];
+  HIP_CHECK(hipMemcpy(c->d_nhash.as<uint64_t>(cap), hash.data(), cap * 8, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(c->d_nid.as<int32_t>(cap), idv.data(), cap * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(c->d_own.as<int32_t>(own.size()), own.data(), own.size() * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(c->d_hdr.as<int32_t>(nt + 1), c->hdr_id_host.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(c->d_tprefix.as<uint32_t>(nt + 1), prefix.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+  c->names.hash = c->d_nhash.get<uint64_t>();
+  c->names.id = c->d_nid.get<int32_t>();
+  c->names.mask = cap - 1;
+  c->names.own_id = c->d_own.get<int32_t>();
+  c->names.n_targets = nt;
+  c->names.empty_id = ids[""];
+}
+
+std::string rname(const bk_ctx *c, int tid) { return tid < 0 ? "*" : c->tname[tid]; }
+
+void run_stream(bk_ctx *c)
+{
+  if (!c->have_records) throw bk_error(BK_ERR_ARG, "no records uploaded");
+  const uint64_t n = c->rec.n;
+  if (c->cand_cap == 0) c->cand_cap = std::max<uint64_t>(1u << 16, n / 8 + 1024);
+  if (c->split_cap == 0) c->split_cap = std::max<uint64_t>(1u << 14, n / 16 + 1024);
+  for (int attempt = 0; attempt < 3; ++attempt)
+  {
+    StreamCounters *dc = c->d_counters.as<StreamCounters>(1);
+    SdState *dsd = c->d_sd.as<SdState>(1);
+    HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(StreamCounters), c->st));
+    HIP_CHECK(hipMemsetAsync(dsd, 0, sizeof(SdState), c->st));
+    StreamArgs a{};
+    a.n = n;
+    a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
+    a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash;
+    a.cigar_off = c->rec.cigar_off; a.cigar = c->rec.cigar; a.aux_off = c->rec.aux_off; a.aux = c->rec.aux;
+    a.mapq_min = c->mapq_min;
+    a.names = c->names;
+    a.counters = dc;
+    a.sd = dsd;
+    a.cand = c->d_cand.as<Cand>(c->cand_cap);
+    a.cand_cap = c->cand_cap;
+    a.split = c->d_split_raw.as<bk_split>(c->split_cap);
+    a.split_cap = c->split_cap;
+    {
+      // algorithmic bytes of this pass: 39 B/record + CIGAR words + aux bytes (+ outputs, added after)
+      Scope s(c, "k_stream", 39ull * n + 4ull * c->rec.n_cigar_words + c->rec.n_aux_bytes);
+      launch_stream(a, c->st);
+    }
+    HIP_CHECK(hipMemcpyAsync(&c->hc, dc, sizeof(StreamCounters), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipMemcpyAsync(&c->hsd, dsd, sizeof(SdState), hipMemcpyDeviceToHost, c->st));
+    HIP_CHECK(hipStreamSynchronize(c->st));
+    if (c->hc.n_cand <= c->cand_cap && c->hc.n_split <= c->split_cap) break;
+    if (c->timing && !c->timers.empty()) c->timers.pop_back();  // overflowed attempt is not a measured pass
+    c->cand_cap = std::max<uint64_t>(c->cand_cap, c->hc.n_cand + 1024);
+    c->split_cap = std::max<uint64_t>(c->split_cap, c->hc.n_split + 1024);
+    if (attempt == 2) throw bk_error(BK_ERR_LIMIT, "stream pass: output capacity");
+  }
+  if (c->timing && !c->timers.empty()) c->timers.back().bytes += 32ull * c->hc.n_cand + 48ull * c->hc.n_split;
+  if (c->hc.unsorted) throw bk_error(BK_ERR_UNSORTED, "records are not coordinate sorted (the reference requires an indexed, sorted BAM)");
+  c->stream_done = true;
+  c->splits_sorted = false;
+  c->stats_done = false;
+}
+
+void ensure_splits_sorted(bk_ctx *c)
+{
+  if (c->splits_sorted) return;
+  Scope s(c, "split_sort");
+  bk_split *sorted = c->d_split.as<bk_split>(c->hc.n_split + 1);
+  sort_splits(c->d_split_raw.get<bk_split>(), c->hc.n_split, sorted, c->bb, c->st);
+  c->splits_sorted = true;
+}
+}  // namespace
+
+extern "C" {
+
+int bk_init(int device, const uint32_t *target_len, const char *const *target_name, int n_targets, bk_ctx **out)
+{
+  if (!out || n_targets < 0 || (n_targets && (!target_len || !target_name)))
+  {
+    g_init_error = "bk_init: bad arguments";
+    return BK_ERR_ARG;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+  {
+    g_init_error = "bk_init: no HIP device " + std::to_string(device) + " (this library has no CPU path)";
+    return BK_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+  {
+    g_init_error = std::string("bk_init: device is not gfx950 (") + prop.gcnArchName + "); kernels are built for MI355X only";
+    return BK_ERR_NO_DEVICE;
+  }
+  bk_ctx *c = new bk_ctx();
+  c->device = device;
+  c->nt = n_targets;
+  for (int i = 0; i < n_targets; ++i)
+  {
+    c->tlen.push_back(target_len[i]);
+    c->tname.push_back(target_name[i]);
+  }
+  int rc = guarded(c, [&] {
+    HIP_CHECK(hipStreamCreate(&c->st));
+    build_name_tables(c);
+  });
+  if (rc != BK_OK)
+  {
+    g_init_error = c->err;
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return BK_OK;
+}
+
+void bk_free(bk_ctx *ctx)
+{
+  if (!ctx) return;
+  (void) hipSetDevice(ctx->device);
+  (void) hipStreamSynchronize(ctx->st);
+  for (auto &t : ctx->timers)
+  {
+    if (t.a) (void) hipEventDestroy(t.a);
+    if (t.b) (void) hipEventDestroy(t.b);
+  }
+  if (ctx->own_stream && ctx->st) (void) hipStreamDestroy(ctx->st);
+  delete ctx;
+}
+
+const char *bk_last_error(const bk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int bk_set_stream(bk_ctx *ctx, void *hip_stream)
+{
+  return guarded(ctx, [&] {
+    if (ctx->own_stream && ctx->st) HIP_CHECK(hipStreamDestroy(ctx->st));
+    ctx->st = (hipStream_t) hip_stream;
+    ctx->own_stream = false;
+  });
+}
+int bk_sync(bk_ctx *ctx)
+{
+  return guarded(ctx, [&] { HIP_CHECK(hipStreamSynchronize(ctx->st)); });
+}
+
+int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
+{
+  return guarded(ctx, [&] {
+    if (!s) throw bk_error(BK_ERR_ARG, "bk_upload_records: null table");
+    if (s->n > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records in one context (shard across GPUs)");
+    ctx->stream_done = ctx->stats_done = ctx->clustered = false;
+    if (mem_space == BK_MEM_DEVICE)
+    {
+      ctx->rec = *s;
+    }
+    else
+    {
+      const uint64_t n = s->n;
+      const void *src[12] = {s->tid, s->pos, s->mtid, s->mpos, s->isize, s->flag, s->mapq, s->qhash, s->cigar_off, s->cigar, s->aux_off, s->aux};
+      const size_t bytes[12] = {n * 4, n * 4, n * 4, n * 4, n * 4, n * 2, n, n * 8, (n + 1) * 4, s->n_cigar_words * 4, (n + 1) * 4, s->n_aux_bytes};
+      void *dst[12];
+      for (int k = 0; k < 12; ++k)
+      {
+        dst[k] = ctx->col[k].ensure(bytes[k] + 16);
+        if (bytes[k]) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->st));
+      }
+      HIP_CHECK(hipStreamSynchronize(ctx->st));
+      bk_soa d = *s;
+      d.tid = (const int32_t *) dst[0]; d.pos = (const int32_t *) dst[1]; d.mtid = (const int32_t *) dst[2]; d.mpos = (const int32_t *) dst[3];
+      d.isize = (const int32_t *) dst[4]; d.flag = (const uint16_t *) dst[5]; d.mapq = (const uint8_t *) dst[6]; d.qhash = (const uint64_t *) dst[7];
+      d.cigar_off = (const uint32_t *) dst[8]; d.cigar = (const uint32_t *) dst[9]; d.aux_off = (const uint32_t *) dst[10]; d.aux = (const uint8_t *) dst[11];
+      ctx->rec = d;
+    }
+    ctx->have_records = true;
+  });
+}
+
+int bk_isize_stats(bk_ctx *ctx, double *mean, double *sd)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done) run_stream(ctx);
+    if (!ctx->stats_done)
+    {
+      const double n = (double) ctx->hc.isize_n;
+      const double m = (double) (long long) ctx->hc.isize_sum / n;  // (double) long / (double) size_t, BreakID.cc:1941
+      ctx->mean = m;
+      if (ctx->hc.isize_n == 0)
+        ctx->sd = std::nan("");
+      else
+      {
+        double sum_d = ctx->hsd.sumsq - 2.0 * m * (double) ctx->hc.isize_sum + n * m * m;
+        if (!(sum_d > 0)) sum_d = 0;
+        double da = (double) ctx->hsd.vmax - m, dmax = da * da + m * m;
+        double bound = 2.0 * sum_d + 2.0 * n + 2.0 * dmax + 4.0;
+        int k = std::ilogb(bound) + 1;
+        double thr = k >= 51 ? 1.0e300 : std::ldexp(1.0, k - 53);
+        {
+          Scope s(ctx, "isize_sd", 6ull * ctx->rec.n);
+          launch_sd(ctx->rec.flag, ctx->rec.isize, ctx->rec.n, m, thr, ctx->d_sd.get<SdState>(), ctx->sdb, ctx->st);
+        }
+        HIP_CHECK(hipMemcpyAsync(&ctx->hsd, ctx->d_sd.get<SdState>(), sizeof(SdState), hipMemcpyDeviceToHost, ctx->st));
+        HIP_CHECK(hipStreamSynchronize(ctx->st));
+        ctx->sd = std::sqrt((double) ctx->hsd.t_final / n);  // sqrt(long / (double) size), :1946
+      }
+      ctx->stats_done = true;
+    }
+    if (mean) *mean = ctx->mean;
+    if (sd) *sd = ctx->sd;
+  });
+}
+
+int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, uint32_t *n_groups)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done || mapq_min != ctx->mapq_min)
+    {
+      ctx->mapq_min = mapq_min;
+      run_stream(ctx);
+    }
+    {
+      Scope s(ctx, "mate_join");
+      join_candidates(ctx->d_cand.get<Cand>(), ctx->hc.n_cand, w, ctx->d_tprefix.get<uint32_t>(), ctx->nt, ctx->jb, ctx->st, ctx->jr);
+    }
+    const uint32_t ng = ctx->jr.n_groups;
+    ctx->gkey_host.assign(ng, 0);
+    ctx->gstart_host.assign(ng + 1, 0);
+    if (ng)
+    {
+      HIP_CHECK(hipMemcpyAsync(ctx->gkey_host.data(), ctx->jr.gkey, ng * 4, hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipMemcpyAsync(ctx->gstart_host.data(), ctx->jr.gstart, (ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipStreamSynchronize(ctx->st));
+    }
+    // the reference iterates groups in std::map<string> order of "chrA_chrB" (BreakID.cc:93,119)
+    std::vector<std::string> keys(ng);
+    for (uint32_t g = 0; g < ng; ++g)
+    {
+      int t1 = (int) (ctx->gkey_host[g] / (uint32_t) (ctx->nt + 1)) - 1, t2 = (int) (ctx->gkey_host[g] % (uint32_t) (ctx->nt + 1)) - 1;
+      keys[g] = rname(ctx, t1) + "_" + rname(ctx, t2);
+    }
+    ctx->lex_to_num.resize(ng);
+    std::iota(ctx->lex_to_num.begin(), ctx->lex_to_num.end(), 0u);
+    std::sort(ctx->lex_to_num.begin(), ctx->lex_to_num.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    ctx->glex_host.assign(ng, 0);
+    for (uint32_t l = 0; l < ng; ++l) ctx->glex_host[ctx->lex_to_num[l]] = l;
+    uint32_t *dg = ctx->d_glex.as<uint32_t>((uint64_t) ng + 1);
+    if (ng) HIP_CHECK(hipMemcpyAsync(dg, ctx->glex_host.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
+    join_assign_ids(ctx->jr, dg, ctx->st);
+    ctx->clustered = false;
+    if (n_pairs) *n_pairs = ctx->jr.n_pairs;
+    if (n_groups) *n_groups = ng;
+  });
+}
+
+int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
+{
+  return guarded(ctx, [&] {
+    {
+      Scope s(ctx, "remove_isolated");
+      remove_isolated_all(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ctx->jr.n_groups, ctx->jr.n_pairs, w, ctx->list, ctx->cb, ctx->st);
+    }
+    ctx->iso_n = ctx->list.n;
+    uint32_t *ii = ctx->iso_idx.as<uint32_t>(ctx->list.n + 1);
+    uint64_t *ig = ctx->iso_goff.as<uint64_t>((uint64_t) ctx->list.ng + 1);
+    if (ctx->list.n) HIP_CHECK(hipMemcpyAsync(ii, ctx->list.idx.get<uint32_t>(), ctx->list.n * 4, hipMemcpyDeviceToDevice, ctx->st));
+    if (ctx->list.ng) HIP_CHECK(hipMemcpyAsync(ig, ctx->list.goff.get<uint64_t>(), ((uint64_t) ctx->list.ng + 1) * 8, hipMemcpyDeviceToDevice, ctx->st));
+    {
+      Scope s(ctx, fast ? "fast_cluster" : "ahc_cluster");
+      if (fast)
+        fast_cluster_all(ctx->jr.pairs, ctx->list, w, ctx->d_cluster, ctx->cb, ctx->st);
+      else
+        ahc_cluster_all(ctx->jr.pairs, ctx->list, w, ctx->d_cluster, ctx->ab, ctx->cb, ctx->st);
+    }
+    ctx->clustered = true;
+    if (n_clustered) *n_clustered = ctx->list.n;
+  });
+}
+
+int bk_split_evidence(bk_ctx *ctx, uint64_t *n_tuples)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done) run_stream(ctx);
+    ensure_splits_sorted(ctx);
+    if (n_tuples) *n_tuples = ctx->hc.n_split;
+  });
+}
+
+int bk_cluster_summary(bk_ctx *ctx, double w, uint64_t *n_clusters)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->clustered) throw bk_error(BK_ERR_ARG, "bk_cluster_summary: call bk_mask_and_cluster first");
+    Scope s(ctx, "cluster_summary");
+    ctx->n_clusters = cluster_summary(ctx->jr.pairs, ctx->list.idx.get<uint32_t>(), ctx->list.gof.get<uint32_t>(), ctx->d_cluster.get<uint32_t>(), ctx->list.n,
+                                      ctx->list.ng, ctx->jr.gkey, ctx->d_glex.get<uint32_t>(), ctx->nt, w, ctx->d_clusters, ctx->bb, ctx->st);
+    if (n_clusters) *n_clusters = ctx->n_clusters;
+  });
+}
+
+int bk_split_breakpoints(bk_ctx *ctx, double w, uint64_t *n_valid)
+{
+  return guarded(ctx, [&] {
+    ensure_splits_sorted(ctx);
+    RecView r;
+    r.n = ctx->rec.n;
+    r.tid = ctx->rec.tid; r.pos = ctx->rec.pos; r.flag = ctx->rec.flag; r.mapq = ctx->rec.mapq;
+    r.cigar_off = ctx->rec.cigar_off; r.cigar = ctx->rec.cigar;
+    {
+      Scope s(ctx, "split_breakpoints");
+      split_breakpoints(r, ctx->d_split.get<bk_split>(), ctx->hc.n_split, ctx->d_clusters.get<bk_cluster>(), ctx->n_clusters, w, (int) ctx->hc.max_span,
+                        ctx->d_hdr.get<int32_t>(), ctx->bb, ctx->st);
+    }
+    if (n_valid)
+    {
+      const void *d;
+      uint64_t cnt;
+      int rc = bk_fetch(ctx, BK_STAGE_CLUSTERS, &d, &cnt, nullptr, nullptr);
+      if (rc != BK_OK) throw bk_error(rc, ctx->err);
+      uint64_t v = 0;
+      for (auto &c : ctx->f_clusters) v += (c.flags & 2u) ? 1 : 0;
+      *n_valid = v;
+    }
+  });
+}
+
+int bk_run(bk_ctx *ctx, int mapq_min, int fast, double *w_out, uint64_t *n_valid)
+{
+  if (!ctx) return BK_ERR_ARG;
+  ctx->mapq_min = mapq_min;
+  double mean, sd;
+  int rc = bk_isize_stats(ctx, &mean, &sd);
+  if (rc) return rc;
+  const int times = 2;
+  const double w = times * std::sqrt(times) * (mean + 3 * sd);  // BreakID.cc:103
+  if (w_out) *w_out = w;
+  if ((rc = bk_discordant_pairs(ctx, mapq_min, w, nullptr, nullptr))) return rc;
+  if ((rc = bk_mask_and_cluster(ctx, w, fast, nullptr))) return rc;
+  if ((rc = bk_split_evidence(ctx, nullptr))) return rc;
+  if ((rc = bk_cluster_summary(ctx, w, nullptr))) return rc;
+  if ((rc = bk_split_breakpoints(ctx, w, n_valid))) return rc;
+  return BK_OK;
+}
+
+int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const uint64_t **group_off, uint32_t *n_groups)
+{
+  return guarded(ctx, [&] {
+    if (!data || !count) throw bk_error(BK_ERR_ARG, "bk_fetch: null output");
+    const uint32_t ng = ctx->jr.n_groups;
+    if (group_off) *group_off = nullptr;
+    if (n_groups) *n_groups = 0;
+    auto fetch_list = [&](int slot, const uint32_t *d_idx, const uint64_t *d_goff, const uint32_t *d_cl, uint64_t n) {
+      std::vector<bk_pair> all(ctx->jr.n_pairs);
+      if (!all.empty()) HIP_CHECK(hipMemcpyAsync(all.data(), ctx->jr.pairs, all.size() * sizeof(bk_pair), hipMemcpyDeviceToHost, ctx->st));
+      std::vector<uint32_t> idx(n), cl(d_cl ? n : 0);
+      std::vector<uint64_t> goff(ng + 1, 0);
+      if (n && d_idx) HIP_CHECK(hipMemcpyAsync(idx.data(), d_idx, n * 4, hipMemcpyDeviceToHost, ctx->st));
+      if (n && d_cl) HIP_CHECK(hipMemcpyAsync(cl.data(), d_cl, n * 4, hipMemcpyDeviceToHost, ctx->st));
+      if (ng && d_goff) HIP_CHECK(hipMemcpyAsync(goff.data(), d_goff, (ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipStreamSynchronize(ctx->st));
+      auto &out = ctx->f_pairs[slot];
+      auto &off = ctx->f_off[slot];
+      out.clear();
+      off.assign(1, 0);
+      for (uint32_t l = 0; l < ng; ++l)
+      {
+        uint32_t g = ctx->lex_to_num[l];
+        for (uint64_t p = goff[g]; p < goff[g + 1]; ++p)
+        {
+          bk_pair pr = all[d_idx ? idx[p] : p];
+          if (d_cl) pr.cluster = (int32_t) cl[p];
+          out.push_back(pr);
+        }
+        off.push_back(out.size());
+      }
+      *data = out.data();
+      *count = out.size();
+      if (group_off) *group_off = off.data();
+      if (n_groups) *n_groups = ng;
+    };
+    switch (stage)
+    {
+    case BK_STAGE_SCAN:
+      fetch_list(0, nullptr, ctx->jr.gstart, nullptr, ctx->jr.n_pairs);
+      break;
+    case BK_STAGE_ISO:
+      fetch_list(1, ctx->iso_idx.get<uint32_t>(), ctx->iso_goff.get<uint64_t>(), nullptr, ctx->iso_n);
+      break;
+    case BK_STAGE_CLUSTERED:
+      if (!ctx->clustered) throw bk_error(BK_ERR_ARG, "bk_fetch: not clustered yet");
+      fetch_list(2, ctx->list.idx.get<uint32_t>(), ctx->list.goff.get<uint64_t>(), ctx->d_cluster.get<uint32_t>(), ctx->list.n);
+      break;
+    case BK_STAGE_SPLITS:
+      ensure_splits_sorted(ctx);
+      ctx->f_splits.resize(ctx->hc.n_split);
+      if (ctx->hc.n_split)
+        HIP_CHECK(hipMemcpyAsync(ctx->f_splits.data(), ctx->d_split.get<bk_split>(), ctx->hc.n_split * sizeof(bk_split), hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipStreamSynchronize(ctx->st));
+      *data = ctx->f_splits.data();
+      *count = ctx->f_splits.size();
+      break;
+    case BK_STAGE_CLUSTERS:
+      ctx->f_clusters.resize(ctx->n_clusters);
+      if (ctx->n_clusters)
+        HIP_CHECK(hipMemcpyAsync(ctx->f_clusters.data(), ctx->d_clusters.get<bk_cluster>(), ctx->n_clusters * sizeof(bk_cluster), hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipStreamSynchronize(ctx->st));
+      // device order is (numeric chr-pair key, id); the reference appends groups in std::map<string> order
+      std::stable_sort(ctx->f_clusters.begin(), ctx->f_clusters.end(), [](const bk_cluster &a, const bk_cluster &b) { return a.group < b.group; });
+      *data = ctx->f_clusters.data();
+      *count = ctx->f_clusters.size();
+      break;
+    case BK_STAGE_GROUP_KEYS:
+      ctx->f_gkeys.clear();
+      for (uint32_t l = 0; l < ng; ++l)
+      {
+        uint32_t k = ctx->gkey_host[ctx->lex_to_num[l]];
+        ctx->f_gkeys.push_back((int32_t) (k / (uint32_t) (ctx->nt + 1)) - 1);
+        ctx->f_gkeys.push_back((int32_t) (k % (uint32_t) (ctx->nt + 1)) - 1);
+      }
+      *data = ctx->f_gkeys.data();
+      *count = ng;
+      break;
+    default:
+      throw bk_error(BK_ERR_ARG, "bk_fetch: unknown stage");
+    }
+  });
+}
+
+int bk_timing_enable(bk_ctx *ctx, int on)
+{
+  return guarded(ctx, [&] {
+    ctx->timing = on != 0;
+    for (auto &t : ctx->timers)
+    {
+      if (t.a) (void) hipEventDestroy(t.a);
+      if (t.b) (void) hipEventDestroy(t.b);
+    }
+    ctx->timers.clear();
+  });
+}
+
+int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const uint64_t **bytes, int *n)
+{
+  return guarded(ctx, [&] {
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    Timing &t = ctx->tout;
+    t.names.clear(); t.ms.clear(); t.bytes.clear(); t.cnames.clear();
+    for (auto &s : ctx->timers)
+    {
+      float v = 0;
+      HIP_CHECK(hipEventElapsedTime(&v, s.a, s.b));
+      t.names.push_back(s.name);
+      t.ms.push_back(v);
+      t.bytes.push_back(s.bytes);
+    }
+    for (auto &s : t.names) t.cnames.push_back(s.c_str());
+    if (names) *names = t.cnames.data();
+    if (ms) *ms = t.ms.data();
+    if (bytes) *bytes = t.bytes.data();
+    if (n) *n = (int) t.names.size();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Internal definitions shared by the HIP translation units of libbreakid_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/breakid_hip.h"
+
+#define BK_WAVE 64
+
+struct bk_error : std::exception
+{
+  int code;
+  std::string msg;
+  bk_error(int c, std::string m) : code(c), msg(std::move(m)) {}
+  const char *what() const noexcept override { return msg.c_str(); }
+};
+
+#define HIP_CHECK(expr)                                                                                         \
+  do                                                                                                            \
+  {                                                                                                             \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess)                                                                                       \
+      throw bk_error(BK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" +   \
+                                     std::to_string(__LINE__) + ")");                                           \
+  } while (0)
+
+// growable device buffer (never shrinks; bench steps reuse the allocation)
+struct DevBuf
+{
+  void *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release()
+  {
+    if (p) (void) hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  void *ensure(size_t bytes)
+  {
+    if (bytes > cap)
+    {
+      release();
+      size_t want = bytes + bytes / 8 + 256;
+      HIP_CHECK(hipMalloc(&p, want));
+      cap = want;
+    }
+    return p;
+  }
+  template <class T> T *as(size_t count) { return (T *) ensure(count * sizeof(T)); }
+  template <class T> T *get() const { return (T *) p; }
+};
+
+static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned) ((a + b - 1) / b); }
+
+// ---- candidate of the discordant filter (BreakID.cc:1419-1420), 32 bytes ------------------------
+struct Cand
+{
+  uint64_t qhash;
+  uint32_t rec;
+  int32_t tid, pos, mtid, mpos;
+  uint16_t flag;
+  uint8_t mapq, pad;
+};
+static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
+
+// counters written by the stream kernel
+struct StreamCounters
+{
+  unsigned long long isize_sum;   // sum |isize| over proper pairs
+  unsigned long long isize_n;     // count
+  unsigned long long n_cand;      // discordant candidates appended
+  unsigned long long n_split;     // split tuples appended
+  unsigned int max_span;          // max(bam_endpos - pos)
+  unsigned int unsorted;          // 1 if (tid,pos) order violated
+  unsigned long long cigar_words; // traffic accounting
+  unsigned long long aux_bytes;
+};
+
+// interned chromosome-name table (device copy): open addressing on FNV-1a of the text
+struct NameTableUnused
+{
+  const uint64_t *hash; // capacity entries, 0 = empty
+  const int32_t *id;
+  uint32_t mask;        // capacity - 1
+  const int32_t *own_id; // per tid: id of chromID2ChrName(tid) (util_bam.cc:128-142)
+  int32_t n_targets;
+  int32_t empty_id;     // id of ""
+};
+
+struct Timing
+{
+  std::vector<std::string> names;
+  std::vector<float> ms;
+  std::vector<uint64_t> bytes;
+  std::vector<const char *> cnames;
+};

@@ -1,0 +1,40 @@
+// Interface of bp.hip (cluster summary + split-read breakpoint stage).
+#pragma once
+#include "bk_common.h"
+#include "prims.h"
+
+struct ClusterAcc
+{
+  uint32_t *n;
+  unsigned long long *sum1, *sum2;
+  uint32_t *min1, *max1, *min2, *max2, *type;
+};
+
+// device view of the record columns the region queries touch
+struct RecView
+{
+  uint64_t n;
+  const int32_t *tid, *pos;
+  const uint16_t *flag;
+  const uint8_t *mapq;
+  const uint32_t *cigar_off, *cigar;
+};
+
+struct BpWork
+{
+  uint64_t t1lo, t1hi, t2lo, t2hi;
+  uint32_t ok, pad;
+};
+
+struct BpBufs
+{
+  DevBuf key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp;
+  prims::RadixBufs radix;
+};
+
+void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st);
+// returns the number of clusters that passed the near-diagonal filter; clusters_out holds them in (group key order, id) order
+uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32_t *gof, const uint32_t *cl, uint64_t n, uint32_t ng, const uint32_t *gkey,
+                         const uint32_t *glex, int32_t nt, double w, DevBuf &clusters_out, BpBufs &b, hipStream_t st);
+void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
+                       hipStream_t st);

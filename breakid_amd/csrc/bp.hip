@@ -1,0 +1,484 @@
+// Cluster summary (findClusterBreakPointInfoSaTag, BreakID.cc:225-352) and the split-read breakpoint
+// stage (findEncompassingReadsAndBreakPointInfo :390-490, find_sa_reads region rule :892-894,:1032,
+// find_bp_pair :577-857, cal_single_base_depth util_bed.cc:154-192).  The reference pulls records per
+// cluster through BAI region queries; here the per-read evidence tuples already exist (stream.hip) and
+// a region query is a binary search on the coordinate-sorted record table with htslib's overlap
+// predicate (hts.c:1963-1965: tid == T && pos < end && bam_endpos > beg).  One wavefront per cluster.
+#include "bk_common.h"
+#include "prims.h"
+#include "bp.h"
+
+namespace
+{
+// ---- summary -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_group_kmax(const uint32_t *__restrict__ gof, const uint32_t *__restrict__ cl, uint64_t n, uint32_t *__restrict__ kmax)
+{
+  uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) atomicMax(&kmax[gof[p]], cl[p] + 1);
+}
+__global__ __launch_bounds__(256) void k_accumulate(const bk_pair *__restrict__ pairs, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ gof,
+                                                    const uint32_t *__restrict__ cl, const uint32_t *__restrict__ slotbase, uint64_t n, ClusterAcc acc)
+{
+  uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const bk_pair pr = pairs[idx[p]];
+  uint32_t s = slotbase[gof[p]] + cl[p];
+  atomicAdd(&acc.n[s], 1u);
+  atomicAdd(&acc.sum1[s], (unsigned long long) pr.p1_pos);
+  atomicAdd(&acc.sum2[s], (unsigned long long) pr.p2_pos);
+  atomicMin(&acc.min1[s], pr.p1_pos);
+  atomicMax(&acc.max1[s], pr.p1_pos);
+  atomicMin(&acc.min2[s], pr.p2_pos);
+  atomicMax(&acc.max2[s], pr.p2_pos);
+  uint32_t type;
+  if (pr.p1_tid != pr.p2_tid)
+    type = BK_TYPE_DIFF_CHR;
+  else
+  {
+    type = 0;
+    if (pr.p1_rev && !pr.p2_rev) type |= BK_TYPE_ABS_REVERSE;
+    if (pr.p1_rev == pr.p2_rev) type |= BK_TYPE_SAME_ORIENT;
+    if (!pr.p1_rev && pr.p2_rev) type |= BK_TYPE_DEFAULT_ORIENT;
+  }
+  atomicOr(&acc.type[s], type);
+}
+// slot -> (group, id): group found by binary search on slotbase
+__global__ __launch_bounds__(256) void k_finalize(ClusterAcc acc, const uint32_t *__restrict__ slotbase, uint32_t ng, uint32_t nslots, const uint32_t *__restrict__ gkey,
+                                                  const uint32_t *__restrict__ glex, int32_t nt, double w, uint32_t *__restrict__ keep, bk_cluster *__restrict__ tmp)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  uint32_t k = 0;
+  uint32_t n = acc.n[s];
+  if (n)
+  {
+    uint32_t lo = 0, hi = ng;  // largest g with slotbase[g] <= s
+    while (lo < hi)
+    {
+      uint32_t m = (lo + hi) >> 1;
+      if (slotbase[m] <= s) lo = m + 1; else hi = m;
+    }
+    uint32_t g = lo - 1;
+    bk_cluster c;
+    c.group = glex[g];
+    c.id = (int32_t) (s - slotbase[g]);
+    c.p1_tid = (int32_t) (gkey[g] / (uint32_t) (nt + 1)) - 1;
+    c.p2_tid = (int32_t) (gkey[g] % (uint32_t) (nt + 1)) - 1;
+    unsigned long long m1 = (uint32_t) ((double) acc.sum1[s] / (double) n);  // :342-343
+    unsigned long long m2 = (uint32_t) ((double) acc.sum2[s] / (double) n);
+    c.p1_mean = (uint32_t) m1;
+    c.p2_mean = (uint32_t) m2;
+    c.p1_min = acc.min1[s];
+    c.p1_max = acc.max1[s];
+    c.p2_min = acc.min2[s];
+    c.p2_max = acc.max2[s];
+    c.p1_exact = 0xFFFFFFFFu;
+    c.p2_exact = -1;
+    c.n_drp = n;
+    c.n_sr = 0;
+    c.depth1 = c.depth2 = 0;
+    c.type_mask = acc.type[s];
+    long long dist = (long long) (m1 - m2);  // :345
+    bool same = c.p1_tid == c.p2_tid;
+    bool near = same && (double) dist <= 2 * w && (double) dist >= -2 * w;  // :348
+    c.flags = near ? 0u : 1u;
+    k = near ? 0u : 1u;
+    tmp[s] = c;
+  }
+  keep[s] = k;
+}
+__global__ __launch_bounds__(256) void k_compact_clusters(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ off, uint32_t nslots, const bk_cluster *__restrict__ tmp,
+                                                          bk_cluster *__restrict__ out)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nslots && keep[s]) out[off[s]] = tmp[s];
+}
+
+// ---- region machinery ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t rec_endpos(const RecView &r, uint64_t i)
+{
+  uint32_t c0 = r.cigar_off[i], c1 = r.cigar_off[i + 1];
+  int32_t pos = r.pos[i];
+  if (!(r.flag[i] & 4) && c1 > c0)
+  {
+    int l = 0;
+    for (uint32_t k = c0; k < c1; ++k)
+    {
+      uint32_t v = r.cigar[k], op = v & 15u;
+      if ((0x3C1A7u >> (op << 1)) & 2u) l += (int) (v >> 4);
+    }
+    return pos + l;
+  }
+  return pos + 1;
+}
+// first record index with (tid,pos) >= (T,P) in coordinate order (unmapped tid=-1 sorts last)
+__device__ uint64_t rec_lower(const RecView &r, int32_t T, long long P)
+{
+  uint64_t lo = 0, hi = r.n;
+  const uint32_t Tu = (uint32_t) T;
+  while (lo < hi)
+  {
+    uint64_t m = (lo + hi) >> 1;
+    uint32_t t = (uint32_t) r.tid[m];
+    bool lt = t != Tu ? (t < Tu) : ((long long) r.pos[m] < P);
+    if (lt) lo = m + 1; else hi = m;
+  }
+  return lo;
+}
+__device__ uint64_t split_lower(const bk_split *__restrict__ sp, uint64_t ns, uint64_t rec)
+{
+  uint64_t lo = 0, hi = ns;
+  while (lo < hi)
+  {
+    uint64_t m = (lo + hi) >> 1;
+    if ((uint64_t) sp[m].rec < rec) lo = m + 1; else hi = m;
+  }
+  return lo;
+}
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+struct Region
+{
+  int32_t tid;
+  int beg, end;
+  bool valid;
+};
+__device__ __forceinline__ Region make_region(int32_t tid, uint32_t mean, int wi)
+{
+  Region r;
+  uint32_t rs = (uint32_t) ((unsigned long long) mean - (unsigned long long) (long long) wi);  // :430-433 (uint64 arithmetic, uint32 result)
+  uint32_t re = (uint32_t) ((unsigned long long) mean + (unsigned long long) (long long) wi);
+  r.tid = tid;
+  r.beg = (int) rs;  // uint32 -> int at bam_iter_query (:881)
+  r.end = (int) re;
+  if (r.beg < 0) r.beg = 0;  // hts.c:1776
+  r.valid = !(r.end < r.beg || tid < 0);
+  return r;
+}
+__device__ __forceinline__ bool in_region(const Region &rg, int32_t tid, int32_t pos, int32_t endpos) { return tid == rg.tid && pos < rg.end && endpos > rg.beg; }
+
+// find_sa_reads' region verdict: coverage >= 5 and >= 2 evidence alignments, else the map is cleared
+__device__ bool scan_side(const RecView &r, const bk_split *__restrict__ sp, uint64_t nsp, const Region &rg, int maxspan, uint64_t &tlo, uint64_t &thi, bool &poison)
+{
+  tlo = thi = 0;
+  if (!rg.valid) return false;
+  const int lane = threadIdx.x & 63;
+  uint64_t lo = rec_lower(r, rg.tid, (long long) rg.beg - maxspan);
+  uint64_t hi = rec_lower(r, rg.tid, (long long) rg.end);
+  long long cov = 0;
+  for (uint64_t i = lo + lane; i < hi; i += 64)
+    if (in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) ++cov;
+  cov = wave_sum(cov);
+  tlo = split_lower(sp, nsp, lo);
+  thi = split_lower(sp, nsp, hi);
+  long long ev = 0, bad = 0;
+  for (uint64_t t = tlo + lane; t < thi; t += 64)
+  {
+    const bk_split s = sp[t];
+    if (in_region(rg, s.tid, s.pos, s.endpos))
+    {
+      ++ev;
+      if (s.flags & 2u) ++bad;
+    }
+  }
+  ev = wave_sum(ev);
+  bad = wave_sum(bad);
+  if (bad) poison = true;
+  return !(cov < 5 || ev < 2);
+}
+
+__device__ __forceinline__ bool tuples_match(const bk_split &a, const bk_split &b)
+{
+  return a.qhash == b.qhash && ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.prim_start == b.prim_start &&
+         a.sec_start == b.sec_start && a.prim_end == b.prim_end && a.sec_end == b.sec_end && a.prim_cigar == b.prim_cigar && a.sec_cigar == b.sec_cigar &&
+         a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;  // new_condition, :627-637
+}
+
+// phase 1: region verdicts + number of (i,j) matches per cluster
+__global__ __launch_bounds__(256) void k_bp_regions(RecView r, const bk_split *__restrict__ sp, uint64_t nsp, const bk_cluster *__restrict__ cl, uint32_t ncl, int wi, int maxspan,
+                                                    BpWork *__restrict__ work, uint32_t *__restrict__ nmatch, uint32_t *__restrict__ err)
+{
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= ncl) return;
+  const bk_cluster k = cl[c];
+  BpWork wk;
+  wk.ok = 0;
+  wk.t1lo = wk.t1hi = wk.t2lo = wk.t2hi = 0;
+  bool poison = false;
+  Region r1 = make_region(k.p1_tid, k.p1_mean, wi), r2 = make_region(k.p2_tid, k.p2_mean, wi);
+  bool ok1 = scan_side(r, sp, nsp, r1, maxspan, wk.t1lo, wk.t1hi, poison);
+  bool ok2 = false;
+  if (ok1) ok2 = scan_side(r, sp, nsp, r2, maxspan, wk.t2lo, wk.t2hi, poison);
+  long long m = 0;
+  if (ok1 && ok2)
+  {
+    wk.ok = 1;
+    for (uint64_t i = wk.t1lo + lane; i < wk.t1hi; i += 64)
+    {
+      const bk_split a = sp[i];
+      if (!in_region(r1, a.tid, a.pos, a.endpos)) continue;
+      for (uint64_t j = wk.t2lo; j < wk.t2hi; ++j)
+      {
+        const bk_split b = sp[j];
+        if (in_region(r2, b.tid, b.pos, b.endpos) && tuples_match(a, b)) ++m;
+      }
+    }
+    m = wave_sum(m);
+  }
+  if (lane == 0)
+  {
+    work[c] = wk;
+    nmatch[c] = (uint32_t) m;
+    if (poison) atomicOr(err, 1u);
+  }
+}
+
+// decimal text of "p1,p2" as the reference builds it with to_string(int32)
+__device__ int key_text(int32_t a, int32_t b, char *out)
+{
+  int n = 0;
+  for (int part = 0; part < 2; ++part)
+  {
+    long long v = part ? b : a;
+    char tmp[12];
+    int t = 0;
+    bool neg = v < 0;
+    if (neg) v = -v;
+    do
+    {
+      tmp[t++] = (char) ('0' + v % 10);
+      v /= 10;
+    } while (v);
+    if (neg) out[n++] = '-';
+    while (t) out[n++] = tmp[--t];
+    if (!part) out[n++] = ',';
+  }
+  return n;
+}
+// std::string operator< on the two key texts
+__device__ bool key_less(int32_t a1, int32_t a2, int32_t b1, int32_t b2)
+{
+  char sa[28], sb[28];
+  int la = key_text(a1, a2, sa), lb = key_text(b1, b2, sb);
+  int l = la < lb ? la : lb;
+  for (int i = 0; i < l; ++i)
+  {
+    unsigned char x = (unsigned char) sa[i], y = (unsigned char) sb[i];
+    if (x != y) return x < y;
+  }
+  return la < lb;
+}
+
+__device__ uint32_t base_depth(const RecView &r, int32_t tid, unsigned long long pos, int maxspan)
+{
+  // cal_single_base_depth: bam_iter_query(idx, tid, pos - 1, pos) with uint64 -> int conversions
+  int beg = (int) (pos - 1ull), end = (int) pos;
+  if (beg < 0) beg = 0;
+  if (end < beg || tid < 0) return 0;
+  Region rg;
+  rg.tid = tid;
+  rg.beg = beg;
+  rg.end = end;
+  rg.valid = true;
+  const int lane = threadIdx.x & 63;
+  uint64_t lo = rec_lower(r, tid, (long long) beg - maxspan), hi = rec_lower(r, tid, (long long) end);
+  long long d = 0;
+  for (uint64_t i = lo + lane; i < hi; i += 64)
+  {
+    if (!in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) continue;
+    uint16_t f = r.flag[i];
+    if (r.mapq[i] > 0 && !(f & 0x400) && (f & 1)) ++d;  // util_bed.cc:183
+  }
+  return (uint32_t) wave_sum(d);
+}
+
+// phase 2: emit (p1_bp, p2_bp) for every match, vote, depth
+__global__ __launch_bounds__(256) void k_bp_vote(RecView r, const bk_split *__restrict__ sp, bk_cluster *__restrict__ cl, uint32_t ncl, int wi, int maxspan,
+                                                 const BpWork *__restrict__ work, const uint32_t *__restrict__ moff, int2 *__restrict__ emit, uint32_t *__restrict__ ecount,
+                                                 const int32_t *__restrict__ hdr_id)
+{
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= ncl) return;
+  const BpWork wk = work[c];
+  if (!wk.ok) return;
+  bk_cluster k = cl[c];
+  Region r1 = make_region(k.p1_tid, k.p1_mean, wi), r2 = make_region(k.p2_tid, k.p2_mean, wi);
+  const int32_t p1_chr = hdr_id[k.p1_tid + 1];
+  int2 *E = emit + moff[c];
+  const uint32_t K = moff[c + 1] - moff[c];
+  for (uint64_t i = wk.t1lo + lane; i < wk.t1hi; i += 64)
+  {
+    const bk_split a = sp[i];
+    if (!in_region(r1, a.tid, a.pos, a.endpos)) continue;
+    for (uint64_t j = wk.t2lo; j < wk.t2hi; ++j)
+    {
+      const bk_split b = sp[j];
+      if (in_region(r2, b.tid, b.pos, b.endpos) && tuples_match(a, b))
+      {
+        uint32_t slot = atomicAdd(&ecount[c], 1u);
+        int2 e;
+        if (a.prim_chr == p1_chr)  // :647
+        {
+          e.x = (int32_t) a.prim_bp;
+          e.y = (int32_t) a.sec_bp;
+        }
+        else
+        {
+          e.x = (int32_t) a.sec_bp;
+          e.y = (int32_t) a.prim_bp;
+        }
+        if (slot < K) E[slot] = e;
+      }
+    }
+  }
+  __threadfence_block();
+  // every lane of this wave must see the emitted list: wave-local, same CU -> a workgroup-scope fence and
+  // the wave's own in-order memory pipeline suffice, but keep it simple and safe:
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  // vote (:804-855): for each distinct key, count emitted pairs within +-2 on both coordinates (unsigned
+  // arithmetic, :820-821); first strict maximum in std::map<string> order wins
+  int best_cnt = 0;
+  int32_t best1 = 0, best2 = 0;
+  for (uint32_t q = lane; q < K; q += 64)
+  {
+    const int2 e = E[q];
+    const uint32_t t1 = (uint32_t) e.x, t2 = (uint32_t) e.y;
+    int cnt = 0;
+    for (uint32_t m = 0; m < K; ++m)
+    {
+      const int2 u = E[m];
+      if (((uint32_t) u.x <= t1 + 2u && (uint32_t) u.x >= t1 - 2u) && ((uint32_t) u.y <= t2 + 2u && (uint32_t) u.y >= t2 - 2u)) ++cnt;
+    }
+    if (cnt > best_cnt || (cnt == best_cnt && cnt > 0 && key_less(e.x, e.y, best1, best2)))
+    {
+      best_cnt = cnt;
+      best1 = e.x;
+      best2 = e.y;
+    }
+  }
+  for (int d = 32; d; d >>= 1)
+  {
+    int oc = __shfl_xor(best_cnt, d, 64);
+    int32_t o1 = __shfl_xor(best1, d, 64), o2 = __shfl_xor(best2, d, 64);
+    if (oc > best_cnt || (oc == best_cnt && oc > 0 && key_less(o1, o2, best1, best2)))
+    {
+      best_cnt = oc;
+      best1 = o1;
+      best2 = o2;
+    }
+  }
+  if (best_cnt >= 2)  // :446
+  {
+    k.p1_exact = (uint32_t) best1;
+    k.p2_exact = best2;
+    k.n_sr = (uint32_t) best_cnt;
+    uint32_t d1 = base_depth(r, k.p1_tid, (unsigned long long) k.p1_exact, maxspan);
+    uint32_t d2 = base_depth(r, k.p2_tid, (unsigned long long) (long long) k.p2_exact, maxspan);
+    k.depth1 = d1;
+    k.depth2 = d2;
+    k.flags |= 2u;
+    if (lane == 0) cl[c] = k;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_split_keys(const bk_split *__restrict__ sp, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+  {
+    key[i] = sp[i].rec;
+    val[i] = (uint32_t) i;
+  }
+}
+__global__ __launch_bounds__(256) void k_split_gather(const bk_split *__restrict__ in, const uint32_t *__restrict__ perm, uint64_t n, bk_split *__restrict__ out)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[perm[i]];
+}
+}  // namespace
+
+static inline unsigned nb(uint64_t n) { return cdiv(n ? n : 1, 256); }
+
+void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st)
+{
+  if (n == 0) return;
+  uint64_t *key = b.key.as<uint64_t>(n);
+  uint32_t *val = b.val.as<uint32_t>(n);
+  hipLaunchKernelGGL(k_split_keys, dim3(nb(n)), dim3(256), 0, st, unsorted, n, key, val);
+  uint64_t *ks;
+  uint32_t *vs;
+  prims::radix_sort_pairs(key, val, n, 0, 32, b.radix, st, &ks, &vs);
+  hipLaunchKernelGGL(k_split_gather, dim3(nb(n)), dim3(256), 0, st, unsorted, vs, n, sorted);
+}
+
+uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32_t *gof, const uint32_t *cl, uint64_t n, uint32_t ng, const uint32_t *gkey,
+                         const uint32_t *glex, int32_t nt, double w, DevBuf &clusters_out, BpBufs &b, hipStream_t st)
+{
+  if (n == 0 || ng == 0) return 0;
+  uint32_t *kmax = b.kmax.as<uint32_t>((uint64_t) ng + 1);
+  HIP_CHECK(hipMemsetAsync(kmax, 0, ((uint64_t) ng + 1) * 4, st));
+  hipLaunchKernelGGL(k_group_kmax, dim3(nb(n)), dim3(256), 0, st, gof, cl, n, kmax);
+  uint32_t *slotbase = b.slotbase.as<uint32_t>((uint64_t) ng + 1);
+  prims::exclusive_scan<uint32_t>(kmax, slotbase, ng, b.scan_tmp, st);
+  uint32_t nslots = 0;
+  HIP_CHECK(hipMemcpyAsync(&nslots, slotbase + ng, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (nslots == 0) return 0;
+  ClusterAcc acc;
+  acc.n = b.an.as<uint32_t>(nslots);
+  acc.sum1 = b.as1.as<unsigned long long>(nslots);
+  acc.sum2 = b.as2.as<unsigned long long>(nslots);
+  acc.min1 = b.amin1.as<uint32_t>(nslots);
+  acc.max1 = b.amax1.as<uint32_t>(nslots);
+  acc.min2 = b.amin2.as<uint32_t>(nslots);
+  acc.max2 = b.amax2.as<uint32_t>(nslots);
+  acc.type = b.atype.as<uint32_t>(nslots);
+  HIP_CHECK(hipMemsetAsync(acc.n, 0, (size_t) nslots * 4, st));
+  HIP_CHECK(hipMemsetAsync(acc.sum1, 0, (size_t) nslots * 8, st));
+  HIP_CHECK(hipMemsetAsync(acc.sum2, 0, (size_t) nslots * 8, st));
+  HIP_CHECK(hipMemsetAsync(acc.min1, 0xFF, (size_t) nslots * 4, st));
+  HIP_CHECK(hipMemsetAsync(acc.max1, 0, (size_t) nslots * 4, st));
+  HIP_CHECK(hipMemsetAsync(acc.min2, 0xFF, (size_t) nslots * 4, st));
+  HIP_CHECK(hipMemsetAsync(acc.max2, 0, (size_t) nslots * 4, st));
+  HIP_CHECK(hipMemsetAsync(acc.type, 0, (size_t) nslots * 4, st));
+  hipLaunchKernelGGL(k_accumulate, dim3(nb(n)), dim3(256), 0, st, pairs, idx, gof, cl, slotbase, n, acc);
+  uint32_t *keep = b.keep.as<uint32_t>((uint64_t) nslots + 1), *off = b.off.as<uint32_t>((uint64_t) nslots + 1);
+  bk_cluster *tmp = b.tmpc.as<bk_cluster>(nslots);
+  hipLaunchKernelGGL(k_finalize, dim3(nb(nslots)), dim3(256), 0, st, acc, slotbase, ng, nslots, gkey, glex, nt, w, keep, tmp);
+  prims::exclusive_scan<uint32_t>(keep, off, nslots, b.scan_tmp, st);
+  uint32_t nk = 0;
+  HIP_CHECK(hipMemcpyAsync(&nk, off + nslots, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  bk_cluster *out = clusters_out.as<bk_cluster>((uint64_t) nk + 1);
+  if (nk) hipLaunchKernelGGL(k_compact_clusters, dim3(nb(nslots)), dim3(256), 0, st, keep, off, nslots, tmp, out);
+  return nk;
+}
+
+void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
+                       hipStream_t st)
+{
+  if (ncl == 0) return;
+  if (ncl > 0x7FFFFFFFull) throw bk_error(BK_ERR_LIMIT, "too many clusters");
+  const int wi = (int) w;  // `const int w` parameter, BreakID.cc:390
+  BpWork *work = b.work.as<BpWork>(ncl);
+  uint32_t *nmatch = b.nmatch.as<uint32_t>(ncl + 1), *moff = b.moff.as<uint32_t>(ncl + 1);
+  uint32_t *err = b.err.as<uint32_t>(4);
+  HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
+  hipLaunchKernelGGL(k_bp_regions, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, sp, nsp, cl, (uint32_t) ncl, wi, maxspan, work, nmatch, err);
+  prims::exclusive_scan<uint32_t>(nmatch, moff, ncl, b.scan_tmp, st);
+  uint32_t host[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(&host[0], moff + ncl, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&host[1], err, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (host[1]) throw bk_error(BK_ERR_CIGAR, "error cigar: ");  // the reference's exit(-1), BreakID.cc:954-968
+  int2 *emit = b.emit.as<int2>((uint64_t) host[0] + 1);
+  uint32_t *ecount = b.ecount.as<uint32_t>(ncl + 1);
+  HIP_CHECK(hipMemsetAsync(ecount, 0, (ncl + 1) * 4, st));
+  hipLaunchKernelGGL(k_bp_vote, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, sp, cl, (uint32_t) ncl, wi, maxspan, work, moff, emit, ecount, hdr_id);
+}

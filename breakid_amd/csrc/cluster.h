@@ -1,0 +1,28 @@
+// Interface of cluster.hip (isolated-pair masking + fast clustering) and ahc.hip.
+#pragma once
+#include "bk_common.h"
+#include "prims.h"
+#include "sortemu.h"
+
+// an ordered list of pair-table indices partitioned into groups
+struct PairList
+{
+  uint64_t n = 0;
+  uint32_t ng = 0;
+  DevBuf idx;   // u32[n]   index into the pair table
+  DevBuf gof;   // u32[n]   group (numeric key order) of each element
+  DevBuf goff;  // u64[ng+1]
+  uint64_t total(hipStream_t st) const;
+};
+
+struct ClusterBufs
+{
+  DevBuf key, perm, tmp, cnt, off, off2, idx2, gof2, goff2, jump, mark, apos, kid, kprev2, k1, k2, pk, knum, clfull, small, scan_tmp;
+  SortEmuBufs se;
+  prims::RadixBufs radix;
+};
+
+// remove_isolated_pairs for every group; L receives the surviving list (x-sorted, duplicates included)
+void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st);
+// find_cluster_pairs_enspan_fast for every group with >= 2 pairs; L becomes the clustered list, cluster_out[p] its cluster number
+void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluster_out, ClusterBufs &b, hipStream_t st);

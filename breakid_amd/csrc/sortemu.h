@@ -1,0 +1,14 @@
+// std::sort (libstdc++ introsort) emulation over all groups at once — see sortemu.hip.
+#pragma once
+#include "bk_common.h"
+#include "prims.h"
+
+struct SortEmuBufs
+{
+  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp;
+  prims::RadixBufs radix;
+};
+
+// key/idx: n elements, groups are the contiguous ranges goff[g]..goff[g+1]; gof[p] = group of position p.
+// On return every group is ordered exactly as std::sort(begin, end, [](a,b){return a.key < b.key;}) leaves it.
+void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const uint64_t *goff, uint32_t ng, uint64_t n, SortEmuBufs &b, hipStream_t st);

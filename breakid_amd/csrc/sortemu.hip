@@ -1,0 +1,287 @@
+// Exact, data-parallel emulation of libstdc++'s std::sort (introsort) on every group at once.
+//
+// The reference sorts its pair vectors with *unstable* std::sort (BreakID.cc:1091,1127,1274,1278,1282)
+// and then reads neighbours of the sorted vector (mask_pairs_chr_pos :1847-1858, fast clustering
+// :1064,:1100), so the order std::sort leaves equal keys in is observable.  std::sort is
+// deterministic given the comparison outcomes:
+//   __introsort_loop: while (size > 16) { median-of-3 of (first+1, mid, last-1) swapped to first;
+//                     Hoare partition of [first+1,last) around *first; recurse right, loop left }
+//   __final_insertion_sort: stable for equal keys.
+// so the result = a stable sort by key of the array as the introsort loop leaves it.  One partition
+// level is a data-parallel step: with l_j the j-th position (from the left) whose key >= pivot and r_j
+// the j-th position (from the right) whose key <= pivot, the loop swaps (l_j, r_j) for every j < J,
+// J = #{j : l_j < r_j}, and returns cut = min(l_J, r_{J-1}) (l_0 when J = 0).  All segments of all groups
+// advance one level per pass (prefix sums give the ranks), then one stable radix sort finishes.
+#include "bk_common.h"
+#include "prims.h"
+#include "sortemu.h"
+
+namespace
+{
+struct Seg
+{
+  uint32_t first, last;
+  uint32_t pivot;
+  int32_t depth;
+  uint32_t cut;
+};
+
+// depth_limit = 2 * floor(log2(n))  (std::__lg(n) * 2)
+__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, uint32_t *__restrict__ cnt)
+{
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  uint64_t sz = goff[g + 1] - goff[g];
+  cnt[g] = sz > 16 ? 1u : 0u;
+}
+__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const uint32_t *__restrict__ off, Seg *__restrict__ segs)
+{
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  uint64_t sz = goff[g + 1] - goff[g];
+  if (sz > 16)
+  {
+    Seg s;
+    s.first = (uint32_t) goff[g];
+    s.last = (uint32_t) goff[g + 1];
+    s.pivot = 0;
+    s.depth = 2 * (63 - __clzll((long long) sz));
+    s.cut = 0;
+    segs[off[g]] = s;
+  }
+}
+
+// __move_median_to_first(first, first+1, mid, last-1)
+__global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Seg sg = segs[s];
+  if (sg.depth == 0)
+  {
+    atomicOr(err, 1u);  // std::sort would switch to heapsort here; not emulated (needs 2*log2(n) bad splits)
+  }
+  uint32_t first = sg.first, last = sg.last;
+  uint32_t a = first + 1, b = first + (last - first) / 2, c = last - 1;
+  uint32_t ka = key[a], kb = key[b], kc = key[c];
+  uint32_t pick;
+  if (ka < kb)
+  {
+    if (kb < kc) pick = b;
+    else if (ka < kc) pick = c;
+    else pick = a;
+  }
+  else if (ka < kc) pick = a;
+  else if (kb < kc) pick = c;
+  else pick = b;
+  uint32_t kf = key[first], kp = key[pick];
+  uint32_t xf = idx[first], xp = idx[pick];
+  key[first] = kp;
+  key[pick] = kf;
+  idx[first] = xp;
+  idx[pick] = xf;
+  segs[s].pivot = kp;
+  segs[s].depth = sg.depth - 1;
+}
+
+__device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t p)
+{
+  // largest s with segs[s].first <= p, or ~0u
+  uint32_t lo = 0, hi = ns;
+  while (lo < hi)
+  {
+    uint32_t m = (lo + hi) >> 1;
+    if (segs[m].first <= p) lo = m + 1; else hi = m;
+  }
+  if (lo == 0) return 0xFFFFFFFFu;
+  uint32_t s = lo - 1;
+  return p < segs[s].last ? s : 0xFFFFFFFFu;
+}
+
+// lr[p] = (#L-stopper at p) | (#R-stopper at p) << 32 ; segof[p] = segment index or ~0
+__global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t n,
+                                                  unsigned long long *__restrict__ lr, uint32_t *__restrict__ segof)
+{
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t s = find_seg(segs, ns, p);
+  segof[p] = s;
+  unsigned long long v = 0;
+  if (s != 0xFFFFFFFFu && p > segs[s].first)
+  {
+    uint32_t k = key[p], pv = segs[s].pivot;
+    if (k >= pv) v |= 1ull;          // !(key < pivot): the left scan stops here
+    if (k <= pv) v |= 1ull << 32;    // !(pivot < key): the right scan stops here
+  }
+  lr[p] = v;
+}
+
+__global__ __launch_bounds__(256) void k_se_lists(const Seg *__restrict__ segs, const uint32_t *__restrict__ segof, const uint32_t *__restrict__ key, uint32_t n,
+                                                  const unsigned long long *__restrict__ LR, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR)
+{
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t s = segof[p];
+  if (s == 0xFFFFFFFFu) return;
+  Seg sg = segs[s];
+  if (p <= sg.first) return;
+  uint32_t k = key[p];
+  unsigned long long here = LR[p], base = LR[sg.first], end = LR[sg.last];
+  if (k >= sg.pivot)
+  {
+    uint32_t j = (uint32_t) here - (uint32_t) base;
+    posL[sg.first + 1 + j] = p;
+  }
+  if (k <= sg.pivot)
+  {
+    uint32_t nR = (uint32_t) (end >> 32) - (uint32_t) (base >> 32);
+    uint32_t jl = (uint32_t) (here >> 32) - (uint32_t) (base >> 32);
+    posR[sg.first + 1 + (nR - 1 - jl)] = p;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const uint32_t *__restrict__ segof, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t n,
+                                                 const unsigned long long *__restrict__ LR, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR)
+{
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t s = segof[p];
+  if (s == 0xFFFFFFFFu) return;
+  const uint32_t first = segs[s].first, last = segs[s].last;
+  unsigned long long base = LR[first], end = LR[last];
+  uint32_t nL = (uint32_t) end - (uint32_t) base;
+  uint32_t nR = (uint32_t) (end >> 32) - (uint32_t) (base >> 32);
+  uint32_t m = nL < nR ? nL : nR;
+  uint32_t j = p - first;
+  if (j > m) return;
+  const uint32_t INF = 0xFFFFFFFFu;
+  uint32_t lj = j < nL ? posL[first + 1 + j] : INF;
+  uint32_t rj = j < nR ? posR[first + 1 + j] : first;
+  bool cont = (j < nL) && (j < nR) && (lj < rj);
+  if (cont)
+  {
+    uint32_t k1 = key[lj], k2 = key[rj], x1 = idx[lj], x2 = idx[rj];
+    key[lj] = k2;
+    key[rj] = k1;
+    idx[lj] = x2;
+    idx[rj] = x1;
+  }
+  else
+  {
+    bool prev_cont = false;
+    uint32_t rprev = 0;
+    if (j > 0)
+    {
+      uint32_t lp = posL[first + j];   // j-1 < m <= nL, nR
+      rprev = posR[first + j];
+      prev_cont = lp < rprev;
+    }
+    if (j == 0)
+      segs[s].cut = lj;                               // J = 0: the left scan's first stop (exists: median-of-3 sentinel)
+    else if (prev_cont)
+      segs[s].cut = lj < rprev ? lj : rprev;          // cut = min(l_J, r_{J-1})
+  }
+}
+
+__global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ cnt)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Seg sg = segs[s];
+  cnt[s] = ((sg.cut - sg.first) > 16 ? 1u : 0u) + ((sg.last - sg.cut) > 16 ? 1u : 0u);
+}
+__global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ off, Seg *__restrict__ out)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Seg sg = segs[s];
+  uint32_t o = off[s];
+  if ((sg.cut - sg.first) > 16)
+  {
+    Seg c = sg;
+    c.last = sg.cut;
+    out[o++] = c;
+  }
+  if ((sg.last - sg.cut) > 16)
+  {
+    Seg c = sg;
+    c.first = sg.cut;
+    out[o++] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_se_compose(const uint32_t *__restrict__ key, const uint32_t *__restrict__ gof, uint32_t n, uint64_t *__restrict__ ck)
+{
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) ck[p] = ((uint64_t) gof[p] << 32) | key[p];
+}
+__global__ __launch_bounds__(256) void k_se_decompose(const uint64_t *__restrict__ ck, const uint32_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n)
+  {
+    key[p] = (uint32_t) ck[p];
+    idx[p] = v[p];
+  }
+}
+}  // namespace
+
+void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const uint64_t *goff, uint32_t ng, uint64_t n64, SortEmuBufs &b, hipStream_t st)
+{
+  if (n64 == 0 || ng == 0) return;
+  if (n64 > 0x7FFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: more than 2^31 pairs");
+  const uint32_t n = (uint32_t) n64;
+  uint32_t *cnt = b.cnt.as<uint32_t>((uint64_t) (n / 8 + ng) + 32);
+  uint32_t *err = b.err.as<uint32_t>(4);
+  HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
+  // level 0 segments = groups larger than 16
+  hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt);
+  prims::exclusive_scan<uint32_t>(cnt, cnt, ng, b.scan_tmp, st);
+  uint32_t ns = 0;
+  HIP_CHECK(hipMemcpyAsync(&ns, cnt + ng, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  size_t max_segs = (size_t) n / 8 + ng + 16;
+  Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
+  if (ns)
+  {
+    hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs);
+    unsigned long long *lr = b.lr.as<unsigned long long>((uint64_t) n + 1);
+    uint32_t *segof = b.segof.as<uint32_t>(n);
+    uint32_t *posL = b.posL.as<uint32_t>((uint64_t) n + 2), *posR = b.posR.as<uint32_t>((uint64_t) n + 2);
+    const unsigned nbk = cdiv(n, 256);
+    int level = 0;
+    while (ns)
+    {
+      if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
+      hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err);
+      hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, n, lr, segof);
+      prims::exclusive_scan<unsigned long long>(lr, lr, n, b.scan_tmp, st);
+      hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, n, lr, posL, posR);
+      hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, n, lr, posL, posR);
+      hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
+      prims::exclusive_scan<uint32_t>(cnt, cnt, ns, b.scan_tmp, st);
+      uint32_t ns2 = 0;
+      HIP_CHECK(hipMemcpyAsync(&ns2, cnt + ns, 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (ns2 > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
+      if (ns2) hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2);
+      std::swap(segs, segs2);
+      ns = ns2;
+      if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
+    }
+    uint32_t e = 0;
+    HIP_CHECK(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (e) throw bk_error(BK_ERR_LIMIT, "std::sort emulation hit introsort's depth limit (heapsort branch is not emulated)");
+  }
+  // __final_insertion_sort == stable sort by key of what the introsort loop left
+  uint64_t *ck = b.ck.as<uint64_t>(n);
+  hipLaunchKernelGGL(k_se_compose, dim3(cdiv(n, 256)), dim3(256), 0, st, key, gof, n, ck);
+  int gbits = 1;
+  while ((1u << gbits) < ng && gbits < 31) ++gbits;
+  uint64_t *ko;
+  uint32_t *vo;
+  prims::radix_sort_pairs(ck, idx, n, 0, 32 + gbits, b.radix, st, &ko, &vo);
+  // vo may alias idx: element p is read and written by the same lane only
+  hipLaunchKernelGGL(k_se_decompose, dim3(cdiv(n, 256)), dim3(256), 0, st, ko, vo, n, key, idx);
+}

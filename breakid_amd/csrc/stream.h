@@ -1,0 +1,56 @@
+// Interface of stream.hip (streaming record pass + bit-exact sd replay).
+#pragma once
+#include "bk_common.h"
+
+struct SdState
+{
+  double sumsq;           // sum of v^2 (approximate, only bounds the binade of the running total)
+  unsigned int vmax;      // max |isize| over proper pairs
+  unsigned int pad;
+  long long t_final;      // the reference's insert_size_sd_total after the last add
+};
+
+struct SdException
+{
+  unsigned long long l_before;  // sum of floor(d) over all earlier qualifying records
+  double d;
+};
+
+struct SdBufs
+{
+  DevBuf blockL, blockE, scan_tmp, scan_tmp2, exceptions;
+  unsigned long long last_exceptions = 0;
+};
+
+struct NameTableDev
+{
+  const uint64_t *hash;
+  const int32_t *id;
+  uint32_t mask;
+  const int32_t *own_id;
+  int32_t n_targets;
+  int32_t empty_id;
+};
+
+struct StreamArgs
+{
+  uint64_t n;
+  const int32_t *tid, *pos, *mtid, *mpos, *isize;
+  const uint16_t *flag;
+  const uint8_t *mapq;
+  const uint64_t *qhash;
+  const uint32_t *cigar_off, *cigar, *aux_off;
+  const uint8_t *aux;
+  int mapq_min;
+  NameTableDev names;
+  StreamCounters *counters;
+  SdState *sd;
+  Cand *cand;
+  unsigned long long cand_cap;
+  bk_split *split;
+  unsigned long long split_cap;
+};
+
+void launch_stream(const StreamArgs &a, hipStream_t st);
+// mean: host-computed (double) sum / (double) n; thr: exception threshold 2^(kmax-53) (or huge = replay all)
+void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st);

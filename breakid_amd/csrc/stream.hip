@@ -1,0 +1,607 @@
+// Streaming pass over the columnar record table (one lane per record, coalesced column reads):
+//   A1  insert-size sums            BreakID.cc:1929-1941
+//   A2  discordant-candidate filter BreakID.cc:1419-1420  (wave-ballot compaction)
+//   A12 per-read SA/CIGAR evidence  BreakID.cc:895-1016 + CigarRoller.cc / Cigar.cc semantics
+// plus the bit-exact replay of the reference's order-dependent sd accumulation (BreakID.cc:1942-1946).
+// HBM-bound integer/byte work: no MFMA.  gfx950 only.
+#include "bk_common.h"
+#include "prims.h"
+#include "stream.h"
+
+namespace
+{
+// ---- CIGAR roll-up (CigarRoller.cc:26-46 operator+=, :67-116 Add, Cigar.cc:80-144) ------------------
+// classes: 1 match, 3 insert, 4 del, 5 skip, 6 softClip, 7 hardClip, 8 pad (Cigar.h:65-76)
+struct Roll
+{
+  int n_ops;          // number of rolled operations
+  int last;           // class of the last rolled op
+  int op0, op1;       // classes of the first two rolled ops
+  uint32_t c0, c1;    // their counts
+  int reflen, nmatch; // getExpectedReferenceBaseCount / getNumMatches (int arithmetic like the reference)
+  int begin, tail;    // getNumBeginClips / getNumEndClips
+  bool lead;
+  __device__ void init()
+  {
+    n_ops = 0; last = 0; op0 = op1 = 0; c0 = c1 = 0; reflen = nmatch = 0; begin = tail = 0; lead = true;
+  }
+  __device__ void add(int cls, uint32_t count)
+  {
+    if (count == 0) return;
+    if (n_ops == 0 || last != cls)
+    {
+      if (n_ops == 0) { op0 = cls; c0 = count; }
+      else if (n_ops == 1) { op1 = cls; c1 = count; }
+      ++n_ops;
+      last = cls;
+    }
+    else
+    {
+      if (n_ops == 1) c0 += count;
+      else if (n_ops == 2) c1 += count;
+    }
+    bool clip = (cls == 6 || cls == 7);
+    if (cls == 1 || cls == 4 || cls == 5) reflen += (int) count;
+    if (cls == 1) nmatch += (int) count;
+    if (clip)
+    {
+      if (lead) begin += (int) count;
+      tail += (int) count;
+    }
+    else
+    {
+      lead = false;
+      tail = 0;
+    }
+  }
+  __device__ void add_code(int c, int count)  // Add(char operation, int count): BAM codes and letters
+  {
+    int cls;
+    switch (c)
+    {
+    case 0: case 'M': cls = 1; break;
+    case 1: case 'I': cls = 3; break;
+    case 2: case 'D': cls = 4; break;
+    case 3: case 'N': cls = 5; break;
+    case 4: case 'S': cls = 6; break;
+    case 5: case 'H': cls = 7; break;
+    case 6: case 'P': cls = 8; break;
+    case 7: case '=': cls = 1; break;
+    case 8: case 'X': cls = 1; break;
+    default: return;  // reference logs an error and ignores the op
+    }
+    add(cls, (uint32_t) count);
+  }
+  // rolled string matches ([0-9]+[MS]){2}
+  __device__ bool two_op_ms() const { return n_ops == 2 && (op0 == 1 || op0 == 6) && (op1 == 1 || op1 == 6); }
+};
+
+__device__ __forceinline__ void roll_bam(Roll &r, const uint32_t *__restrict__ w, uint32_t n)
+{
+  r.init();
+  for (uint32_t k = 0; k < n; ++k)
+  {
+    uint32_t v = w[k];
+    r.add_code((int) (v & 15u), (int) (v >> 4));
+  }
+}
+
+// CigarRoller::Add(const char*) (:119-136): digits -> strtol, any other byte -> Add(byte, count)
+__device__ void roll_text(Roll &r, const uint8_t *__restrict__ s, uint32_t len)
+{
+  r.init();
+  int count = 0;
+  uint32_t i = 0;
+  while (i < len && s[i])
+  {
+    uint8_t ch = s[i];
+    if (ch >= '0' && ch <= '9')
+    {
+      long long v = 0;
+      while (i < len && s[i] >= '0' && s[i] <= '9')
+      {
+        v = v * 10 + (s[i] - '0');
+        if (v > 0x7fffffffffffffLL) v = 0x7fffffffffffffLL;
+        ++i;
+      }
+      count = (int) v;
+    }
+    else
+    {
+      r.add_code((int) ch, count);
+      ++i;
+    }
+  }
+}
+
+// raw text fully matches ([0-9]+[MS]){2}  (CigarRoller.cc:326)
+__device__ bool text_two_op_ms(const uint8_t *__restrict__ s, uint32_t len)
+{
+  uint32_t i = 0;
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k)
+  {
+    uint32_t d = i;
+    while (i < len && s[i] >= '0' && s[i] <= '9') ++i;
+    if (i == d) return false;
+    if (i >= len || (s[i] != 'M' && s[i] != 'S')) return false;
+    ++i;
+  }
+  return i == len;
+}
+
+__device__ __forceinline__ uint64_t fnv_bytes(const uint8_t *__restrict__ s, uint32_t len)
+{
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (uint32_t i = 0; i < len; ++i)
+  {
+    h ^= s[i];
+    h *= 0x100000001B3ull;
+  }
+  return h;
+}
+__device__ __forceinline__ void fnv_push(uint64_t &h, uint8_t c)
+{
+  h ^= c;
+  h *= 0x100000001B3ull;
+}
+__device__ void fnv_push_dec(uint64_t &h, uint32_t v)  // decimal text of a count (sprintf "%d")
+{
+  char buf[10];
+  int n = 0;
+  do
+  {
+    buf[n++] = (char) ('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) fnv_push(h, (uint8_t) buf[--n]);
+}
+__device__ __forceinline__ char cls_char(int cls) { return cls == 1 ? 'M' : 'S'; }
+
+__device__ int32_t intern_name(const NameTableDev &nt, const uint8_t *__restrict__ s, uint32_t len)
+{
+  uint64_t h = fnv_bytes(s, len);
+  if (h == 0) h = 1;
+  uint32_t slot = (uint32_t) h & nt.mask;
+  for (uint32_t probe = 0; probe <= nt.mask; ++probe)
+  {
+    uint64_t e = nt.hash[slot];
+    if (e == 0) break;
+    if (e == h) return nt.id[slot];
+    slot = (slot + 1) & nt.mask;
+  }
+  return (int32_t) (0x40000000u | (uint32_t) (fnv_bytes(s, len) & 0x3FFFFFFFu));
+}
+
+// bam_endpos (sam.c:344-350) with BAM_CIGAR_TYPE 0x3C1A7
+__device__ __forceinline__ int32_t cigar_reflen_hts(const uint32_t *__restrict__ w, uint32_t n)
+{
+  int l = 0;
+  for (uint32_t k = 0; k < n; ++k)
+  {
+    uint32_t v = w[k], op = v & 15u;
+    if ((0x3C1A7u >> (op << 1)) & 2u) l += (int) (v >> 4);
+  }
+  return l;
+}
+
+// Evidence tuple of one record (BreakID.cc:895-1016).  false = record yields no tuple.
+__device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int32_t tid, int32_t pos, uint32_t c0, uint32_t c1,
+                             int32_t endpos, bk_split &t)
+{
+  uint32_t a0 = a.aux_off[i], a1 = a.aux_off[i + 1];
+  if (a1 <= a0) return false;                       // sa_tag == ""
+  if ((flag & 0x400) || !(flag & 1)) return false;  // :898
+  const uint8_t *blob = a.aux + a0;
+  uint32_t blen = a1 - a0;
+  // aux blob: [OC '\t'] SA
+  uint32_t oc_len = 0, sa_beg = 0;
+  for (uint32_t k = 0; k < blen; ++k)
+  {
+    uint8_t ch = blob[k];
+    if (ch == ',') break;
+    if (ch == '\t')
+    {
+      oc_len = k;
+      sa_beg = k + 1;
+      break;
+    }
+  }
+  const uint8_t *sa = blob + sa_beg;
+  uint32_t sa_len = blen - sa_beg;
+  if (sa_len == 0) return false;
+  // split_string(sa, ","), empty tokens dropped (util_bed.cc:194-222): tokens 0,1,3
+  uint32_t tb[4], te[4];
+  int nt = 0;
+  {
+    uint32_t st = 0;
+    while (nt < 4)
+    {
+      uint32_t e = st;
+      while (e < sa_len && sa[e] != ',') ++e;
+      if (e > st)
+      {
+        tb[nt] = st;
+        te[nt] = e;
+        ++nt;
+      }
+      if (e >= sa_len) break;
+      st = e + 1;
+    }
+  }
+  if (nt < 4) return false;
+  const uint8_t *c2 = sa + tb[3];
+  uint32_t c2len = te[3] - tb[3];
+  Roll own, sac, tmp;
+  roll_bam(own, a.cigar + c0, c1 - c0);
+  roll_text(sac, c2, c2len);
+  if (oc_len)
+    roll_text(tmp, blob, oc_len);
+  else
+    tmp = own;
+  // is_complementary_cigar(sa[3], 10)  CigarRoller.cc:323-346
+  if (!tmp.two_op_ms() || !text_two_op_ms(c2, c2len)) return false;
+  {
+    int c1_m = tmp.nmatch, c2_m = sac.nmatch;
+    int c1_s = tmp.begin + tmp.tail, c2_s = sac.tail + sac.begin;
+    if (!((c1_m <= c2_s + 10 && c1_m >= c2_s - 10) && (c1_m + c1_s == c2_m + c2_s))) return false;
+  }
+  t.rec = (uint32_t) i;
+  t.tid = tid;
+  t.pos = pos;
+  t.endpos = endpos;
+  t.qhash = a.qhash[i];
+  bool secondary = (flag & 0x100) != 0;
+  uint32_t flags = secondary ? 1u : 0u;
+  // stoi(sa[1])
+  uint32_t sa_start;
+  {
+    const uint8_t *p = sa + tb[1];
+    uint32_t l = te[1] - tb[1], k = 0;
+    while (k < l && (p[k] == ' ' || (p[k] >= 9 && p[k] <= 13))) ++k;
+    bool neg = false;
+    if (k < l && (p[k] == '+' || p[k] == '-'))
+    {
+      neg = p[k] == '-';
+      ++k;
+    }
+    long long v = 0;
+    while (k < l && p[k] >= '0' && p[k] <= '9')
+    {
+      v = v * 10 + (p[k] - '0');
+      if (v > 0x7fffffffLL) v = 0x7fffffffLL;
+      ++k;
+    }
+    sa_start = (uint32_t) (int) (neg ? -v : v);
+  }
+  uint32_t sa_end = sa_start + (uint32_t) sac.reflen - 1u;  // CigarRoller.cc:316-321
+  long long a_start = (long long) pos + 1;                    // BamAlignment.cc:172-175
+  long long a_end = (own.reflen == 0 ? (long long) pos : (long long) pos + own.reflen - 1) + 1;
+  int32_t own_chr = (tid >= 0 && tid < a.names.n_targets) ? a.names.own_id[tid] : a.names.empty_id;
+  int32_t sa_chr = intern_name(a.names, sa + tb[0], te[0] - tb[0]);
+  uint32_t own_end_val, own_bp = 0, sa_bp = 0;
+  uint64_t own_cig;
+  bool poison = false;
+  if (oc_len)
+  {
+    own_cig = fnv_bytes(blob, oc_len);
+    own_end_val = (uint32_t) a_start + (uint32_t) tmp.reflen - 1u;
+  }
+  else
+  {
+    uint64_t h = 0xCBF29CE484222325ull;  // text of the rolled BAM cigar: exactly two ops here
+    fnv_push_dec(h, own.c0);
+    fnv_push(h, (uint8_t) cls_char(own.op0));
+    fnv_push_dec(h, own.c1);
+    fnv_push(h, (uint8_t) cls_char(own.op1));
+    own_cig = h;
+    own_end_val = (uint32_t) a_end;
+  }
+  if (tmp.begin != 0)
+    own_bp = (uint32_t) a_start;
+  else if (tmp.tail != 0)
+    own_bp = (uint32_t) a_end;
+  else
+    poison = true;
+  if (sac.begin != 0)
+    sa_bp = sa_start;
+  else if (sac.tail != 0)
+    sa_bp = sa_end;
+  else
+    poison = true;
+  uint64_t sa_cig = fnv_bytes(c2, c2len);
+  if (!secondary)
+  {
+    t.prim_chr = own_chr; t.prim_start = (uint32_t) a_start; t.prim_end = own_end_val; t.prim_cigar = own_cig; t.prim_bp = own_bp;
+    t.sec_chr = sa_chr; t.sec_start = sa_start; t.sec_end = sa_end; t.sec_cigar = sa_cig; t.sec_bp = sa_bp;
+  }
+  else
+  {
+    t.prim_chr = sa_chr; t.prim_start = sa_start; t.prim_end = sa_end; t.prim_cigar = sa_cig; t.prim_bp = sa_bp;
+    t.sec_chr = own_chr; t.sec_start = (uint32_t) a_start; t.sec_end = own_end_val; t.sec_cigar = own_cig; t.sec_bp = own_bp;
+  }
+  if (poison) flags |= 2u;
+  t.flags = flags;
+  t.pad = 0;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stream(StreamArgs a)
+{
+  __shared__ unsigned long long s_sum[4], s_n[4];
+  __shared__ double s_sq[4];
+  __shared__ unsigned int s_span[4], s_vmax[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+  unsigned long long isum = 0, icnt = 0;
+  double isq = 0.0;
+  unsigned int span = 1, vmax = 0, unsorted = 0;
+  const uint64_t n_round = ((a.n + stride - 1) / stride) * stride;  // keep whole waves in the loop for the ballots
+  for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
+  {
+    const bool live = i < a.n;
+    uint16_t flag = 0;
+    uint8_t mapq = 0;
+    int32_t tid = -1, pos = 0;
+    uint32_t c0 = 0, c1 = 0;
+    int32_t endpos = 0;
+    if (live)
+    {
+      flag = a.flag[i];
+      mapq = a.mapq[i];
+      tid = a.tid[i];
+      pos = a.pos[i];
+      c0 = a.cigar_off[i];
+      c1 = a.cigar_off[i + 1];
+      // A1 (:1932): PAIRED && PROPER && !(UNMAP|SECONDARY|QCFAIL|DUP)
+      if ((flag & 1) && (flag & 2) && !(flag & (0x4 | 0x100 | 0x200 | 0x400)))
+      {
+        int v = a.isize[i];
+        v = v < 0 ? -v : v;
+        isum += (unsigned long long) (long long) v;
+        icnt += 1;
+        isq += (double) v * (double) v;
+        vmax = max(vmax, (unsigned int) v);
+      }
+      // bam_endpos for the span bound used by the region selects
+      if (!(flag & 4) && c1 > c0)
+        endpos = pos + cigar_reflen_hts(a.cigar + c0, c1 - c0);
+      else
+        endpos = pos + 1;
+      int sp = endpos - pos;
+      span = max(span, (unsigned int) (sp < 0 ? 0 : sp));
+      if (i > 0)
+      {
+        uint32_t pt = (uint32_t) a.tid[i - 1], ct = (uint32_t) tid;
+        if (pt > ct || (pt == ct && a.pos[i - 1] > pos)) unsorted = 1;
+      }
+    }
+    // A2 (:1419-1420): mapq >= q && !DUP && !SECONDARY && PAIRED && !PROPER_PAIR
+    const bool cand = live && ((int) mapq >= a.mapq_min) && !(flag & 0x400) && !(flag & 0x100) && (flag & 1) && !(flag & 2);
+    {
+      uint64_t m = __ballot(cand);
+      if (m)
+      {
+        unsigned long long base = 0;
+        int leader = __ffsll((long long) m) - 1;
+        if (lane == leader) base = atomicAdd(&a.counters->n_cand, (unsigned long long) __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (cand)
+        {
+          unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (slot < a.cand_cap)
+          {
+            Cand c;
+            c.qhash = a.qhash[i];
+            c.rec = (uint32_t) i;
+            c.tid = tid;
+            c.pos = pos;
+            c.mtid = a.mtid[i];
+            c.mpos = a.mpos[i];
+            c.flag = flag;
+            c.mapq = mapq;
+            c.pad = 0;
+            a.cand[slot] = c;
+          }
+        }
+      }
+    }
+    // A12 per-read evidence
+    if (live)
+    {
+      bk_split t;
+      if (record_split(a, i, flag, tid, pos, c0, c1, endpos, t))
+      {
+        unsigned long long slot = atomicAdd(&a.counters->n_split, 1ull);
+        if (slot < a.split_cap) a.split[slot] = t;
+      }
+    }
+  }
+  // block reduction of the scalar accumulators
+  for (int d = 32; d; d >>= 1)
+  {
+    isum += __shfl_down(isum, d, 64);
+    icnt += __shfl_down(icnt, d, 64);
+    isq += __shfl_down(isq, d, 64);
+    span = max(span, (unsigned int) __shfl_down((int) span, d, 64));
+    vmax = max(vmax, (unsigned int) __shfl_down((int) vmax, d, 64));
+    unsorted |= (unsigned int) __shfl_down((int) unsorted, d, 64);
+  }
+  if (lane == 0)
+  {
+    s_sum[w] = isum;
+    s_n[w] = icnt;
+    s_sq[w] = isq;
+    s_span[w] = span;
+    s_vmax[w] = vmax;
+    if (unsorted) atomicOr(&a.counters->unsorted, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    unsigned long long ts = 0, tn = 0;
+    double tq = 0;
+    unsigned int sp = 1, vm = 0;
+    for (int k = 0; k < 4; ++k)
+    {
+      ts += s_sum[k];
+      tn += s_n[k];
+      tq += s_sq[k];
+      sp = max(sp, s_span[k]);
+      vm = max(vm, s_vmax[k]);
+    }
+    if (tn)
+    {
+      atomicAdd(&a.counters->isize_sum, ts);
+      atomicAdd(&a.counters->isize_n, tn);
+      atomicAdd(&a.sd->sumsq, tq);
+      atomicMax(&a.sd->vmax, vm);
+    }
+    atomicMax(&a.counters->max_span, sp);
+  }
+}
+
+// ---- bit-exact sd replay ----------------------------------------------------------------------------
+// The reference accumulates  long T += (v-mean)^2  with a truncation after every add (:1942-1946).
+// For T < 2^51 one step adds floor(d) unless d lies within half an ulp(T+d) below an integer, where the
+// double add rounds up to the next integer ("exception").  floor(d) sums are order independent; only the
+// rare exceptions need the running T, so they are compacted in record order with their exact prefix
+// sum and replayed by one wave.
+constexpr int SD_ITEMS = 8;
+constexpr int SD_TILE = 256 * SD_ITEMS;
+
+__device__ __forceinline__ bool sd_elem(const uint16_t *__restrict__ flag, const int32_t *__restrict__ isize, uint64_t i, uint64_t n, double mean,
+                                        double thr, double &d, unsigned long long &fd, bool &exc)
+{
+  d = 0;
+  fd = 0;
+  exc = false;
+  if (i >= n) return false;
+  uint16_t f = flag[i];
+  if (!((f & 1) && (f & 2) && !(f & (0x4 | 0x100 | 0x200 | 0x400)))) return false;
+  int v = isize[i];
+  v = v < 0 ? -v : v;
+  double a = __dsub_rn((double) v, mean);
+  d = __dmul_rn(a, a);
+  double fl = floor(d);
+  fd = (unsigned long long) fl;
+  double gap = __dsub_rn(__dadd_rn(fl, 1.0), d);  // distance to the next integer (exact for d < 2^52)
+  exc = gap <= thr;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_sd_count(const uint16_t *__restrict__ flag, const int32_t *__restrict__ isize, uint64_t n, double mean, double thr,
+                                                  unsigned long long *__restrict__ blockL, unsigned long long *__restrict__ blockE)
+{
+  __shared__ unsigned long long lds[4];
+  unsigned long long L = 0, E = 0;
+  uint64_t base = (uint64_t) blockIdx.x * SD_TILE;
+#pragma unroll
+  for (int k = 0; k < SD_ITEMS; ++k)
+  {
+    double d;
+    unsigned long long fd;
+    bool exc;
+    sd_elem(flag, isize, base + (uint64_t) k * 256 + threadIdx.x, n, mean, thr, d, fd, exc);
+    L += fd;
+    E += exc ? 1ull : 0ull;
+  }
+  unsigned long long tot;
+  (void) prims::block_exclusive_scan(L, lds, tot);
+  if (threadIdx.x == 0) blockL[blockIdx.x] = tot;
+  (void) prims::block_exclusive_scan(E, lds, tot);
+  if (threadIdx.x == 0) blockE[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_sd_emit(const uint16_t *__restrict__ flag, const int32_t *__restrict__ isize, uint64_t n, double mean, double thr,
+                                                 const unsigned long long *__restrict__ baseL, const unsigned long long *__restrict__ baseE,
+                                                 SdException *__restrict__ out)
+{
+  __shared__ unsigned long long lds[4];
+  if (baseE[blockIdx.x + 1] == baseE[blockIdx.x]) return;  // block has no exception
+  unsigned long long carryL = baseL[blockIdx.x], carryE = baseE[blockIdx.x];
+  uint64_t base = (uint64_t) blockIdx.x * SD_TILE;
+#pragma unroll 1
+  for (int k = 0; k < SD_ITEMS; ++k)
+  {
+    double d;
+    unsigned long long fd;
+    bool exc;
+    sd_elem(flag, isize, base + (uint64_t) k * 256 + threadIdx.x, n, mean, thr, d, fd, exc);
+    unsigned long long totL, totE;
+    unsigned long long exL = prims::block_exclusive_scan(fd, lds, totL);
+    unsigned long long exE = prims::block_exclusive_scan(exc ? 1ull : 0ull, lds, totE);
+    if (exc)
+    {
+      SdException e;
+      e.l_before = carryL + exL;
+      e.d = d;
+      out[carryE + exE] = e;
+    }
+    carryL += totL;
+    carryE += totE;
+  }
+}
+
+// one wave: replay the exceptions in record order
+__global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ ex, const unsigned long long *n_ex_p, const unsigned long long *l_total_p,
+                                                SdState *s)
+{
+  const unsigned long long n_ex = *n_ex_p;
+  const int lane = threadIdx.x;
+  long long corr = 0;
+  for (unsigned long long base = 0; base < n_ex; base += 64)
+  {
+    unsigned long long i = base + lane;
+    unsigned long long lb = 0;
+    double d = 0;
+    if (i < n_ex)
+    {
+      lb = ex[i].l_before;
+      d = ex[i].d;
+    }
+    int cnt = (int) min((unsigned long long) 64, n_ex - base);
+    for (int j = 0; j < cnt; ++j)
+    {
+      unsigned long long lbj = __shfl(lb, j, 64);
+      double dj = __shfl(d, j, 64);
+      long long tprev = (long long) lbj + corr;
+      long long tnew = (long long) __dadd_rn((double) tprev, dj);  // long += double
+      corr += (tnew - tprev) - (long long) floor(dj);
+    }
+  }
+  if (lane == 0)
+  {
+    s->t_final = (long long) *l_total_p + corr;
+  }
+}
+}  // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------
+void launch_stream(const StreamArgs &a, hipStream_t st)
+{
+  if (a.n == 0) return;
+  unsigned blocks = cdiv(a.n, 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st)
+{
+  uint32_t nb = cdiv(n, SD_TILE);
+  if (nb == 0) nb = 1;
+  unsigned long long *blockL = b.blockL.as<unsigned long long>(nb + 1);
+  unsigned long long *blockE = b.blockE.as<unsigned long long>(nb + 1);
+  hipLaunchKernelGGL(k_sd_count, dim3(nb), dim3(256), 0, st, flag, isize, n, mean, thr, blockL, blockE);
+  prims::exclusive_scan<unsigned long long>(blockL, blockL, nb, b.scan_tmp, st);
+  prims::exclusive_scan<unsigned long long>(blockE, blockE, nb, b.scan_tmp2, st);
+  // exception capacity: read the total back (tiny sync) so the list can be sized exactly
+  unsigned long long n_ex = 0;
+  HIP_CHECK(hipMemcpyAsync(&n_ex, blockE + nb, sizeof n_ex, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  SdException *ex = b.exceptions.as<SdException>(n_ex + 1);
+  if (n_ex) hipLaunchKernelGGL(k_sd_emit, dim3(nb), dim3(256), 0, st, flag, isize, n, mean, thr, blockL, blockE, ex);
+  hipLaunchKernelGGL(k_sd_walk, dim3(1), dim3(64), 0, st, ex, blockE + nb, blockL + nb, sd);
+  b.last_exceptions = n_ex;
+}

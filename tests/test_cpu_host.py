@@ -1,0 +1,60 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the BAM decoder reproduces the generator's SoA, the product refuses to run without a GPU."""
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+from breakid_amd import abi, capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "breakid_hip.h")).read()
+    return sorted(set(re.findall(r"^(?:int|void|uint64_t|const char \*)\s*(bk_[a-z_0-9]+)\s*\(", txt, re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(capi.LIB_PATH):
+        capi.build()
+    L = capi.lib()
+    syms = _declared_symbols()
+    assert set(capi.EXPORTS) <= set(syms)
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.BreakIDError) as e:
+        capi.Context([("chr1", 1000)])
+    assert e.value.code == abi.BK_ERR_NO_DEVICE
+
+
+def test_bam_decoder_matches_generator():
+    ds = synth.make_g1()
+    ds.recs[5].oc = "50M50S"
+    ds.recs[5].sa = "chr2,100,+,50S50M,60,0;"
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "a.bam")
+        ds.write_bam(p)
+        contigs, cols = capi.decode_bam(p)
+    ref = ds.to_soa()
+    assert contigs == ds.contigs
+    for k, _ in abi.SOA_COLS:
+        assert np.array_equal(cols[k], ref[k]), k
+
+
+def test_qname_hash_matches_python():
+    L = capi.lib()
+    for s in [b"", b"a", b"read/1", b"L12_3", b"x" * 200]:
+        assert L.bk_qname_hash(s, len(s)) == synth.fnv1a64(s)
+
+
+def test_abi_struct_sizes():
+    assert abi.PAIR.itemsize == 48 and abi.SPLIT.itemsize == 80 and abi.CLUSTER.itemsize == 72

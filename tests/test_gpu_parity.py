@@ -1,0 +1,98 @@
+"""GPU parity: libbreakid_hip.so (through its C ABI) against the CPU oracle and the reference's golden
+stage dumps.  Bit-exact for every integer / index quantity; mean, sd, w compared as IEEE doubles."""
+import os
+
+import numpy as np
+import pytest
+
+from breakid_amd import abi, capi, synth
+from oracle import pyoracle
+from tests import refdump
+
+pytestmark = pytest.mark.gpu
+
+DATASETS = ["g1", "g2", "small", "ties"]
+
+
+def _run_gpu(contigs, cols, fast, qual=20):
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    mean, sd = ctx.isize_stats()
+    w = capi.w_from(mean, sd)
+    ctx.discordant_pairs(qual, w)
+    ctx.mask_and_cluster(w, fast)
+    ctx.split_evidence()
+    ctx.cluster_summary(w)
+    ctx.split_breakpoints(w)
+    return ctx, mean, sd, w
+
+
+def _compare_stages(ctx, o):
+    for st in (abi.STAGE_GROUP_KEYS, abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_SPLITS, abi.STAGE_CLUSTERS):
+        a, ao = ctx.fetch(st)
+        b, bo = o.fetch(st)
+        assert len(a) == len(b), (st, len(a), len(b))
+        if ao is not None or bo is not None:
+            assert np.array_equal(ao, bo), (st, ao, bo)
+        if not np.array_equal(a, b):
+            bad = [i for i in range(len(a)) if a[i] != b[i]][:5]
+            raise AssertionError("stage %d differs at %s:\n gpu=%s\n ref=%s" % (st, bad, a[bad], b[bad]))
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_fast_matches_reference_dump_and_oracle(golden_dir, name):
+    contigs, cols = refdump.load_soa(golden_dir, name)
+    dump = refdump.parse_stages(os.path.join(golden_dir, "%s.fast.stages.txt" % name))
+    ctx, mean, sd, w = _run_gpu(contigs, cols, fast=True)
+    refdump.compare_with_dump(dump, [n for n, _ in contigs], ctx.fetch, mean, sd, w)
+    o = pyoracle.Oracle(contigs, cols)
+    o.run(20, fast=True)
+    _compare_stages(ctx, o)
+    ctx.close()
+    o.close()
+
+
+@pytest.mark.parametrize("seed,n,loci,ppl,noise", [(11, 60_000, 80, 30, 400), (12, 150_000, 30, 200, 2000)])
+def test_fast_random_vs_oracle(seed, n, loci, ppl, noise):
+    contigs = [("chr1", 5_000_000), ("chr2", 4_000_000), ("chr10", 3_000_000), ("chrX", 2_000_000)]
+    ds = synth.make_cfg(seed, contigs, n, loci, ppl, noise, jitter=250, read_len=100)
+    cols = ds.to_soa()
+    ctx, mean, sd, w = _run_gpu(contigs, cols, fast=True)
+    o = pyoracle.Oracle(contigs, cols)
+    om, os_ = o.isize_stats()
+    assert (mean, sd) == (om, os_)
+    o.run(20, fast=True)
+    _compare_stages(ctx, o)
+    ctx.close()
+    o.close()
+
+
+def test_empty_and_tiny_inputs():
+    contigs = [("chr1", 100000), ("chr2", 100000)]
+    ds = synth.Dataset(contigs)
+    rng = np.random.default_rng(1)
+    for i in range(40):
+        ds.recs += synth._proper_pair(rng, i, 0, 100, 90000, 100, 300, 30)
+    ds.sort()
+    cols = ds.to_soa()
+    ctx, mean, sd, w = _run_gpu(contigs, cols, fast=True)
+    o = pyoracle.Oracle(contigs, cols)
+    assert (mean, sd) == o.isize_stats()
+    o.run(20, fast=True)
+    _compare_stages(ctx, o)
+    ctx.close()
+
+
+def test_unsorted_records_are_rejected():
+    contigs = [("chr1", 100000)]
+    ds = synth.Dataset(contigs)
+    rng = np.random.default_rng(1)
+    for i in range(10):
+        ds.recs += synth._proper_pair(rng, i, 0, 100, 90000, 100, 300, 30)
+    cols = ds.to_soa()  # not sorted
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.isize_stats()
+    assert e.value.code == abi.BK_ERR_UNSORTED
+    ctx.close()
