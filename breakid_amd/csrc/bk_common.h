@@ -32,6 +32,26 @@ struct DevBuf
 {
   void *p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap)
+  {
+    o.p = nullptr;
+    o.cap = 0;
+  }
+  DevBuf &operator=(DevBuf &&o) noexcept
+  {
+    if (this != &o)
+    {
+      release();
+      p = o.p;
+      cap = o.cap;
+      o.p = nullptr;
+      o.cap = 0;
+    }
+    return *this;
+  }
   ~DevBuf() { release(); }
   void release()
   {

@@ -59,7 +59,10 @@ __global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__rest
   Seg sg = segs[s];
   if (sg.depth == 0)
   {
-    atomicOr(err, 1u);  // std::sort would switch to heapsort here; not emulated (needs 2*log2(n) bad splits)
+    // std::sort switches to heapsort here (__partial_sort(first,last,last)); k_se_heapsort finishes the segment
+    segs[s].depth = -1;
+    atomicAdd(err + 3, 1u);
+    return;
   }
   uint32_t first = sg.first, last = sg.last;
   uint32_t a = first + 1, b = first + (last - first) / 2, c = last - 1;
@@ -84,6 +87,67 @@ __global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__rest
   segs[s].depth = sg.depth - 1;
 }
 
+// libstdc++ __adjust_heap / __push_heap on parallel (key, idx) arrays, comparator a.key < b.key
+__device__ void adjust_heap(uint32_t *__restrict__ k, uint32_t *__restrict__ x, long hole, long len, uint32_t vk, uint32_t vx)
+{
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2)
+  {
+    child = 2 * (child + 1);
+    if (k[child] < k[child - 1]) child--;
+    k[hole] = k[child];
+    x[hole] = x[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2)
+  {
+    child = 2 * (child + 1);
+    k[hole] = k[child - 1];
+    x[hole] = x[child - 1];
+    hole = child - 1;
+  }
+  long parent = (hole - 1) / 2;
+  while (hole > top && k[parent] < vk)
+  {
+    k[hole] = k[parent];
+    x[hole] = x[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  k[hole] = vk;
+  x[hole] = vx;
+}
+// __heap_select(first,last,last) + __sort_heap: one lane per exhausted segment (they are rare and short)
+__global__ void k_se_heapsort(const Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Seg sg = segs[s];
+  if (sg.depth != -1) return;
+  uint32_t *k = key + sg.first, *x = idx + sg.first;
+  long len = (long) sg.last - (long) sg.first;
+  if (len >= 2)
+  {
+    long parent = (len - 2) / 2;
+    while (true)
+    {
+      adjust_heap(k, x, parent, len, k[parent], x[parent]);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  long last = len;
+  while (last > 1)
+  {
+    --last;
+    uint32_t vk = k[last], vx = x[last];
+    k[last] = k[0];
+    x[last] = x[0];
+    adjust_heap(k, x, 0, last, vk, vx);
+  }
+}
+
 __device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t p)
 {
   // largest s with segs[s].first <= p, or ~0u
@@ -95,7 +159,7 @@ __device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint3
   }
   if (lo == 0) return 0xFFFFFFFFu;
   uint32_t s = lo - 1;
-  return p < segs[s].last ? s : 0xFFFFFFFFu;
+  return (p < segs[s].last && segs[s].depth >= 0) ? s : 0xFFFFFFFFu;
 }
 
 // lr[p] = (#L-stopper at p) | (#R-stopper at p) << 32 ; segof[p] = segment index or ~0
@@ -188,13 +252,14 @@ __global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, uint
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   Seg sg = segs[s];
-  cnt[s] = ((sg.cut - sg.first) > 16 ? 1u : 0u) + ((sg.last - sg.cut) > 16 ? 1u : 0u);
+  cnt[s] = sg.depth < 0 ? 0u : ((sg.cut - sg.first) > 16 ? 1u : 0u) + ((sg.last - sg.cut) > 16 ? 1u : 0u);
 }
 __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ off, Seg *__restrict__ out)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   Seg sg = segs[s];
+  if (sg.depth < 0) return;
   uint32_t o = off[s];
   if ((sg.cut - sg.first) > 16)
   {
@@ -254,6 +319,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     {
       if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
       hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err);
+      hipLaunchKernelGGL(k_se_heapsort, dim3(cdiv(ns, 64)), dim3(64), 0, st, segs, ns, key, idx);
       hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, n, lr, segof);
       prims::exclusive_scan<unsigned long long>(lr, lr, n, b.scan_tmp, st);
       hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, n, lr, posL, posR);
@@ -269,10 +335,6 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       ns = ns2;
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
-    uint32_t e = 0;
-    HIP_CHECK(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (e) throw bk_error(BK_ERR_LIMIT, "std::sort emulation hit introsort's depth limit (heapsort branch is not emulated)");
   }
   // __final_insertion_sort == stable sort by key of what the introsort loop left
   uint64_t *ck = b.ck.as<uint64_t>(n);

@@ -1041,9 +1041,8 @@ uint32_t base_depth(Oracle &o, int tid, uint64_t pos)
 int ora_split_breakpoints(ora *o, double wd)
 {
   const int w = (int) wd;  // :390 `const int w`
-  std::vector<bk_cluster> out;
   std::vector<VoteIn> s1, s2;
-  for (auto c : o->clusters)
+  for (auto &c : o->clusters)  // every cluster stays in the stage output; flags bit1 marks the survivors (:481)
   {
     uint32_t r1s = (uint32_t) ((uint64_t) c.p1_mean - w), r1e = (uint32_t) ((uint64_t) c.p1_mean + w);
     uint32_t r2s = (uint32_t) ((uint64_t) c.p2_mean - w), r2e = (uint32_t) ((uint64_t) c.p2_mean + w);
@@ -1074,11 +1073,9 @@ int ora_split_breakpoints(ora *o, double wd)
         c.depth1 = base_depth(*o, c.p1_tid, (uint64_t) c.p1_exact);
         c.depth2 = base_depth(*o, c.p2_tid, (uint64_t) (int64_t) c.p2_exact);
         c.flags |= 2;
-        out.push_back(c);
       }
     }
   }
-  o->clusters = out;
   return 0;
 }
 

@@ -96,3 +96,23 @@ def test_unsorted_records_are_rejected():
         ctx.isize_stats()
     assert e.value.code == abi.BK_ERR_UNSORTED
     ctx.close()
+
+
+def test_wgs_shape_device_resident_vs_oracle():
+    """hg19-shaped table generated in HBM, handed over by device pointers (BK_MEM_DEVICE).  Same-chr groups
+    of this shape drive std::sort into its heapsort branch (introsort depth limit), which must be emulated."""
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs(2_000_000, 12346, dev)
+    host = synth_gpu.to_numpy_cols(cols)
+    ctx = capi.Context(contigs)
+    ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w, n_valid = ctx.run(qual=20, fast=True)
+    o = pyoracle.Oracle(contigs, host)
+    ow, rc = o.run(20, fast=True)
+    assert rc == 0 and w == ow
+    _compare_stages(ctx, o)
+    assert n_valid == 400
+    ctx.close()
+    o.close()
