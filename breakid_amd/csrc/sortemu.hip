@@ -15,6 +15,8 @@
 #include "bk_common.h"
 #include "prims.h"
 #include "sortemu.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace
 {
@@ -62,6 +64,8 @@ __global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__rest
     // std::sort switches to heapsort here (__partial_sort(first,last,last)); k_se_heapsort finishes the segment
     segs[s].depth = -1;
     atomicAdd(err + 3, 1u);
+    atomicAdd(err + 2, sg.last - sg.first);
+    atomicMax(err + 1, sg.last - sg.first);
     return;
   }
   uint32_t first = sg.first, last = sg.last;
@@ -335,6 +339,13 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       ns = ns2;
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
+  }
+  if (getenv("BK_DEBUG_SORT"))
+  {
+    uint32_t e[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
   }
   // __final_insertion_sort == stable sort by key of what the introsort loop left
   uint64_t *ck = b.ck.as<uint64_t>(n);
