@@ -36,7 +36,7 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close"]
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort"]
 
 
 def lib():
@@ -45,6 +45,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BreakIDError(abi.BK_ERR_NO_DEVICE, "libbreakid_hip.so is not built (run __graft_entry__.build()); "
                                                      "there is no CPU fallback")
+        try:
+            # when PyTorch-ROCm lives in the same process it must load its HIP runtime first: two copies of
+            # libamdhip64 (torch's bundled one and /opt/rocm's) cannot both own the device
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, u64p, dp = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)
         L.bk_init.argtypes = [C.c_int, vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
@@ -65,6 +71,7 @@ def lib():
         L.bk_timing.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
                                 C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]
         L.bk_timing_enable.argtypes = [vp, C.c_int]
+        L.bk_debug_std_sort.argtypes = [vp, vp, vp, C.c_uint32, vp]
         L.bk_qname_hash.restype = C.c_uint64
         L.bk_qname_hash.argtypes = [C.c_char_p, C.c_size_t]
         L.bk_bam_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -180,6 +187,13 @@ class Context:
         except RuntimeError:
             self._check(-1 if not self.L.bk_last_error(self.h) else abi.BK_ERR_ARG)
             raise
+
+    def debug_std_sort(self, key, group_off):
+        key = np.ascontiguousarray(key, np.uint32)
+        group_off = np.ascontiguousarray(group_off, np.uint64)
+        perm = np.zeros(len(key), np.uint32)
+        self._check(self.L.bk_debug_std_sort(self.h, key.ctypes.data, group_off.ctypes.data, len(group_off) - 1, perm.ctypes.data))
+        return perm
 
     def timing_enable(self, on=True):
         self._check(self.L.bk_timing_enable(self.h, int(on)))

@@ -61,12 +61,12 @@ struct bk_ctx
   bool have_records = false;
 
   // stream pass
-  DevBuf d_counters, d_sd, d_cand, d_split_raw, d_split;
+  DevBuf d_counters, d_sd, d_cand, d_split_raw, d_split, d_sa_list;
   StreamCounters hc{};
   SdState hsd{};
   bool stream_done = false, splits_sorted = false;
   int mapq_min = 20;
-  uint64_t cand_cap = 0, split_cap = 0;
+  uint64_t cand_cap = 0, split_cap = 0, sa_cap = 0;
   SdBufs sdb;
   double mean = 0, sd = 0;
   bool stats_done = false;
@@ -216,14 +216,15 @@ void run_stream(bk_ctx *c)
   if (!c->have_records) throw bk_error(BK_ERR_ARG, "no records uploaded");
   const uint64_t n = c->rec.n;
   if (c->cand_cap == 0) c->cand_cap = std::max<uint64_t>(1u << 16, n / 8 + 1024);
-  if (c->split_cap == 0) c->split_cap = std::max<uint64_t>(1u << 14, n / 16 + 1024);
+  if (c->split_cap == 0) c->split_cap = std::max<uint64_t>(1u << 14, n / 32 + 1024);
+  if (c->sa_cap == 0) c->sa_cap = std::max<uint64_t>(1u << 14, n / 16 + 1024);
+  StreamArgs a{};
   for (int attempt = 0; attempt < 3; ++attempt)
   {
     StreamCounters *dc = c->d_counters.as<StreamCounters>(1);
     SdState *dsd = c->d_sd.as<SdState>(1);
     HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(StreamCounters), c->st));
     HIP_CHECK(hipMemsetAsync(dsd, 0, sizeof(SdState), c->st));
-    StreamArgs a{};
     a.n = n;
     a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
     a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash;
@@ -236,22 +237,38 @@ void run_stream(bk_ctx *c)
     a.cand_cap = c->cand_cap;
     a.split = c->d_split_raw.as<bk_split>(c->split_cap);
     a.split_cap = c->split_cap;
+    a.sa_list = c->d_sa_list.as<uint32_t>(c->sa_cap);
+    a.sa_cap = c->sa_cap;
     {
-      // algorithmic bytes of this pass: 39 B/record + CIGAR words + aux bytes (+ outputs, added after)
-      Scope s(c, "k_stream", 39ull * n + 4ull * c->rec.n_cigar_words + c->rec.n_aux_bytes);
+      // algorithmic bytes of this pass: 39 B/record + 4 B per CIGAR op (+ 32 B per candidate, added below)
+      Scope s(c, "k_stream", 39ull * n + 4ull * c->rec.n_cigar_words);
       launch_stream(a, c->st);
     }
     HIP_CHECK(hipMemcpyAsync(&c->hc, dc, sizeof(StreamCounters), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipMemcpyAsync(&c->hsd, dsd, sizeof(SdState), hipMemcpyDeviceToHost, c->st));
     HIP_CHECK(hipStreamSynchronize(c->st));
-    if (c->hc.n_cand <= c->cand_cap && c->hc.n_split <= c->split_cap) break;
+    if (c->hc.n_cand <= c->cand_cap && c->hc.n_sa <= c->sa_cap) break;
     if (c->timing && !c->timers.empty()) c->timers.pop_back();  // overflowed attempt is not a measured pass
     c->cand_cap = std::max<uint64_t>(c->cand_cap, c->hc.n_cand + 1024);
-    c->split_cap = std::max<uint64_t>(c->split_cap, c->hc.n_split + 1024);
+    c->sa_cap = std::max<uint64_t>(c->sa_cap, c->hc.n_sa + 1024);
     if (attempt == 2) throw bk_error(BK_ERR_LIMIT, "stream pass: output capacity");
   }
-  if (c->timing && !c->timers.empty()) c->timers.back().bytes += 32ull * c->hc.n_cand + 48ull * c->hc.n_split;
+  if (c->timing && !c->timers.empty()) c->timers.back().bytes += 32ull * c->hc.n_cand + 4ull * c->hc.n_sa;
   if (c->hc.unsorted) throw bk_error(BK_ERR_UNSORTED, "records are not coordinate sorted (the reference requires an indexed, sorted BAM)");
+  // rare path: evidence tuples of the SA-bearing records (capacity = one tuple per listed record)
+  if (c->hc.n_sa > c->split_cap)
+  {
+    c->split_cap = c->hc.n_sa + 1024;
+    a.split = c->d_split_raw.as<bk_split>(c->split_cap);
+    a.split_cap = c->split_cap;
+  }
+  {
+    Scope s(c, "k_split_records", c->rec.n_aux_bytes + 4ull * c->hc.n_sa);
+    launch_split_records(a, c->hc.n_sa, c->st);
+  }
+  HIP_CHECK(hipMemcpyAsync(&c->hc, c->d_counters.get<StreamCounters>(), sizeof(StreamCounters), hipMemcpyDeviceToHost, c->st));
+  HIP_CHECK(hipStreamSynchronize(c->st));
+  if (c->timing && !c->timers.empty()) c->timers.back().bytes += 48ull * c->hc.n_split;
   c->stream_done = true;
   c->splits_sorted = false;
   c->stats_done = false;
@@ -617,6 +634,26 @@ int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const u
     default:
       throw bk_error(BK_ERR_ARG, "bk_fetch: unknown stage");
     }
+  });
+}
+
+int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_off, uint32_t n_groups, uint32_t *perm_out)
+{
+  return guarded(ctx, [&] {
+    if (!key || !group_off || !perm_out) throw bk_error(BK_ERR_ARG, "bk_debug_std_sort: null argument");
+    const uint64_t n = group_off[n_groups];
+    DevBuf dk, dp, dgof, dgoff;
+    std::vector<uint32_t> gof(n), iota(n);
+    for (uint32_t g = 0; g < n_groups; ++g)
+      for (uint64_t p = group_off[g]; p < group_off[g + 1]; ++p) gof[p] = g;
+    std::iota(iota.begin(), iota.end(), 0u);
+    HIP_CHECK(hipMemcpy(dk.as<uint32_t>(n + 1), key, n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dp.as<uint32_t>(n + 1), iota.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dgof.as<uint32_t>(n + 1), gof.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dgoff.as<uint64_t>((uint64_t) n_groups + 1), group_off, ((uint64_t) n_groups + 1) * 8, hipMemcpyHostToDevice));
+    std_sort_groups(dk.get<uint32_t>(), dp.get<uint32_t>(), dgof.get<uint32_t>(), dgoff.get<uint64_t>(), n_groups, n, ctx->cb.se, ctx->st);
+    HIP_CHECK(hipMemcpyAsync(perm_out, dp.get<uint32_t>(), n * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
   });
 }
 

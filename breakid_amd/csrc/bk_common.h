@@ -96,8 +96,8 @@ struct StreamCounters
   unsigned long long n_split;     // split tuples appended
   unsigned int max_span;          // max(bam_endpos - pos)
   unsigned int unsorted;          // 1 if (tid,pos) order violated
-  unsigned long long cigar_words; // traffic accounting
-  unsigned long long aux_bytes;
+  unsigned long long n_sa;        // SA-bearing records handed to k_split_records
+  unsigned long long pad0;
 };
 
 // interned chromosome-name table (device copy): open addressing on FNV-1a of the text

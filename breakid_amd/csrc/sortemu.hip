@@ -54,7 +54,7 @@ __global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, 
 }
 
 // __move_median_to_first(first, first+1, mid, last-1)
-__global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err)
+__global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
@@ -63,7 +63,8 @@ __global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__rest
   {
     // std::sort switches to heapsort here (__partial_sort(first,last,last)); k_se_heapsort finishes the segment
     segs[s].depth = -1;
-    atomicAdd(err + 3, 1u);
+    uint32_t slot = atomicAdd(err + 3, 1u);
+    heap_list[slot] = make_uint2(sg.first, sg.last);
     atomicAdd(err + 2, sg.last - sg.first);
     atomicMax(err + 1, sg.last - sg.first);
     return;
@@ -91,64 +92,196 @@ __global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__rest
   segs[s].depth = sg.depth - 1;
 }
 
-// libstdc++ __adjust_heap / __push_heap on parallel (key, idx) arrays, comparator a.key < b.key
-__device__ void adjust_heap(uint32_t *__restrict__ k, uint32_t *__restrict__ x, long hole, long len, uint32_t vk, uint32_t vx)
+// ---- heapsort branch of std::sort (__partial_sort(first,last,last) = make_heap + sort_heap) ----------------
+// libstdc++'s __adjust_heap moves the hole to the bottom along the larger-child path and pushes the value back
+// up with a strict compare; the net effect equals a top-down sift that stops at the first node whose larger
+// child is < value (ties between children go to the right child, equal child keeps descending).  In that form
+// every write is final when it is made, so
+//   * make_heap runs level by level (nodes of one depth own disjoint subtrees), and
+//   * the pops of sort_heap are pipelined inside one wavefront: pop t+1 starts two steps behind pop t and
+//     stalls while an in-flight pop could still reach the leaf it is about to detach (ancestor test).
+// Verified on the host against std::partial_sort on tie-heavy inputs.
+struct HeapSeg
 {
-  const long top = hole;
-  long child = hole;
-  while (child < (len - 1) / 2)
+  uint32_t first, last;
+};
+
+struct LdsMem
+{
+  uint32_t *k, *x;
+  __device__ __forceinline__ uint32_t ldk(uint32_t i) const { return k[i]; }
+  __device__ __forceinline__ uint32_t ldx(uint32_t i) const { return x[i]; }
+  __device__ __forceinline__ void st(uint32_t i, uint32_t kv, uint32_t xv) const
   {
-    child = 2 * (child + 1);
-    if (k[child] < k[child - 1]) child--;
-    k[hole] = k[child];
-    x[hole] = x[child];
-    hole = child;
+    k[i] = kv;
+    x[i] = xv;
   }
-  if ((len & 1) == 0 && child == (len - 2) / 2)
+  __device__ __forceinline__ void step_sync() const { __builtin_amdgcn_wave_barrier(); }
+};
+// global-memory variant for segments that do not fit LDS: every access goes to the XCD's L2 (agent-scope
+// relaxed atomics = sc1, no vector-L1 hit on a line another lane just rewrote) and each step drains its stores
+struct GlbMem
+{
+  uint32_t *k, *x;
+  __device__ __forceinline__ uint32_t ldk(uint32_t i) const { return __hip_atomic_load(k + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ uint32_t ldx(uint32_t i) const { return __hip_atomic_load(x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ void st(uint32_t i, uint32_t kv, uint32_t xv) const
   {
-    child = 2 * (child + 1);
-    k[hole] = k[child - 1];
-    x[hole] = x[child - 1];
-    hole = child - 1;
+    __hip_atomic_store(k + i, kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(x + i, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  long parent = (hole - 1) / 2;
-  while (hole > top && k[parent] < vk)
-  {
-    k[hole] = k[parent];
-    x[hole] = x[parent];
-    hole = parent;
-    parent = (hole - 1) / 2;
-  }
-  k[hole] = vk;
-  x[hole] = vx;
+  __device__ __forceinline__ void step_sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+__device__ __forceinline__ bool anc_or_self(uint32_t a, uint32_t b)  // is node a an ancestor of (or equal to) node b
+{
+  uint32_t A = a + 1, B = b + 1;
+  int da = 31 - __clz(A), db = 31 - __clz(B);
+  return db >= da && (B >> (db - da)) == A;
 }
-// __heap_select(first,last,last) + __sort_heap: one lane per exhausted segment (they are rare and short)
-__global__ void k_se_heapsort(const Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
+
+// one top-down sift step of the value (vk,vx) sitting in `hole`; returns true while the hole keeps descending
+template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint32_t &hole, uint32_t len, uint32_t vk, uint32_t vx)
 {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ns) return;
-  Seg sg = segs[s];
-  if (sg.depth != -1) return;
-  uint32_t *k = key + sg.first, *x = idx + sg.first;
-  long len = (long) sg.last - (long) sg.first;
-  if (len >= 2)
+  const uint32_t right = 2 * (hole + 1), left = right - 1;
+  uint32_t c = 0, kc = 0;
+  bool has = true;
+  if (right < len)
   {
-    long parent = (len - 2) / 2;
-    while (true)
+    uint32_t kl = mem.ldk(left), kr = mem.ldk(right);
+    if (kr < kl)
     {
-      adjust_heap(k, x, parent, len, k[parent], x[parent]);
-      if (parent == 0) break;
-      parent--;
+      c = left;
+      kc = kl;
+    }
+    else
+    {
+      c = right;
+      kc = kr;
     }
   }
-  long last = len;
-  while (last > 1)
+  else if (left < len)
   {
-    --last;
-    uint32_t vk = k[last], vx = x[last];
-    k[last] = k[0];
-    x[last] = x[0];
-    adjust_heap(k, x, 0, last, vk, vx);
+    c = left;
+    kc = mem.ldk(left);
+  }
+  else
+    has = false;
+  if (has && !(kc < vk))
+  {
+    uint32_t xc = mem.ldx(c);
+    mem.st(hole, kc, xc);
+    hole = c;
+    return true;
+  }
+  mem.st(hole, vk, vx);
+  return false;
+}
+
+// executed by one full wavefront (64 lanes, all active)
+template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
+{
+  if (m < 2) return;
+  const uint32_t lane = threadIdx.x & 63;
+  // make_heap, bottom level first
+  const uint32_t lastp = (m - 2) / 2;
+  for (int d = 31 - __clz(lastp + 1); d >= 0; --d)
+  {
+    const uint32_t lo = (1u << d) - 1;
+    uint32_t hi = (1u << (d + 1)) - 2;
+    if (hi > lastp) hi = lastp;
+    for (uint32_t base = lo; base <= hi; base += 64)
+    {
+      const uint32_t p = base + lane;
+      if (p <= hi)
+      {
+        uint32_t hole = p;
+        const uint32_t vk = mem.ldk(p), vx = mem.ldx(p);
+        while (sift_step(mem, hole, m, vk, vx))
+        {
+        }
+      }
+      mem.step_sync();
+    }
+  }
+  // sort_heap: pop t detaches leaf L = m - t, stores the maximum there and sifts the leaf's old value from the root
+  bool active = false;
+  uint32_t hole = 0, len = 0, vk = 0, vx = 0;
+  uint32_t next_t = 1;
+  int since = 2;
+  // every pop needs at most ~depth steps and a new one starts every other step unless stalled; the bound only
+  // guards against a non-terminating wave (it cannot be reached by a correct run)
+  const unsigned long long max_iter = 64ull * m + 4096ull;
+  for (unsigned long long iter = 0; iter < max_iter; ++iter)
+  {
+    if (active) active = sift_step(mem, hole, len, vk, vx);
+    mem.step_sync();
+    ++since;
+    bool launched = false;
+    if (next_t < m)
+    {
+      const uint32_t L = m - next_t;
+      const bool blocks = active && anc_or_self(hole, L);
+      if (since >= 2 && __ballot(blocks) == 0ull)
+      {
+        if (lane == (next_t & 63u))
+        {
+          vk = mem.ldk(L);
+          vx = mem.ldx(L);
+          const uint32_t k0 = mem.ldk(0), x0 = mem.ldx(0);
+          mem.st(L, k0, x0);
+          hole = 0;
+          len = L;
+          active = true;
+        }
+        mem.step_sync();
+        since = 0;
+        ++next_t;
+        launched = true;
+      }
+    }
+    if (!launched && next_t >= m && __ballot(active) == 0ull) break;
+  }
+}
+
+constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
+constexpr uint32_t HEAP_LARGE = 18432;   // 144 KiB of LDS (one wave per CU)
+
+// cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global memory)
+template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+  __shared__ uint32_t stat[CLS == 0 ? 2 * HEAP_SMALL : 2];
+  const uint32_t s = blockIdx.x;
+  if (s >= nh) return;
+  const HeapSeg sg = hs[s];
+  const uint32_t m = sg.last - sg.first;
+  const int cls = m <= HEAP_SMALL ? 0 : (m <= HEAP_LARGE ? 1 : 2);
+  if (cls != CLS) return;
+  uint32_t *gk = key + sg.first, *gx = idx + sg.first;
+  if (CLS == 2)
+  {
+    GlbMem mem{gk, gx};
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of this range may sit stale in this CU's L1
+    heapsort_wave(mem, m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    return;
+  }
+  uint32_t *lk = CLS == 0 ? stat : dyn;
+  uint32_t *lx = lk + (CLS == 0 ? HEAP_SMALL : HEAP_LARGE);
+  for (uint32_t i = threadIdx.x; i < m; i += 64)
+  {
+    lk[i] = gk[i];
+    lx[i] = gx[i];
+  }
+  __syncthreads();
+  LdsMem mem{lk, lx};
+  heapsort_wave(mem, m);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < m; i += 64)
+  {
+    gk[i] = lk[i];
+    gx[i] = lx[i];
   }
 }
 
@@ -311,6 +444,8 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   HIP_CHECK(hipStreamSynchronize(st));
   size_t max_segs = (size_t) n / 8 + ng + 16;
   Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
+  uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
+  const uint32_t ns_initial = ns;
   if (ns)
   {
     hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs);
@@ -322,8 +457,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     while (ns)
     {
       if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-      hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err);
-      hipLaunchKernelGGL(k_se_heapsort, dim3(cdiv(ns, 64)), dim3(64), 0, st, segs, ns, key, idx);
+      hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
       hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, n, lr, segof);
       prims::exclusive_scan<unsigned long long>(lr, lr, n, b.scan_tmp, st);
       hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, n, lr, posL, posR);
@@ -340,11 +474,30 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
-  if (getenv("BK_DEBUG_SORT"))
+  if (ns_initial)
   {
+    // segments that exhausted introsort's depth limit are heapsorted now (they are final: no children)
     uint32_t e[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t nh = e[3];
+    if (nh)
+    {
+      const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
+      hipLaunchKernelGGL(k_se_heapsort<0>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx);
+      if (e[1] > HEAP_SMALL)
+      {
+        static bool attr_set = false;
+        if (!attr_set)
+        {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HEAP_LARGE * 4));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh), dim3(64), 2 * HEAP_LARGE * 4, st, hl, nh, key, idx);
+      }
+      if (e[1] > HEAP_LARGE) hipLaunchKernelGGL(k_se_heapsort<2>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx);
+    }
+    if (getenv("BK_DEBUG_SORT"))
     fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
   }
   // __final_insertion_sort == stable sort by key of what the introsort loop left

@@ -49,8 +49,11 @@ struct StreamArgs
   unsigned long long cand_cap;
   bk_split *split;
   unsigned long long split_cap;
+  uint32_t *sa_list;
+  unsigned long long sa_cap;
 };
 
 void launch_stream(const StreamArgs &a, hipStream_t st);
+void launch_split_records(const StreamArgs &a, unsigned long long n_sa, hipStream_t st);
 // mean: host-computed (double) sum / (double) n; thr: exception threshold 2^(kmax-53) (or huge = replay all)
 void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st);

@@ -327,98 +327,261 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Streaming kernel.  Each lane owns 4 consecutive records per iteration (16-byte column loads), so one
+// wave-instruction moves 1 KiB per 32-bit column.  Outputs that are rare per record (5 % candidates,
+// ~1 % SA-bearing records) are staged in LDS bins and flushed with one global atomic per ~half-full bin:
+// a single device counter saturates near 90 returning atomics/us (MI355X_MICROARCH.md, dequeue row),
+// which a per-wave append would hit at this record rate.
+constexpr int ST_V = 4;             // records per lane per iteration
+constexpr int ST_CAND_CAP = 768;    // LDS candidate bin (24 KiB)
+constexpr int ST_SA_CAP = 1024;     // LDS bin of SA-bearing record indices (4 KiB)
+
+struct StreamAcc
+{
+  unsigned long long isum, icnt;
+  double isq;
+  unsigned int span, vmax, unsorted;
+};
+
+__device__ __forceinline__ void stream_record(const StreamArgs &a, uint64_t i, uint16_t flag, uint8_t mapq, int32_t tid, int32_t pos, int32_t isize, uint32_t c0, uint32_t c1,
+                                              uint32_t a0, uint32_t a1, uint32_t ptid, int32_t ppos, bool has_prev, StreamAcc &acc, bool &cand, bool &sa)
+{
+  // A1 (:1932): PAIRED && PROPER && !(UNMAP|SECONDARY|QCFAIL|DUP)
+  if ((flag & 1) && (flag & 2) && !(flag & (0x4 | 0x100 | 0x200 | 0x400)))
+  {
+    int v = isize < 0 ? -isize : isize;
+    acc.isum += (unsigned long long) (long long) v;
+    acc.icnt += 1;
+    acc.isq += (double) v * (double) v;
+    acc.vmax = max(acc.vmax, (unsigned int) v);
+  }
+  // bam_endpos span bound for the later region selects (reads the CIGAR words: 4 B per op, algorithmic)
+  int sp = 1;
+  if (!(flag & 4) && c1 > c0) sp = cigar_reflen_hts(a.cigar + c0, c1 - c0);
+  acc.span = max(acc.span, (unsigned int) (sp < 0 ? 0 : sp));
+  if (has_prev && (ptid > (uint32_t) tid || (ptid == (uint32_t) tid && ppos > pos))) acc.unsorted = 1;
+  // A2 (:1419-1420): mapq >= q && !DUP && !SECONDARY && PAIRED && !PROPER_PAIR
+  cand = ((int) mapq >= a.mapq_min) && !(flag & 0x400) && !(flag & 0x100) && (flag & 1) && !(flag & 2);
+  // A12 gate (:898): SA tag present, !DUP, PAIRED -> evaluated by k_split_records
+  sa = (a1 > a0) && !(flag & 0x400) && (flag & 1);
+}
+
 __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
 {
+  __shared__ __attribute__((aligned(16))) Cand s_cand[ST_CAND_CAP];
+  __shared__ uint32_t s_sa[ST_SA_CAP];
+  __shared__ unsigned int s_ncand, s_nsa;
+  __shared__ unsigned long long s_gbase[2];
   __shared__ unsigned long long s_sum[4], s_n[4];
   __shared__ double s_sq[4];
   __shared__ unsigned int s_span[4], s_vmax[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-  unsigned long long isum = 0, icnt = 0;
-  double isq = 0.0;
-  unsigned int span = 1, vmax = 0, unsorted = 0;
-  const uint64_t n_round = ((a.n + stride - 1) / stride) * stride;  // keep whole waves in the loop for the ballots
-  for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride)
+  if (threadIdx.x == 0)
   {
-    const bool live = i < a.n;
-    uint16_t flag = 0;
-    uint8_t mapq = 0;
-    int32_t tid = -1, pos = 0;
-    uint32_t c0 = 0, c1 = 0;
-    int32_t endpos = 0;
+    s_ncand = 0;
+    s_nsa = 0;
+  }
+  __syncthreads();
+  StreamAcc acc;
+  acc.isum = acc.icnt = 0;
+  acc.isq = 0.0;
+  acc.span = 1;
+  acc.vmax = 0;
+  acc.unsorted = 0;
+  const uint64_t nq = a.n / ST_V;  // full quads
+  const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+  const uint64_t q_round = ((nq + stride - 1) / stride) * stride;  // whole blocks stay in the loop (barriers inside)
+  for (uint64_t q = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; q < q_round; q += stride)
+  {
+    const bool live = q < nq;
+    const uint64_t i0 = q * ST_V;
+    bool cand[ST_V], sa[ST_V];
+    int32_t tidv[ST_V], posv[ST_V];
+    uint16_t flv[ST_V];
+    uint8_t mqv[ST_V];
+#pragma unroll
+    for (int k = 0; k < ST_V; ++k) cand[k] = sa[k] = false;
     if (live)
     {
-      flag = a.flag[i];
-      mapq = a.mapq[i];
-      tid = a.tid[i];
-      pos = a.pos[i];
-      c0 = a.cigar_off[i];
-      c1 = a.cigar_off[i + 1];
-      // A1 (:1932): PAIRED && PROPER && !(UNMAP|SECONDARY|QCFAIL|DUP)
-      if ((flag & 1) && (flag & 2) && !(flag & (0x4 | 0x100 | 0x200 | 0x400)))
+      const int4 t4 = reinterpret_cast<const int4 *>(a.tid)[q];
+      const int4 p4 = reinterpret_cast<const int4 *>(a.pos)[q];
+      const int4 z4 = reinterpret_cast<const int4 *>(a.isize)[q];
+      const ushort4 f4 = reinterpret_cast<const ushort4 *>(a.flag)[q];
+      const uchar4 m4 = reinterpret_cast<const uchar4 *>(a.mapq)[q];
+      const uint4 co = reinterpret_cast<const uint4 *>(a.cigar_off)[q];
+      const uint4 ao = reinterpret_cast<const uint4 *>(a.aux_off)[q];
+      const uint32_t co_n = a.cigar_off[i0 + ST_V], ao_n = a.aux_off[i0 + ST_V];
+      uint32_t ptid = 0;
+      int32_t ppos = 0;
+      if (i0 > 0)
       {
-        int v = a.isize[i];
-        v = v < 0 ? -v : v;
-        isum += (unsigned long long) (long long) v;
-        icnt += 1;
-        isq += (double) v * (double) v;
-        vmax = max(vmax, (unsigned int) v);
+        ptid = (uint32_t) a.tid[i0 - 1];
+        ppos = a.pos[i0 - 1];
       }
-      // bam_endpos for the span bound used by the region selects
-      if (!(flag & 4) && c1 > c0)
-        endpos = pos + cigar_reflen_hts(a.cigar + c0, c1 - c0);
-      else
-        endpos = pos + 1;
-      int sp = endpos - pos;
-      span = max(span, (unsigned int) (sp < 0 ? 0 : sp));
-      if (i > 0)
+      tidv[0] = t4.x; tidv[1] = t4.y; tidv[2] = t4.z; tidv[3] = t4.w;
+      posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+      flv[0] = f4.x; flv[1] = f4.y; flv[2] = f4.z; flv[3] = f4.w;
+      mqv[0] = m4.x; mqv[1] = m4.y; mqv[2] = m4.z; mqv[3] = m4.w;
+      const int32_t izv[ST_V] = {z4.x, z4.y, z4.z, z4.w};
+      const uint32_t cov[ST_V + 1] = {co.x, co.y, co.z, co.w, co_n};
+      const uint32_t aov[ST_V + 1] = {ao.x, ao.y, ao.z, ao.w, ao_n};
+#pragma unroll
+      for (int k = 0; k < ST_V; ++k)
       {
-        uint32_t pt = (uint32_t) a.tid[i - 1], ct = (uint32_t) tid;
-        if (pt > ct || (pt == ct && a.pos[i - 1] > pos)) unsorted = 1;
+        stream_record(a, i0 + k, flv[k], mqv[k], tidv[k], posv[k], izv[k], cov[k], cov[k + 1], aov[k], aov[k + 1], k ? (uint32_t) tidv[k - 1] : ptid,
+                      k ? posv[k - 1] : ppos, k ? true : (i0 > 0), acc, cand[k], sa[k]);
       }
     }
-    // A2 (:1419-1420): mapq >= q && !DUP && !SECONDARY && PAIRED && !PROPER_PAIR
-    const bool cand = live && ((int) mapq >= a.mapq_min) && !(flag & 0x400) && !(flag & 0x100) && (flag & 1) && !(flag & 2);
+    // ---- stage candidates: wave prefix over the per-lane counts, one LDS atomic per wave ----
     {
-      uint64_t m = __ballot(cand);
-      if (m)
+      unsigned int c = 0;
+#pragma unroll
+      for (int k = 0; k < ST_V; ++k) c += cand[k] ? 1u : 0u;
+      unsigned int inc = c;
+      for (int d = 1; d < 64; d <<= 1)
       {
-        unsigned long long base = 0;
-        int leader = __ffsll((long long) m) - 1;
-        if (lane == leader) base = atomicAdd(&a.counters->n_cand, (unsigned long long) __popcll(m));
-        base = __shfl(base, leader, 64);
-        if (cand)
+        unsigned int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      unsigned int total = __shfl(inc, 63, 64);
+      if (total)
+      {
+        unsigned int base = 0;
+        if (lane == 63) base = atomicAdd(&s_ncand, total);
+        base = __shfl(base, 63, 64);
+        unsigned int slot = base + inc - c;
+#pragma unroll
+        for (int k = 0; k < ST_V; ++k)
         {
-          unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot < a.cand_cap)
+          if (!cand[k]) continue;
+          const uint64_t i = i0 + k;
+          Cand cd;
+          cd.qhash = a.qhash[i];
+          cd.rec = (uint32_t) i;
+          cd.tid = tidv[k];
+          cd.pos = posv[k];
+          cd.mtid = a.mtid[i];
+          cd.mpos = a.mpos[i];
+          cd.flag = flv[k];
+          cd.mapq = mqv[k];
+          cd.pad = 0;
+          if (slot < ST_CAND_CAP)
+            s_cand[slot] = cd;
+          else
           {
-            Cand c;
-            c.qhash = a.qhash[i];
-            c.rec = (uint32_t) i;
-            c.tid = tid;
-            c.pos = pos;
-            c.mtid = a.mtid[i];
-            c.mpos = a.mpos[i];
-            c.flag = flag;
-            c.mapq = mapq;
-            c.pad = 0;
-            a.cand[slot] = c;
+            // bin overflow (denser than ~75 % candidates in this block iteration): direct append
+            unsigned long long g = atomicAdd(&a.counters->n_cand, 1ull);
+            if (g < a.cand_cap) a.cand[g] = cd;
           }
+          ++slot;
         }
       }
     }
-    // A12 per-read evidence
-    if (live)
+    // ---- stage SA-bearing record indices ----
     {
-      bk_split t;
-      if (record_split(a, i, flag, tid, pos, c0, c1, endpos, t))
+      unsigned int c = 0;
+#pragma unroll
+      for (int k = 0; k < ST_V; ++k) c += sa[k] ? 1u : 0u;
+      uint64_t any = __ballot(c != 0);
+      if (any)
       {
-        unsigned long long slot = atomicAdd(&a.counters->n_split, 1ull);
-        if (slot < a.split_cap) a.split[slot] = t;
+        unsigned int inc = c;
+        for (int d = 1; d < 64; d <<= 1)
+        {
+          unsigned int o = __shfl_up(inc, d, 64);
+          if (lane >= d) inc += o;
+        }
+        unsigned int total = __shfl(inc, 63, 64);
+        unsigned int base = 0;
+        if (lane == 63) base = atomicAdd(&s_nsa, total);
+        base = __shfl(base, 63, 64);
+        unsigned int slot = base + inc - c;
+#pragma unroll
+        for (int k = 0; k < ST_V; ++k)
+        {
+          if (!sa[k]) continue;
+          if (slot < ST_SA_CAP)
+            s_sa[slot] = (uint32_t) (i0 + k);
+          else
+          {
+            unsigned long long g = atomicAdd(&a.counters->n_sa, 1ull);
+            if (g < a.sa_cap) a.sa_list[g] = (uint32_t) (i0 + k);
+          }
+          ++slot;
+        }
       }
     }
+    __syncthreads();
+    // ---- flush bins that are at least half full (or on the last iteration) ----
+    const bool last_iter = q + stride >= q_round;  // uniform per block: all lanes share the iteration index
+    const unsigned int nc = min(s_ncand, (unsigned int) ST_CAND_CAP), ns = min(s_nsa, (unsigned int) ST_SA_CAP);
+    const bool flush_c = nc && (nc >= ST_CAND_CAP / 2 || last_iter), flush_s = ns && (ns >= ST_SA_CAP / 2 || last_iter);
+    if (flush_c || flush_s)
+    {
+      if (threadIdx.x == 0)
+      {
+        if (flush_c) s_gbase[0] = atomicAdd(&a.counters->n_cand, (unsigned long long) nc);
+        if (flush_s) s_gbase[1] = atomicAdd(&a.counters->n_sa, (unsigned long long) ns);
+      }
+      __syncthreads();
+      if (flush_c)
+      {
+        const unsigned long long g = s_gbase[0];
+        // 32-byte records as two 16-byte halves per lane pair: contiguous 16 B stores across the block
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_cand);
+        uint4 *dst = reinterpret_cast<uint4 *>(a.cand);
+        for (unsigned int h = threadIdx.x; h < nc * 2; h += 256)
+          if (g + (h >> 1) < a.cand_cap) dst[g * 2 + h] = src[h];
+      }
+      if (flush_s)
+      {
+        const unsigned long long g = s_gbase[1];
+        for (unsigned int h = threadIdx.x; h < ns; h += 256)
+          if (g + h < a.sa_cap) a.sa_list[g + h] = s_sa[h];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0)
+      {
+        if (flush_c) s_ncand = 0;
+        if (flush_s) s_nsa = 0;
+      }
+      __syncthreads();
+    }
   }
-  // block reduction of the scalar accumulators
+  // ---- tail records (n % 4) : block 0, first lanes, straight to global ----
+  if (blockIdx.x == 0 && threadIdx.x < (a.n - nq * ST_V))
+  {
+    const uint64_t i = nq * ST_V + threadIdx.x;
+    bool cand, sa;
+    const uint16_t flag = a.flag[i];
+    const uint8_t mapq = a.mapq[i];
+    const int32_t tid = a.tid[i], pos = a.pos[i];
+    uint32_t ptid = 0;
+    int32_t ppos = 0;
+    if (i > 0)
+    {
+      ptid = (uint32_t) a.tid[i - 1];
+      ppos = a.pos[i - 1];
+    }
+    stream_record(a, i, flag, mapq, tid, pos, a.isize[i], a.cigar_off[i], a.cigar_off[i + 1], a.aux_off[i], a.aux_off[i + 1], ptid, ppos, i > 0, acc, cand, sa);
+    if (cand)
+    {
+      Cand cd;
+      cd.qhash = a.qhash[i]; cd.rec = (uint32_t) i; cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
+      cd.flag = flag; cd.mapq = mapq; cd.pad = 0;
+      unsigned long long g = atomicAdd(&a.counters->n_cand, 1ull);
+      if (g < a.cand_cap) a.cand[g] = cd;
+    }
+    if (sa)
+    {
+      unsigned long long g = atomicAdd(&a.counters->n_sa, 1ull);
+      if (g < a.sa_cap) a.sa_list[g] = (uint32_t) i;
+    }
+  }
+  // ---- block reduction of the scalar accumulators ----
+  unsigned long long isum = acc.isum, icnt = acc.icnt;
+  double isq = acc.isq;
+  unsigned int span = acc.span, vmax = acc.vmax, unsorted = acc.unsorted;
   for (int d = 32; d; d >>= 1)
   {
     isum += __shfl_down(isum, d, 64);
@@ -459,6 +622,28 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
       atomicMax(&a.sd->vmax, vm);
     }
     atomicMax(&a.counters->max_span, sp);
+  }
+}
+
+// rare path: one lane per SA-bearing record (the list k_stream compacted), full evidence evaluation
+__global__ __launch_bounds__(256) void k_split_records(StreamArgs a, unsigned long long n_sa)
+{
+  unsigned long long j = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_sa) return;
+  const uint64_t i = a.sa_list[j];
+  const uint16_t flag = a.flag[i];
+  const int32_t tid = a.tid[i], pos = a.pos[i];
+  const uint32_t c0 = a.cigar_off[i], c1 = a.cigar_off[i + 1];
+  int32_t endpos;
+  if (!(flag & 4) && c1 > c0)
+    endpos = pos + cigar_reflen_hts(a.cigar + c0, c1 - c0);
+  else
+    endpos = pos + 1;
+  bk_split t;
+  if (record_split(a, i, flag, tid, pos, c0, c1, endpos, t))
+  {
+    unsigned long long slot = atomicAdd(&a.counters->n_split, 1ull);
+    if (slot < a.split_cap) a.split[slot] = t;
   }
 }
 
@@ -582,9 +767,15 @@ __global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ 
 void launch_stream(const StreamArgs &a, hipStream_t st)
 {
   if (a.n == 0) return;
-  unsigned blocks = cdiv(a.n, 256);
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  unsigned blocks = cdiv(a.n / 4 + 1, 256);
+  if (blocks > 256 * 6) blocks = 256 * 6;  // 6 resident blocks per CU (LDS bins: ~29 KiB per block)
   hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_split_records(const StreamArgs &a, unsigned long long n_sa, hipStream_t st)
+{
+  if (n_sa == 0) return;
+  hipLaunchKernelGGL(k_split_records, dim3(cdiv(n_sa, 256)), dim3(256), 0, st, a, n_sa);
 }
 
 void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st)

@@ -149,6 +149,11 @@ int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const u
 int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const uint64_t **bytes, int *n);
 int bk_timing_enable(bk_ctx *ctx, int on);
 
+/* Test hook: orders every group [group_off[g], group_off[g+1]) of `key` exactly as
+ * std::sort(first, last, [](a, b){ return a.key < b.key; }) of libstdc++ does (the reference's unstable sorts,
+ * BreakID.cc:1274-1282,1091,1127) and returns the permutation (perm_out[p] = original index of the element now at p). */
+int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_off, uint32_t n_groups, uint32_t *perm_out);
+
 /* ---- host feed (C++ BGZF/BAM decoder -> pinned SoA); replaces htslib's reader for this path --- */
 typedef struct bk_bam bk_bam;
 uint64_t bk_qname_hash(const char *name, size_t len);

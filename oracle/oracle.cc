@@ -1173,6 +1173,20 @@ int ora_unit_vote(const bk_split *s1, uint32_t n1, const bk_split *s2, uint32_t 
   return 0;
 }
 
+// std::sort of (key, original index) records by key, per group: the permutation the product must reproduce
+int ora_unit_std_sort(const uint32_t *key, const uint64_t *group_off, uint32_t n_groups, uint32_t *perm_out)
+{
+  struct KI { uint32_t key, id; };
+  for (uint32_t g = 0; g < n_groups; ++g)
+  {
+    std::vector<KI> v;
+    for (uint64_t p = group_off[g]; p < group_off[g + 1]; ++p) v.push_back(KI{key[p], (uint32_t) p});
+    std::sort(v.begin(), v.end(), [](KI a, KI b) { return a.key < b.key; });
+    for (size_t i = 0; i < v.size(); ++i) perm_out[group_off[g] + i] = v[i].id;
+  }
+  return 0;
+}
+
 uint64_t ora_text_hash(const char *s, size_t len) { return text_hash(s, len); }
 int ora_name_id(ora *o, const char *name) { return o->intern(name); }
 

@@ -44,6 +44,7 @@ def lib():
         L.ora_unit_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p,
                                       C.c_void_p, C.POINTER(C.c_int)]
         L.ora_unit_vote.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.ora_unit_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.ora_text_hash.restype = C.c_uint64
         L.ora_text_hash.argtypes = [C.c_char_p, C.c_size_t]
         L.ora_name_id.argtypes = [C.c_void_p, C.c_char_p]
@@ -163,3 +164,12 @@ def unit_vote(s1, s2, p1_chr):
     out = np.zeros(3, np.int32)
     L.ora_unit_vote(s1.ctypes.data, len(s1), s2.ctypes.data, len(s2), p1_chr, out.ctypes.data)
     return tuple(int(v) for v in out)
+
+
+def unit_std_sort(key, group_off):
+    L = lib()
+    key = np.ascontiguousarray(key, np.uint32)
+    group_off = np.ascontiguousarray(group_off, np.uint64)
+    perm = np.zeros(len(key), np.uint32)
+    L.ora_unit_std_sort(key.ctypes.data, group_off.ctypes.data, len(group_off) - 1, perm.ctypes.data)
+    return perm

@@ -116,3 +116,58 @@ def test_wgs_shape_device_resident_vs_oracle():
     assert n_valid == 400
     ctx.close()
     o.close()
+
+
+def _triangular(rng, n):
+    """x ~ U[0, y] with y increasing: the discovery-order shape of same-chromosome pairs that drives
+    median-of-3 introsort into its depth limit (heapsort branch) on large segments."""
+    y = np.sort(rng.integers(0, 200_000_000, n))
+    return (rng.random(n) * y).astype(np.uint32)
+
+
+def _median3_killer(n, div):
+    """Musser's median-of-3 killer shifted by one element (libstdc++ samples first+1, mid, last-1): drives
+    introsort into its depth limit, so std::sort heapsorts segments of up to ~n elements.  `div` adds ties."""
+    k = n // 2
+    a = np.zeros(n, np.int64)
+    i = np.arange(k)
+    a[:k] = np.where(i % 2 == 0, i + 1, k + i + (1 if k % 2 == 0 else 0))
+    a[k:2 * k] = 2 * (i + 1)
+    return (np.concatenate([[0], a]) // div).astype(np.uint32)
+
+
+@pytest.mark.parametrize("case", ["random_ties", "triangular_big", "many_groups", "sorted_and_reversed", "all_equal",
+                                  "killer_lds_small", "killer_lds_large", "killer_global", "killer_global_ties", "killer_mixed_ties"])
+def test_std_sort_emulation_matches_libstdcxx(case):
+    rng = np.random.default_rng(99)
+    if case.startswith("killer"):
+        parts = {"killer_lds_small": [_median3_killer(1000, 1), _median3_killer(1000, 2)],
+                 "killer_lds_large": [_median3_killer(12000, 2), _median3_killer(20000, 3)],
+                 "killer_global": [_median3_killer(100000, 1)],
+                 "killer_global_ties": [_median3_killer(100000, 2), _median3_killer(20000, 2)],
+                 "killer_mixed_ties": [_median3_killer(100000, 3), _median3_killer(100000, 7), _median3_killer(300000, 2)]}[case]
+        key = np.concatenate(parts)
+        off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    elif case == "random_ties":
+        key = rng.integers(0, 5000, 300_000).astype(np.uint32)
+        off = np.array([0, 300_000], np.uint64)
+    elif case == "triangular_big":  # heap segments beyond the LDS classes (global-memory pipelined heapsort)
+        parts = [_triangular(rng, 700_000), _triangular(rng, 150_000) // 50, _triangular(rng, 40_000) // 1000]
+        key = np.concatenate(parts)
+        off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    elif case == "many_groups":
+        sizes = rng.integers(0, 400, 3000)
+        key = rng.integers(0, 300, int(sizes.sum())).astype(np.uint32)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    elif case == "sorted_and_reversed":
+        a = np.sort(rng.integers(0, 10_000, 50_000)).astype(np.uint32)
+        key = np.concatenate([a, a[::-1], np.arange(17, dtype=np.uint32), np.arange(16, dtype=np.uint32)])
+        off = np.array([0, 50_000, 100_000, 100_017, 100_033], np.uint64)
+    else:
+        key = np.full(100_000, 7, np.uint32)
+        off = np.array([0, 100_000], np.uint64)
+    ctx = capi.Context([("chr1", 1000)])
+    got = ctx.debug_std_sort(key, off)
+    exp = pyoracle.unit_std_sort(key, off)
+    assert np.array_equal(got, exp), (case, int((got != exp).sum()), np.nonzero(got != exp)[0][:10])
+    ctx.close()
