@@ -14,7 +14,18 @@ namespace
 __global__ __launch_bounds__(256) void k_group_kmax(const uint32_t *__restrict__ gof, const uint32_t *__restrict__ cl, uint64_t n, uint32_t *__restrict__ kmax)
 {
   uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) atomicMax(&kmax[gof[p]], cl[p] + 1);
+  const bool live = p < n;
+  uint32_t g = live ? gof[p] : 0xFFFFFFFFu;
+  uint32_t v = live ? cl[p] + 1 : 0u;
+  // elements arrive grouped: a wave almost always holds one group -> one atomic per wave instead of 64 on one address
+  const uint32_t g0 = __shfl(g, 0, 64);
+  if (__ballot(live && g != g0) == 0ull)
+  {
+    for (int d = 32; d; d >>= 1) v = max(v, (uint32_t) __shfl_xor((int) v, d, 64));
+    if ((threadIdx.x & 63) == 0 && g0 != 0xFFFFFFFFu) atomicMax(&kmax[g0], v);
+  }
+  else if (live)
+    atomicMax(&kmax[g], v);
 }
 __global__ __launch_bounds__(256) void k_accumulate(const bk_pair *__restrict__ pairs, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ gof,
                                                     const uint32_t *__restrict__ cl, const uint32_t *__restrict__ slotbase, uint64_t n, ClusterAcc acc)

@@ -5,7 +5,7 @@
 
 struct SortEmuBufs
 {
-  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list;
+  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch;
   prims::RadixBufs radix;
 };
 

@@ -106,30 +106,26 @@ struct HeapSeg
   uint32_t first, last;
 };
 
+// heap entries are packed (key << 32 | idx): one 8-byte access moves an element, the two children of a node are
+// adjacent.  Only the key half takes part in comparisons.
+typedef unsigned long long hent;
+__device__ __forceinline__ uint32_t hkey(hent e) { return (uint32_t) (e >> 32); }
+
 struct LdsMem
 {
-  uint32_t *k, *x;
-  __device__ __forceinline__ uint32_t ldk(uint32_t i) const { return k[i]; }
-  __device__ __forceinline__ uint32_t ldx(uint32_t i) const { return x[i]; }
-  __device__ __forceinline__ void st(uint32_t i, uint32_t kv, uint32_t xv) const
-  {
-    k[i] = kv;
-    x[i] = xv;
-  }
+  hent *e;
+  __device__ __forceinline__ hent ld(uint32_t i) const { return e[i]; }
+  __device__ __forceinline__ void st(uint32_t i, hent v) const { e[i] = v; }
   __device__ __forceinline__ void step_sync() const { __builtin_amdgcn_wave_barrier(); }
 };
-// global-memory variant for segments that do not fit LDS: every access goes to the XCD's L2 (agent-scope
-// relaxed atomics = sc1, no vector-L1 hit on a line another lane just rewrote) and each step drains its stores
+// global-memory variant for segments that do not fit LDS.  All lanes belong to one wavefront on one CU, so
+// plain accesses are coherent through that CU's write-through L1 (the same guarantee __syncthreads() gives a
+// block); every step drains its stores before the next step's loads.
 struct GlbMem
 {
-  uint32_t *k, *x;
-  __device__ __forceinline__ uint32_t ldk(uint32_t i) const { return __hip_atomic_load(k + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ __forceinline__ uint32_t ldx(uint32_t i) const { return __hip_atomic_load(x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ __forceinline__ void st(uint32_t i, uint32_t kv, uint32_t xv) const
-  {
-    __hip_atomic_store(k + i, kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(x + i, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  hent *e;  // plain accesses; the "memory" clobber of step_sync makes the compiler reload after every step
+  __device__ __forceinline__ hent ld(uint32_t i) const { return e[i]; }
+  __device__ __forceinline__ void st(uint32_t i, hent v) const { e[i] = v; }
   __device__ __forceinline__ void step_sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
@@ -140,41 +136,41 @@ __device__ __forceinline__ bool anc_or_self(uint32_t a, uint32_t b)  // is node 
   return db >= da && (B >> (db - da)) == A;
 }
 
-// one top-down sift step of the value (vk,vx) sitting in `hole`; returns true while the hole keeps descending
-template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint32_t &hole, uint32_t len, uint32_t vk, uint32_t vx)
+// one top-down sift step of the value v sitting in `hole`; returns true while the hole keeps descending
+template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint32_t &hole, uint32_t len, hent v)
 {
   const uint32_t right = 2 * (hole + 1), left = right - 1;
-  uint32_t c = 0, kc = 0;
+  hent ec = 0;
+  uint32_t c = 0;
   bool has = true;
   if (right < len)
   {
-    uint32_t kl = mem.ldk(left), kr = mem.ldk(right);
-    if (kr < kl)
+    const hent el = mem.ld(left), er = mem.ld(right);
+    if (hkey(er) < hkey(el))
     {
       c = left;
-      kc = kl;
+      ec = el;
     }
     else
     {
       c = right;
-      kc = kr;
+      ec = er;
     }
   }
   else if (left < len)
   {
     c = left;
-    kc = mem.ldk(left);
+    ec = mem.ld(left);
   }
   else
     has = false;
-  if (has && !(kc < vk))
+  if (has && !(hkey(ec) < hkey(v)))
   {
-    uint32_t xc = mem.ldx(c);
-    mem.st(hole, kc, xc);
+    mem.st(hole, ec);
     hole = c;
     return true;
   }
-  mem.st(hole, vk, vx);
+  mem.st(hole, v);
   return false;
 }
 
@@ -196,8 +192,8 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
       if (p <= hi)
       {
         uint32_t hole = p;
-        const uint32_t vk = mem.ldk(p), vx = mem.ldx(p);
-        while (sift_step(mem, hole, m, vk, vx))
+        const hent v = mem.ld(p);
+        while (sift_step(mem, hole, m, v))
         {
         }
       }
@@ -206,7 +202,8 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
   }
   // sort_heap: pop t detaches leaf L = m - t, stores the maximum there and sifts the leaf's old value from the root
   bool active = false;
-  uint32_t hole = 0, len = 0, vk = 0, vx = 0;
+  uint32_t hole = 0, len = 0;
+  hent v = 0;
   uint32_t next_t = 1;
   int since = 2;
   // every pop needs at most ~depth steps and a new one starts every other step unless stalled; the bound only
@@ -214,7 +211,7 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
   const unsigned long long max_iter = 64ull * m + 4096ull;
   for (unsigned long long iter = 0; iter < max_iter; ++iter)
   {
-    if (active) active = sift_step(mem, hole, len, vk, vx);
+    if (active) active = sift_step(mem, hole, len, v);
     mem.step_sync();
     ++since;
     bool launched = false;
@@ -226,10 +223,8 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
       {
         if (lane == (next_t & 63u))
         {
-          vk = mem.ldk(L);
-          vx = mem.ldx(L);
-          const uint32_t k0 = mem.ldk(0), x0 = mem.ldx(0);
-          mem.st(L, k0, x0);
+          v = mem.ld(L);
+          mem.st(L, mem.ld(0));
           hole = 0;
           len = L;
           active = true;
@@ -245,13 +240,14 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
 }
 
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
-constexpr uint32_t HEAP_LARGE = 18432;   // 144 KiB of LDS (one wave per CU)
+constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
 
-// cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global memory)
-template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
+// cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
+template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+                                                                       hent *__restrict__ scratch)
 {
-  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
-  __shared__ uint32_t stat[CLS == 0 ? 2 * HEAP_SMALL : 2];
+  extern __shared__ __attribute__((aligned(16))) hent dyn[];
+  __shared__ hent stat[CLS == 0 ? HEAP_SMALL : 1];
   const uint32_t s = blockIdx.x;
   if (s >= nh) return;
   const HeapSeg sg = hs[s];
@@ -259,29 +255,27 @@ template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const Hea
   const int cls = m <= HEAP_SMALL ? 0 : (m <= HEAP_LARGE ? 1 : 2);
   if (cls != CLS) return;
   uint32_t *gk = key + sg.first, *gx = idx + sg.first;
+  hent *buf = CLS == 0 ? stat : (CLS == 1 ? dyn : scratch + sg.first);
+  for (uint32_t i = threadIdx.x; i < m; i += 64) buf[i] = ((hent) gk[i] << 32) | gx[i];
+  __syncthreads();
   if (CLS == 2)
   {
-    GlbMem mem{gk, gx};
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of this range may sit stale in this CU's L1
+    GlbMem mem{buf};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     heapsort_wave(mem, m);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  uint32_t *lk = CLS == 0 ? stat : dyn;
-  uint32_t *lx = lk + (CLS == 0 ? HEAP_SMALL : HEAP_LARGE);
-  for (uint32_t i = threadIdx.x; i < m; i += 64)
+  else
   {
-    lk[i] = gk[i];
-    lx[i] = gx[i];
+    LdsMem mem{buf};
+    heapsort_wave(mem, m);
   }
-  __syncthreads();
-  LdsMem mem{lk, lx};
-  heapsort_wave(mem, m);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += 64)
   {
-    gk[i] = lk[i];
-    gx[i] = lx[i];
+    const hent e = buf[i];
+    gk[i] = hkey(e);
+    gx[i] = (uint32_t) e;
   }
 }
 
@@ -484,18 +478,19 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     if (nh)
     {
       const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
-      hipLaunchKernelGGL(k_se_heapsort<0>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx);
+      hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + 1);
+      hipLaunchKernelGGL(k_se_heapsort<0>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch);
       if (e[1] > HEAP_SMALL)
       {
         static bool attr_set = false;
         if (!attr_set)
         {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HEAP_LARGE * 4));
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_LARGE * 8));
           attr_set = true;
         }
-        hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh), dim3(64), 2 * HEAP_LARGE * 4, st, hl, nh, key, idx);
+        hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh), dim3(64), HEAP_LARGE * 8, st, hl, nh, key, idx, hscratch);
       }
-      if (e[1] > HEAP_LARGE) hipLaunchKernelGGL(k_se_heapsort<2>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx);
+      if (e[1] > HEAP_LARGE) hipLaunchKernelGGL(k_se_heapsort<2>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch);
     }
     if (getenv("BK_DEBUG_SORT"))
     fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
