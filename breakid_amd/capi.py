@@ -36,7 +36,7 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort"]
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort", "bk_debug_ahc"]
 
 
 def lib():
@@ -72,6 +72,7 @@ def lib():
                                 C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]
         L.bk_timing_enable.argtypes = [vp, C.c_int]
         L.bk_debug_std_sort.argtypes = [vp, vp, vp, C.c_uint32, vp]
+        L.bk_debug_ahc.argtypes = [vp, vp, vp, C.c_uint32, C.c_double, vp, vp, C.POINTER(C.c_uint32)]
         L.bk_qname_hash.restype = C.c_uint64
         L.bk_qname_hash.argtypes = [C.c_char_p, C.c_size_t]
         L.bk_bam_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -194,6 +195,16 @@ class Context:
         perm = np.zeros(len(key), np.uint32)
         self._check(self.L.bk_debug_std_sort(self.h, key.ctypes.data, group_off.ctypes.data, len(group_off) - 1, perm.ctypes.data))
         return perm
+
+    def debug_ahc(self, x, y, w):
+        x = np.ascontiguousarray(x, np.uint32)
+        y = np.ascontiguousarray(y, np.uint32)
+        n = len(x)
+        idx = np.zeros(max(n, 1), np.uint32)
+        cl = np.zeros(max(n, 1), np.int32)
+        m = C.c_uint32()
+        self._check(self.L.bk_debug_ahc(self.h, x.ctypes.data, y.ctypes.data, n, float(w), idx.ctypes.data, cl.ctypes.data, C.byref(m)))
+        return idx[:m.value].copy(), cl[:m.value].copy()
 
     def timing_enable(self, on=True):
         self._check(self.L.bk_timing_enable(self.h, int(on)))

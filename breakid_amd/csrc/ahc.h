@@ -5,7 +5,8 @@
 
 struct AhcBufs
 {
-  DevBuf x, y, comp, tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7, scan_tmp;
+  DevBuf x, y, comp, csize, keys, vals, rank, cfs, need0, need1, need2, label, rootcomp, cand_t, npts, ent_cnt, pts_off, ent_off, cand_d, cand_o, cnodes_cnt,
+      cent_used, cpts_used, cbest_d, cbest_j, act, cnodes, entries, pts, out_cnt, out_idx, out_cl, err, newoff, scan_tmp;
   prims::RadixBufs radix;
 };
 

@@ -657,6 +657,39 @@ int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_of
   });
 }
 
+int bk_debug_ahc(bk_ctx *ctx, const uint32_t *x, const uint32_t *y, uint32_t n, double w, uint32_t *idx_out, int32_t *cluster_out, uint32_t *n_out)
+{
+  return guarded(ctx, [&] {
+    if (!x || !y || !idx_out || !cluster_out || !n_out) throw bk_error(BK_ERR_ARG, "bk_debug_ahc: null argument");
+    std::vector<bk_pair> hp(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      memset(&hp[i], 0, sizeof(bk_pair));
+      hp[i].x = x[i];
+      hp[i].y = y[i];
+    }
+    DevBuf dp, dcl;
+    PairList L;
+    L.n = n;
+    L.ng = 1;
+    std::vector<uint32_t> iota(n), gof(n, 0);
+    std::iota(iota.begin(), iota.end(), 0u);
+    uint64_t goff[2] = {0, n};
+    HIP_CHECK(hipMemcpy(dp.as<bk_pair>(n + 1), hp.data(), n * sizeof(bk_pair), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(L.idx.as<uint32_t>(n + 1), iota.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(L.gof.as<uint32_t>(n + 1), gof.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(L.goff.as<uint64_t>(2), goff, 16, hipMemcpyHostToDevice));
+    ahc_cluster_all(dp.get<bk_pair>(), L, w, dcl, ctx->ab, ctx->cb, ctx->st);
+    *n_out = (uint32_t) L.n;
+    if (L.n)
+    {
+      HIP_CHECK(hipMemcpyAsync(idx_out, L.idx.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipMemcpyAsync(cluster_out, dcl.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToHost, ctx->st));
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+  });
+}
+
 int bk_timing_enable(bk_ctx *ctx, int on)
 {
   return guarded(ctx, [&] {

@@ -332,32 +332,35 @@ static void fast_pass(const bk_pair *pairs, PairList &L, int use_y, double w, De
   L.n = total;
 }
 
-void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluster_out, ClusterBufs &b, hipStream_t st)
+void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st)
 {
   // groups with fewer than 2 pairs after masking are not clustered at all (BreakID.cc:125)
-  if (L.n)
+  if (L.n == 0) return;
+  uint32_t *small = b.small.as<uint32_t>((uint64_t) L.ng + 1);
+  hipLaunchKernelGGL(k_group_small, dim3(cdiv(L.ng, 256)), dim3(256), 0, st, L.goff.get<uint64_t>(), L.ng, small);
+  uint32_t *keep = b.cnt.as<uint32_t>(L.n + 1), *off = b.off.as<uint32_t>(L.n + 1);
+  hipLaunchKernelGGL(k_drop_small, dim3(nb(L.n)), dim3(256), 0, st, L.gof.get<uint32_t>(), small, L.n, keep);
+  prims::exclusive_scan<uint32_t>(keep, off, L.n, b.scan_tmp, st);
+  uint32_t total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, off + L.n, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (total != L.n)
   {
-    uint32_t *small = b.small.as<uint32_t>((uint64_t) L.ng + 1);
-    hipLaunchKernelGGL(k_group_small, dim3(cdiv(L.ng, 256)), dim3(256), 0, st, L.goff.get<uint64_t>(), L.ng, small);
-    uint32_t *keep = b.cnt.as<uint32_t>(L.n + 1), *off = b.off.as<uint32_t>(L.n + 1);
-    hipLaunchKernelGGL(k_drop_small, dim3(nb(L.n)), dim3(256), 0, st, L.gof.get<uint32_t>(), small, L.n, keep);
-    prims::exclusive_scan<uint32_t>(keep, off, L.n, b.scan_tmp, st);
-    uint32_t total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, off + L.n, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (total != L.n)
-    {
-      uint32_t *oidx = b.idx2.as<uint32_t>((uint64_t) total + 1), *ogof = b.gof2.as<uint32_t>((uint64_t) total + 1);
-      uint64_t *ogoff = b.goff2.as<uint64_t>((uint64_t) L.ng + 1);
-      hipLaunchKernelGGL(k_compact3, dim3(nb(L.n)), dim3(256), 0, st, keep, off, L.n, L.idx.get<uint32_t>(), L.gof.get<uint32_t>(), (const uint32_t *) nullptr,
-                         (const uint32_t *) nullptr, oidx, ogof, (uint32_t *) nullptr, (uint32_t *) nullptr);
-      hipLaunchKernelGGL(k_new_goff, dim3(cdiv(L.ng + 1, 256)), dim3(256), 0, st, off, L.goff.get<uint64_t>(), L.ng, L.n, ogoff);
-      std::swap(L.idx, b.idx2);
-      std::swap(L.gof, b.gof2);
-      std::swap(L.goff, b.goff2);
-      L.n = total;
-    }
+    uint32_t *oidx = b.idx2.as<uint32_t>((uint64_t) total + 1), *ogof = b.gof2.as<uint32_t>((uint64_t) total + 1);
+    uint64_t *ogoff = b.goff2.as<uint64_t>((uint64_t) L.ng + 1);
+    hipLaunchKernelGGL(k_compact3, dim3(nb(L.n)), dim3(256), 0, st, keep, off, L.n, L.idx.get<uint32_t>(), L.gof.get<uint32_t>(), (const uint32_t *) nullptr,
+                       (const uint32_t *) nullptr, oidx, ogof, (uint32_t *) nullptr, (uint32_t *) nullptr);
+    hipLaunchKernelGGL(k_new_goff, dim3(cdiv(L.ng + 1, 256)), dim3(256), 0, st, off, L.goff.get<uint64_t>(), L.ng, L.n, ogoff);
+    std::swap(L.idx, b.idx2);
+    std::swap(L.gof, b.gof2);
+    std::swap(L.goff, b.goff2);
+    L.n = total;
   }
+}
+
+void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluster_out, ClusterBufs &b, hipStream_t st)
+{
+  drop_small_groups(L, b, st);
   DevBuf none;
   // pass 1 on x (list arrives x-sorted from remove_isolated_pairs), pass 2 on y after std::sort by y
   fast_pass(pairs, L, 0, w, none, b.k1, b, st);

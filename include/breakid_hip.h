@@ -154,6 +154,10 @@ int bk_timing_enable(bk_ctx *ctx, int on);
  * BreakID.cc:1274-1282,1091,1127) and returns the permutation (perm_out[p] = original index of the element now at p). */
 int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_off, uint32_t n_groups, uint32_t *perm_out);
 
+/* Test hook: find_cluster_pairs_enspan_ahc (BreakID.cc:1304-1352) on one group of x-sorted points; returns the
+ * surviving point indices in output order with their cluster numbers. */
+int bk_debug_ahc(bk_ctx *ctx, const uint32_t *x, const uint32_t *y, uint32_t n, double w, uint32_t *idx_out, int32_t *cluster_out, uint32_t *n_out);
+
 /* ---- host feed (C++ BGZF/BAM decoder -> pinned SoA); replaces htslib's reader for this path --- */
 typedef struct bk_bam bk_bam;
 uint64_t bk_qname_hash(const char *name, size_t len);

@@ -171,3 +171,49 @@ def test_std_sort_emulation_matches_libstdcxx(case):
     exp = pyoracle.unit_std_sort(key, off)
     assert np.array_equal(got, exp), (case, int((got != exp).sum()), np.nonzero(got != exp)[0][:10])
     ctx.close()
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_ahc_matches_reference_dump_and_oracle(golden_dir, name):
+    contigs, cols = refdump.load_soa(golden_dir, name)
+    dump = refdump.parse_stages(os.path.join(golden_dir, "%s.ahc.stages.txt" % name))
+    ctx, mean, sd, w = _run_gpu(contigs, cols, fast=False)
+    refdump.compare_with_dump(dump, [n for n, _ in contigs], ctx.fetch, mean, sd, w)
+    o = pyoracle.Oracle(contigs, cols)
+    o.run(20, fast=False)
+    _compare_stages(ctx, o)
+    ctx.close()
+    o.close()
+
+
+def _expected_ahc_list(x, y, T):
+    nodes = pyoracle.unit_ahc(x, y, T)
+    idx, cl, k = [], [], 0
+    for is_root, npts, _, _, pts in nodes:
+        if is_root and npts >= 2:
+            idx += pts
+            cl += [k] * npts
+            k += 1
+    return np.asarray(idx, np.uint32), np.asarray(cl, np.int32)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_ahc_units_vs_oracle(case):
+    rng = np.random.default_rng(500 + case)
+    specs = [(30, 40, 6), (60, 30, 5), (120, 200, 30), (200, 3000, 400), (300, 100, 8), (64, 8, 3), (500, 60, 4), (800, 5000, 300),
+             (150, 12, 2), (400, 40, 40), (1200, 20000, 900), (90, 5, 1)]
+    n, span, T = specs[case]
+    x = rng.integers(0, span, n)
+    y = rng.integers(0, span, n)
+    if case % 3 == 0:  # duplicates like the mask quirk produces
+        x[1::7] = x[0::7][: len(x[1::7])]
+        y[1::7] = y[0::7][: len(y[1::7])]
+    if case == 5:      # two far-apart components with interleaved x order and lattice ties
+        y = y + (np.arange(n) % 2) * 100000
+    order = np.argsort(x, kind="stable")
+    x, y = x[order].astype(np.uint32), y[order].astype(np.uint32)
+    ctx = capi.Context([("chr1", 1000)])
+    gi, gc = ctx.debug_ahc(x, y, T + 0.75)
+    ei, ec = _expected_ahc_list(x, y, T)
+    assert np.array_equal(gi, ei) and np.array_equal(gc, ec), (case, len(gi), len(ei))
+    ctx.close()
