@@ -1,0 +1,455 @@
+// BreakID command line on top of libbreakid_hip.so: same options, same output files as the reference
+// (src/BreakID.cc:6-192, help text src/BreakID.h:27-36).  The hot path (BreakID.cc:98-167 minus annotation)
+// runs on the MI355X through the C ABI; this file is the host side the reference keeps in main():
+// argument parsing, BAM decode into the columnar table, refGene/nib annotation (BreakID.cc:492-567,
+// :1528-1793, RefSeqTranscript.cc, nibtools.cc, util_bam.cc:78-122, util_bed.cc:224-261) and the writers
+// (:1170-1263).  There is no CPU implementation of the hot path in here.
+#include <getopt.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/breakid_hip.h"
+
+#ifndef BREAKID_INSTALLDIR
+#define BREAKID_INSTALLDIR "."
+#endif
+
+using std::string;
+using std::vector;
+
+static const char *HELP =
+    " Usage: \n \t BreakID -i input.bam -o prefix -n nib_folder <options> \n\n \
+     DESCRIPTION\n \
+     \t -h -? -help \t help\n \
+     \t -i*        \t input bam-file\n \
+     \t -o*        \t output file (prefix only)\n \
+     \t -n*        \t folder name to nib files\n \
+     \t -q         \t encompassing reads quality thresholds  [20]\n\
+     \t -t         \t distance relative to (sqrt(2)*(insert size mean +3* insert size sd))  [2]\n \
+     \t -fast      \t use the fast cluster strategy [default no] \n \
+     \t -all       \t no filter enspan out [default is filter]  \n ";
+
+// ---- RefSeqTranscript.{h,cc} -------------------------------------------------------------------------------
+struct Txpt
+{
+  string transcriptID, chrom, strand, geneName;
+  uint32_t txStart = 0, txEnd = 0, cdsStart = 0, cdsEnd = 0, exonCount = 0, cDNALength = 0;
+  vector<uint32_t> exonStarts, exonEnds, codingStarts, codingEnds, codingParts;
+  int codingExonCount = 0;
+};
+
+static vector<uint32_t> split_to_int(const string &s)  // splitStringToInt(s, ","), empty tokens dropped
+{
+  vector<uint32_t> out;
+  size_t st = 0;
+  while (true)
+  {
+    size_t e = s.find(',', st);
+    string tok = s.substr(st, e == string::npos ? string::npos : e - st);
+    if (!tok.empty()) out.push_back((uint32_t) atol(tok.c_str()));
+    if (e == string::npos) break;
+    st = e + 1;
+  }
+  return out;
+}
+
+static Txpt parse_refgene_line(const string &line)  // RefSeqTranscript.cc:19-81 + removeUTR :94-142
+{
+  Txpt t;
+  std::stringstream ss(line);
+  string f[16];
+  for (int i = 0; i < 16; ++i)
+    if (!getline(ss, f[i], '\t')) f[i] = i ? f[i - 1] : "";  // getline leaves `tmp` unchanged at EOF
+  t.transcriptID = f[1];
+  t.chrom = f[2];
+  t.strand = f[3];
+  t.txStart = (uint32_t) atol(f[4].c_str());
+  t.txEnd = (uint32_t) atol(f[5].c_str());
+  t.cdsStart = (uint32_t) atol(f[6].c_str());
+  t.cdsEnd = (uint32_t) atol(f[7].c_str());
+  t.exonCount = (uint32_t) atol(f[8].c_str());
+  t.exonStarts = split_to_int(f[9]);
+  t.exonEnds = split_to_int(f[10]);
+  t.geneName = f[12];
+  if (t.cdsStart != t.cdsEnd)
+  {
+    for (uint32_t i = 0; i < t.exonCount && i < t.exonStarts.size() && i < t.exonEnds.size(); ++i)
+    {
+      uint32_t s = t.exonStarts[i], e = t.exonEnds[i];
+      if (s < t.cdsEnd && e > t.cdsStart)
+      {
+        if (s < t.cdsStart && e > t.cdsStart && e <= t.cdsEnd) { t.codingStarts.push_back(t.cdsStart); t.codingEnds.push_back(e); }
+        else if (s < t.cdsEnd && e > t.cdsEnd && s >= t.cdsStart) { t.codingStarts.push_back(s); t.codingEnds.push_back(t.cdsEnd); }
+        else if (e > t.cdsEnd && s < t.cdsStart) { t.codingStarts.push_back(t.cdsStart); t.codingEnds.push_back(t.cdsEnd); }
+        else { t.codingStarts.push_back(s); t.codingEnds.push_back(e); }
+      }
+    }
+    t.codingExonCount = (int) t.codingStarts.size();
+    for (size_t i = 0; i < t.codingStarts.size(); ++i) t.cDNALength += t.codingEnds[i] - t.codingStarts[i];
+  }
+  for (size_t i = 0; i < t.codingStarts.size(); ++i)  // add_cds_parts
+  {
+    t.codingParts.push_back(t.codingStarts[i]);
+    t.codingParts.push_back(t.codingEnds[i]);
+  }
+  return t;
+}
+
+static bool read_refgene(const string &fn, vector<Txpt> &out)  // readRefSeqTranscript: NR_ transcripts skipped
+{
+  std::ifstream in(fn);
+  if (!in.is_open()) return false;
+  string line;
+  while (getline(in, line, '\n'))
+  {
+    std::stringstream l2(line);
+    string a, b;
+    getline(l2, a, '\t');
+    if (!getline(l2, b, '\t')) b = a;
+    if (b.find("NR_") != string::npos) continue;
+    out.push_back(parse_refgene_line(line));
+  }
+  return true;
+}
+
+// add_exon_num_anno, BreakID.cc:1753-1793
+static void exon_numbers(const Txpt &t, long pos, int &s_no, int &e_no)
+{
+  s_no = e_no = 0;
+  for (size_t i = 0; i + 1 < t.codingParts.size(); ++i)
+  {
+    if (pos >= (long) t.codingParts[i] && pos <= (long) t.codingParts[i + 1])
+    {
+      int idx = (int) i / 2 + 1;
+      if (t.strand == "+")
+      {
+        s_no = idx;
+        e_no = (i % 2 == 1) ? idx + 1 : idx;
+      }
+      if (t.strand == "-")
+      {
+        s_no = t.codingExonCount + 1 - (idx + 1);
+        e_no = (i % 2 == 1) ? t.codingExonCount + 1 - idx : t.codingExonCount + 1 - (idx + 1);
+      }
+      break;
+    }
+  }
+}
+
+// one side of add_exon_anno, BreakID.cc:1549-1585 (find_the_longest_cds_txpt never updates its maximum, so the
+// LAST overlapping transcript with cDNA > 0 wins, RefSeqTranscript.cc:311-320)
+static void annotate_side(const vector<Txpt> &txpts, const string &chr, long pos, string &gene, string &exon_info, string &strand)
+{
+  if (pos == -1)
+  {
+    exon_info = gene = strand = ".";
+    return;
+  }
+  vector<const Txpt *> hit;
+  for (auto &t : txpts)
+    if (chr == t.chrom && pos >= (long) t.txStart && pos <= (long) t.txEnd) hit.push_back(&t);
+  if (hit.empty())
+  {
+    exon_info = ".";
+    gene = "intergenic";
+    strand = ".";
+    return;
+  }
+  Txpt chosen;
+  for (auto *t : hit)
+    if ((int) t->cDNALength > 0) chosen = *t;
+  gene = chosen.geneName;
+  strand = chosen.strand;
+  int a, b;
+  exon_numbers(chosen, pos, a, b);
+  exon_info = chosen.transcriptID + ":" + std::to_string(a) + "-" + std::to_string(b);
+}
+
+// ---- nib access: nibtools.cc:7-58, util_bam.cc:78-122 -------------------------------------------------------------------
+struct Nib
+{
+  std::ifstream in;
+  unsigned long nBases = 0;
+  bool ok = false;
+  void open(const string &fn)
+  {
+    in.open(fn, std::ios::binary);
+    if (!in.is_open()) return;
+    unsigned char raw[8];
+    in.read((char *) raw, 8);
+    unsigned long sig = raw[0] | (raw[1] << 8) | (raw[2] << 16) | ((unsigned long) raw[3] << 24);
+    nBases = raw[4] | (raw[5] << 8) | (raw[6] << 16) | ((unsigned long) raw[7] << 24);
+    ok = sig == 0x6be93d3aUL;
+  }
+  void base(char *out, unsigned long pos)  // leaves *out untouched on any failure, like the reference
+  {
+    if (!ok || pos >= nBases) return;
+    in.seekg(8 + pos / 2);
+    char r;
+    in.read(&r, 1);
+    int v = (pos % 2 == 0) ? ((r & 0xff) >> 4) : (r & 0x0f);
+    static const char tab[16] = {'T', 'C', 'A', 'G', 'N', 'N', 'N', 'N', 'T', 'C', 'A', 'G', 'N', 'N', 'N', 'N'};
+    *out = tab[v & 15];
+  }
+};
+
+static string neighbour_seq(const string &nib_dir, const string &chr, int32_t bp)
+{
+  // left 20 (1-based bp-20 .. bp-1) + right 21 (bp .. bp+20), BreakID.cc:554-559
+  Nib n;
+  n.open(nib_dir + "/hg19_" + chr + ".nib");
+  string s;
+  char b = 'N';
+  for (int32_t i = bp - 20; i < bp; ++i)
+  {
+    n.base(&b, (unsigned long) (long) (i - 1));
+    s += b;
+  }
+  for (int32_t i = bp - 1; i < bp - 1 + 21; ++i)
+  {
+    n.base(&b, (unsigned long) (long) i);
+    s += b;
+  }
+  return s;
+}
+
+static int longest_run(const string &s)  // find_longest_repeat_substring, util_bed.cc:224-261
+{
+  int best = 0;
+  size_t i = 0;
+  while (i < s.size())
+  {
+    size_t j = i + 1;
+    while (j < s.size() && s[j] == s[i]) ++j;
+    best = std::max(best, (int) (j - i));
+    i = j;
+  }
+  return best;
+}
+
+static const char *fusion_type(uint32_t mask)  // determine_fusion_type_from_drp, BreakID.cc:1888-1907
+{
+  if (mask & BK_TYPE_DEFAULT_ORIENT) return "Deletion";
+  if (mask & BK_TYPE_ABS_REVERSE) return "Duplication";
+  if (mask & BK_TYPE_SAME_ORIENT) return "Inversion";
+  if (mask & BK_TYPE_DIFF_CHR) return "Translocation";
+  return "Unknown";
+}
+
+struct OutRow
+{
+  bk_cluster c;
+  string p1_chr, p2_chr, g1, g2, e1, e2, s1, s2, rpt1, rpt2;
+  bool is_rpt;
+  float af1, af2;
+};
+static bool cmp_cluster(OutRow a, OutRow b) { return a.c.n_drp > b.c.n_drp; }  // BreakID.h:185-188 (by value, like the reference)
+
+static void write_row(std::ostream &o, const OutRow &r)
+{
+  o << fusion_type(r.c.type_mask) << "\t";
+  o << r.p1_chr << ":" << r.c.p1_exact << "\t";
+  o << r.p2_chr << ":" << r.c.p2_exact << "\t";
+  o << r.g1 << "\t" << r.s1 << ":" << r.e1 << "\t";
+  o << r.g2 << "\t" << r.s2 << ":" << r.e2 << "\t";
+  o << (long) r.c.n_drp << "\t" << (long) r.c.n_sr << "\t";
+  o << (double) r.c.depth1 << "\t" << (double) r.c.depth2 << "\t";
+  o << r.af1 << "\t" << r.af2 << "\t";
+  o << r.rpt1 << "\t" << r.rpt2 << "\n";
+}
+
+static const char *HEADER =
+    "Fusion_Type\tBreakPoint1\tBreakPoint2\tGene1\tBreakPoint_Info_Pair1\tGene2\tBreakPoint_Info_Pair2\tN_DRP\tN_SR\t"
+    "BreakPoint1_Depth\tBreakPoint2_Depth\tBreakPoint1_AF\tBreakPoint2_AF\tBP1_Neighbour_Seq\tBP2_Neighbour_Seq\n";
+
+int main(int argc, char *argv[])
+{
+  clock_t start = clock();
+  static struct option longopts[] = {{"help", 0, 0, 'h'}, {"i", 1, 0, 1}, {"o", 1, 0, 2}, {"q", 1, 0, 3}, {"n", 1, 0, 4},
+                                     {"fast", 0, 0, 5},   {"t", 0, 0, 6}, {"all", 0, 0, 7}, {"gpu", 1, 0, 8}, {0, 0, 0, 0}};
+  string inp_file, out_file, nib_dir, build = "hg19";
+  int qual = 20, device = 0;
+  bool fast = false, filter = true;
+  int opt, li;
+  optind = 0;
+  while ((opt = getopt_long_only(argc, argv, "h?", longopts, &li)) != -1)
+  {
+    switch (opt)
+    {
+    case 'h': case '?': std::cerr << HELP; exit(1);
+    case 1: inp_file = optarg; break;
+    case 2: out_file = optarg; break;
+    case 3: qual = (int) std::labs(atol(optarg)); break;
+    case 4: nib_dir = optarg; break;
+    case 5: fast = true; break;
+    case 6: break;  // the reference dereferences a NULL optarg here (has_arg = 0); `times` is effectively always 2
+    case 7: filter = false; break;
+    case 8: device = atoi(optarg); break;
+    default: std::cerr << "Error: cannot parse arguments.\n"; exit(1);
+    }
+  }
+  if (inp_file.empty() || out_file.empty())
+  {
+    std::cerr << HELP << "Error: input- and output file is required.\n";
+    exit(1);
+  }
+  if (nib_dir.empty())
+  {
+    std::cerr << HELP << "Error: nib file's root dir is required.\n";
+    exit(1);
+  }
+  std::cout << "start to stats the insert size...\n";
+  char err[512];
+  bk_bam *bam = nullptr;
+  if (bk_bam_open(inp_file.c_str(), &bam, err, sizeof err) != BK_OK)
+  {
+    std::cerr << "Error: can not open bam-file: " << inp_file << std::endl;
+    exit(1);
+  }
+  int nt = 0;
+  const char *const *names = nullptr;
+  const uint32_t *lens = nullptr;
+  bk_bam_header(bam, &nt, &names, &lens);
+  bk_soa soa;
+  if (bk_bam_decode(bam, &soa, err, sizeof err) != BK_OK)
+  {
+    std::cerr << "Error: " << err << std::endl;
+    exit(1);
+  }
+  {
+    std::ifstream rn((nib_dir + "/ref_names.txt").c_str());
+    if (!rn.is_open())
+    {
+      std::cerr << "Error: cannot open reference names file.\n";
+      exit(1);
+    }
+  }
+  bk_ctx *ctx = nullptr;
+  if (bk_init(device, lens, names, nt, &ctx) != BK_OK)
+  {
+    std::cerr << "Error: " << bk_last_error(nullptr) << std::endl;
+    exit(1);
+  }
+  auto die = [&](int rc) {
+    std::cerr << (rc == BK_ERR_CIGAR ? "error cigar: " : bk_last_error(ctx)) << std::endl;
+    exit(rc == BK_ERR_CIGAR ? -1 : 1);
+  };
+  int rc;
+  if ((rc = bk_upload_records(ctx, &soa, BK_MEM_HOST)) != BK_OK) die(rc);
+  double mean = 0, sd = 0;
+  if ((rc = bk_isize_stats(ctx, &mean, &sd)) != BK_OK) die(rc);
+  std::cout << "the insert size mean: " << mean << ", the insert size sd:" << sd << " .\n";
+  const int times = 2;
+  const double w = times * std::sqrt(times) * (mean + 3 * sd);
+  std::cout << "cluster_dist = span_dist = mask_dist = scan_dist = " << w << " .\n";
+  clock_t scan_start = clock();
+  uint64_t n_pairs = 0, n_clustered = 0, n_valid = 0, n_clusters = 0;
+  uint32_t n_groups = 0;
+  std::cout << "Scanning discordant read pairs ...\n";
+  if ((rc = bk_discordant_pairs(ctx, qual, w, &n_pairs, &n_groups)) != BK_OK) die(rc);
+  std::cout << "Scanning discordant read pairs done.\n";
+  clock_t scan_end = clock();
+  clock_t cluster_start = clock();
+  if ((rc = bk_mask_and_cluster(ctx, w, fast ? 1 : 0, &n_clustered)) != BK_OK) die(rc);
+  clock_t cluster_end = clock();
+  if ((rc = bk_split_evidence(ctx, nullptr)) != BK_OK) die(rc);
+  if ((rc = bk_cluster_summary(ctx, w, &n_clusters)) != BK_OK) die(rc);
+  if (n_clustered)  // findEncompassingReadsAndBreakPointInfo opens the index for every group that reaches it (:405-416)
+  {
+    std::ifstream bai((inp_file + ".bai").c_str());
+    if (!bai.is_open())
+    {
+      std::cerr << "Error: please index bam-file first:\t" << inp_file << std::endl;
+      exit(1);
+    }
+  }
+  if ((rc = bk_split_breakpoints(ctx, w, &n_valid)) != BK_OK) die(rc);
+  std::cout << "valid cluster count: " << n_valid << std::endl;
+  const void *data = nullptr;
+  uint64_t cnt = 0;
+  if ((rc = bk_fetch(ctx, BK_STAGE_CLUSTERS, &data, &cnt, nullptr, nullptr)) != BK_OK) die(rc);
+  const bk_cluster *cl = (const bk_cluster *) data;
+  // annotate_cluster_for_sa_tag (BreakID.cc:492-567)
+  vector<OutRow> rows;
+  vector<Txpt> txpts;
+  bool have_valid = false;
+  for (uint64_t i = 0; i < cnt; ++i) have_valid |= (cl[i].flags & 2u) != 0;
+  if (n_clustered >= 1 || have_valid)
+  {
+    // the reference reads refGene.txt for every group that reaches findClusterBreakPointInfoSaTag and exits if it is missing
+    const char *inst = getenv("BREAKID_INSTALLDIR");
+    string ref_gene = string(inst ? inst : BREAKID_INSTALLDIR) + "/ref_files/refGene.txt";
+    if (!read_refgene(ref_gene, txpts))
+    {
+      std::cerr << "Error: cannot open \t" << ref_gene << std::endl;
+      exit(1);
+    }
+  }
+  for (uint64_t i = 0; i < cnt; ++i)
+  {
+    if (!(cl[i].flags & 2u)) continue;
+    OutRow r;
+    r.c = cl[i];
+    r.p1_chr = cl[i].p1_tid < 0 ? "*" : names[cl[i].p1_tid];
+    r.p2_chr = cl[i].p2_tid < 0 ? "*" : names[cl[i].p2_tid];
+    long p1 = (long) cl[i].p1_exact, p2 = (long) cl[i].p2_exact;  // exact positions are never -1 for valid clusters
+    annotate_side(txpts, r.p1_chr, p1, r.g1, r.e1, r.s1);
+    annotate_side(txpts, r.p2_chr, p2, r.g2, r.e2, r.s2);
+    r.rpt1 = neighbour_seq(nib_dir, r.p1_chr, (int32_t) cl[i].p1_exact);
+    r.rpt2 = neighbour_seq(nib_dir, r.p2_chr, cl[i].p2_exact);
+    r.is_rpt = longest_run(r.rpt1) > 10 || longest_run(r.rpt2) > 10;
+    r.af1 = (float) (long) cl[i].n_sr / (float) (double) cl[i].depth1;  // :475-478
+    r.af2 = (float) (long) cl[i].n_sr / (float) (double) cl[i].depth2;
+    rows.push_back(r);
+  }
+  // write_enspan_out (BreakID.cc:1184-1263): std::sort with the reference's comparator
+  std::sort(rows.begin(), rows.end(), cmp_cluster);
+  std::ofstream out, outf;
+  if (!filter)
+  {
+    out.open((out_file + "_fusion_all.txt").c_str());
+    out << HEADER;
+  }
+  outf.open((out_file + "_fusion.txt").c_str());
+  outf << HEADER;
+  for (auto &r : rows)
+  {
+    bool all_ok = r.c.n_sr > 0 && r.c.p1_exact != 0xFFFFFFFFu && r.c.p2_exact != -1;
+    bool filt_ok = all_ok && (!(r.g1 == "intergenic" && r.g2 == "intergenic") && r.g1 != r.g2) && !r.is_rpt;
+    if (filt_ok) write_row(outf, r);
+    if (!filter && all_ok) write_row(out, r);
+  }
+  if (!filter) out.close();
+  outf.close();
+  {
+    std::ofstream p((out_file + "_params.txt").c_str());  // write_enspan_params :1170-1182
+    p << "ENSPAN" << std::endl;
+    p << "inp_file\t" << inp_file << std::endl;
+    p << "out_file\t" << out_file << std::endl;
+    p << "qual\t" << (long) qual << std::endl;
+    p << "w\t" << w << std::endl;
+    p << "build\t" << build << std::endl;
+  }
+  clock_t end = clock();
+  std::cout << "the fusion process of file " << inp_file << "  costs time: " << (end - start) / double(CLOCKS_PER_SEC) << " seconds" << std::endl;
+  {
+    std::ofstream p((out_file + "_performance.txt").c_str());  // :175-191 (the two counters are always 0 there too)
+    p << "scan_dist\tdiscordant pairs\tremove isolated\tafter_cluster\troot cluster\tscanning time\tcluster time\tfind breakpoint time\ttotal time" << std::endl;
+    p << w << "\t" << 0 << "\t" << (long) n_clustered << "\t" << 0 << "\t" << 0 << "\t" << (scan_end - scan_start) / double(CLOCKS_PER_SEC) << "\t"
+      << (cluster_end - cluster_start) / double(CLOCKS_PER_SEC) << "\t" << 0.0 << "\t" << (end - start) / double(CLOCKS_PER_SEC) << std::endl;
+  }
+  bk_free(ctx);
+  bk_bam_close(bam);
+  return 0;
+}

@@ -1,0 +1,54 @@
+"""End-to-end drop-in check: the BreakID command line (same flags, same txt files as the reference) on the
+GPU against the reference's own output files kept as golden fixtures (tools/make_golden.py)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from breakid_amd import synth
+from tests import refdump
+from tools import make_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "breakid_amd", "bin", "BreakID")
+
+
+def _dataset(name):
+    for n, ds, refgene in make_golden.datasets():
+        if n == name:
+            return ds, refgene
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["g1", "g2", "small", "ties"])
+@pytest.mark.parametrize("mode", ["fast", "ahc"])
+def test_cli_txt_outputs_match_reference(golden_dir, name, mode):
+    ds, refgene = _dataset(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        bam = os.path.join(tmp, name + ".bam")
+        ds.write_bam(bam)
+        open(bam + ".bai", "wb").close()  # the hot path streams the BAM; only the presence of the index is part of the CLI contract
+        side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
+        prefix = os.path.join(tmp, "out")
+        cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all"] + (["-fast"] if mode == "fast" else [])
+        r = subprocess.run(cmd, env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for suffix in ("_fusion.txt", "_fusion_all.txt"):
+            got = open(prefix + suffix).read()
+            exp = open(os.path.join(golden_dir, "%s.%s%s" % (name, mode, suffix))).read()
+            assert got == exp, (suffix, got[:600], exp[:600])
+        got = open(prefix + "_params.txt").read().replace(tmp, "<TMP>").replace("out_file\t<TMP>/out", "out_file\t<TMP>/out_" + mode)
+        exp = open(os.path.join(golden_dir, "%s.%s_params.txt" % (name, mode))).read()
+        assert got == exp, (got, exp)
+
+
+def test_cli_usage_errors():
+    r = subprocess.run([BIN, "-h"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr
+    r = subprocess.run([BIN, "-i", "x.bam"], capture_output=True, text=True)
+    assert r.returncode == 1 and "input- and output file is required" in r.stderr
+    r = subprocess.run([BIN, "-i", "x.bam", "-o", "p"], capture_output=True, text=True)
+    assert r.returncode == 1 and "nib file's root dir is required" in r.stderr
