@@ -28,7 +28,7 @@ struct BpWork
 
 struct BpBufs
 {
-  DevBuf key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp;
+  DevBuf key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted;
   prims::RadixBufs radix;
 };
 
@@ -36,5 +36,10 @@ void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hi
 // returns the number of clusters that passed the near-diagonal filter; clusters_out holds them in (group key order, id) order
 uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32_t *gof, const uint32_t *cl, uint64_t n, uint32_t ng, const uint32_t *gkey,
                          const uint32_t *glex, int32_t nt, double w, DevBuf &clusters_out, BpBufs &b, hipStream_t st);
+// phases of the breakpoint stage (a sharded run sums `cov` and `depth` over the record shards between them)
+uint32_t *bp_cov_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl, double w, int maxspan, BpBufs &b, hipStream_t st);
+void bp_vote(const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const uint32_t *cov, const int32_t *hdr_id, BpBufs &b, hipStream_t st);
+uint32_t *bp_depth_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl, int maxspan, BpBufs &b, hipStream_t st);
+void bp_finish(bk_cluster *cl, uint64_t ncl, const uint32_t *depth, BpBufs &b, hipStream_t st);
 void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
                        hipStream_t st);

@@ -172,20 +172,59 @@ __device__ __forceinline__ Region make_region(int32_t tid, uint32_t mean, int wi
 }
 __device__ __forceinline__ bool in_region(const Region &rg, int32_t tid, int32_t pos, int32_t endpos) { return tid == rg.tid && pos < rg.end && endpos > rg.beg; }
 
-// find_sa_reads' region verdict: coverage >= 5 and >= 2 evidence alignments, else the map is cleared
-__device__ bool scan_side(const RecView &r, const bk_split *__restrict__ sp, uint64_t nsp, const Region &rg, int maxspan, uint64_t &tlo, uint64_t &thi, bool &poison)
+__device__ uint64_t split_lower_pos(const bk_split *__restrict__ sp, uint64_t ns, int32_t T, long long P)
 {
-  tlo = thi = 0;
-  if (!rg.valid) return false;
+  // tuples are ordered by record index = coordinate order: first tuple with (tid,pos) >= (T,P)
+  uint64_t lo = 0, hi = ns;
+  const uint32_t Tu = (uint32_t) T;
+  while (lo < hi)
+  {
+    uint64_t m = (lo + hi) >> 1;
+    uint32_t t = (uint32_t) sp[m].tid;
+    bool lt = t != Tu ? (t < Tu) : ((long long) sp[m].pos < P);
+    if (lt) lo = m + 1; else hi = m;
+  }
+  return lo;
+}
+
+// number of records of THIS record table (one shard or the whole file) that overlap the region: total_coverage
+// of find_sa_reads (:894) is the sum of these counts over the shards
+__device__ uint32_t region_cov(const RecView &r, const Region &rg, int maxspan)
+{
+  if (!rg.valid) return 0;
   const int lane = threadIdx.x & 63;
   uint64_t lo = rec_lower(r, rg.tid, (long long) rg.beg - maxspan);
   uint64_t hi = rec_lower(r, rg.tid, (long long) rg.end);
   long long cov = 0;
   for (uint64_t i = lo + lane; i < hi; i += 64)
     if (in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) ++cov;
-  cov = wave_sum(cov);
-  tlo = split_lower(sp, nsp, lo);
-  thi = split_lower(sp, nsp, hi);
+  return (uint32_t) wave_sum(cov);
+}
+
+// phase 1 (per shard): coverage counts of both regions of every cluster
+__global__ __launch_bounds__(256) void k_bp_cov(RecView r, const bk_cluster *__restrict__ cl, uint32_t ncl, int wi, int maxspan, uint32_t *__restrict__ cov)
+{
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= ncl) return;
+  const bk_cluster k = cl[c];
+  uint32_t c1 = region_cov(r, make_region(k.p1_tid, k.p1_mean, wi), maxspan);
+  uint32_t c2 = region_cov(r, make_region(k.p2_tid, k.p2_mean, wi), maxspan);
+  if ((threadIdx.x & 63) == 0)
+  {
+    cov[2 * c] = c1;
+    cov[2 * c + 1] = c2;
+  }
+}
+
+// find_sa_reads' region verdict from the (summed) coverage and the evidence tuples: coverage >= 5 and >= 2
+// evidence alignments, else the map is cleared (:1032)
+__device__ bool side_verdict(const bk_split *__restrict__ sp, uint64_t nsp, const Region &rg, int maxspan, uint32_t cov, uint64_t &tlo, uint64_t &thi, bool &poison)
+{
+  tlo = thi = 0;
+  if (!rg.valid) return false;
+  const int lane = threadIdx.x & 63;
+  tlo = split_lower_pos(sp, nsp, rg.tid, (long long) rg.beg - maxspan);
+  thi = split_lower_pos(sp, nsp, rg.tid, (long long) rg.end);
   long long ev = 0, bad = 0;
   for (uint64_t t = tlo + lane; t < thi; t += 64)
   {
@@ -209,9 +248,9 @@ __device__ __forceinline__ bool tuples_match(const bk_split &a, const bk_split &
          a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;  // new_condition, :627-637
 }
 
-// phase 1: region verdicts + number of (i,j) matches per cluster
-__global__ __launch_bounds__(256) void k_bp_regions(RecView r, const bk_split *__restrict__ sp, uint64_t nsp, const bk_cluster *__restrict__ cl, uint32_t ncl, int wi, int maxspan,
-                                                    BpWork *__restrict__ work, uint32_t *__restrict__ nmatch, uint32_t *__restrict__ err)
+// phase 2: region verdicts + number of (i,j) matches per cluster
+__global__ __launch_bounds__(256) void k_bp_regions(const bk_split *__restrict__ sp, uint64_t nsp, const bk_cluster *__restrict__ cl, uint32_t ncl, int wi, int maxspan,
+                                                    const uint32_t *__restrict__ cov, BpWork *__restrict__ work, uint32_t *__restrict__ nmatch, uint32_t *__restrict__ err)
 {
   const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -219,12 +258,13 @@ __global__ __launch_bounds__(256) void k_bp_regions(RecView r, const bk_split *_
   const bk_cluster k = cl[c];
   BpWork wk;
   wk.ok = 0;
+  wk.pad = 0;
   wk.t1lo = wk.t1hi = wk.t2lo = wk.t2hi = 0;
   bool poison = false;
   Region r1 = make_region(k.p1_tid, k.p1_mean, wi), r2 = make_region(k.p2_tid, k.p2_mean, wi);
-  bool ok1 = scan_side(r, sp, nsp, r1, maxspan, wk.t1lo, wk.t1hi, poison);
+  bool ok1 = side_verdict(sp, nsp, r1, maxspan, cov[2 * c], wk.t1lo, wk.t1hi, poison);
   bool ok2 = false;
-  if (ok1) ok2 = scan_side(r, sp, nsp, r2, maxspan, wk.t2lo, wk.t2hi, poison);
+  if (ok1) ok2 = side_verdict(sp, nsp, r2, maxspan, cov[2 * c + 1], wk.t2lo, wk.t2hi, poison);  // side 2 only if side 1 is non-empty (:438)
   long long m = 0;
   if (ok1 && ok2)
   {
@@ -285,37 +325,15 @@ __device__ bool key_less(int32_t a1, int32_t a2, int32_t b1, int32_t b2)
   return la < lb;
 }
 
-__device__ uint32_t base_depth(const RecView &r, int32_t tid, unsigned long long pos, int maxspan)
-{
-  // cal_single_base_depth: bam_iter_query(idx, tid, pos - 1, pos) with uint64 -> int conversions
-  int beg = (int) (pos - 1ull), end = (int) pos;
-  if (beg < 0) beg = 0;
-  if (end < beg || tid < 0) return 0;
-  Region rg;
-  rg.tid = tid;
-  rg.beg = beg;
-  rg.end = end;
-  rg.valid = true;
-  const int lane = threadIdx.x & 63;
-  uint64_t lo = rec_lower(r, tid, (long long) beg - maxspan), hi = rec_lower(r, tid, (long long) end);
-  long long d = 0;
-  for (uint64_t i = lo + lane; i < hi; i += 64)
-  {
-    if (!in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) continue;
-    uint16_t f = r.flag[i];
-    if (r.mapq[i] > 0 && !(f & 0x400) && (f & 1)) ++d;  // util_bed.cc:183
-  }
-  return (uint32_t) wave_sum(d);
-}
-
-// phase 2: emit (p1_bp, p2_bp) for every match, vote, depth
-__global__ __launch_bounds__(256) void k_bp_vote(RecView r, const bk_split *__restrict__ sp, bk_cluster *__restrict__ cl, uint32_t ncl, int wi, int maxspan,
-                                                 const BpWork *__restrict__ work, const uint32_t *__restrict__ moff, int2 *__restrict__ emit, uint32_t *__restrict__ ecount,
-                                                 const int32_t *__restrict__ hdr_id)
+// phase 3: emit (p1_bp, p2_bp) for every match and vote (find_bp_pair); voted[c] = 1 when encompass_num >= 2 (:446)
+__global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp, bk_cluster *__restrict__ cl, uint32_t ncl, int wi, const BpWork *__restrict__ work,
+                                                 const uint32_t *__restrict__ moff, int2 *__restrict__ emit, uint32_t *__restrict__ ecount,
+                                                 const int32_t *__restrict__ hdr_id, uint32_t *__restrict__ voted)
 {
   const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= ncl) return;
+  if (lane == 0) voted[c] = 0;
   const BpWork wk = work[c];
   if (!wk.ok) return;
   bk_cluster k = cl[c];
@@ -348,9 +366,7 @@ __global__ __launch_bounds__(256) void k_bp_vote(RecView r, const bk_split *__re
       }
     }
   }
-  __threadfence_block();
-  // every lane of this wave must see the emitted list: wave-local, same CU -> a workgroup-scope fence and
-  // the wave's own in-order memory pipeline suffice, but keep it simple and safe:
+  // the list was written by other lanes of this wave: make it visible before it is read back
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   // vote (:804-855): for each distinct key, count emitted pairs within +-2 on both coordinates (unsigned
   // arithmetic, :820-821); first strict maximum in std::map<string> order wins
@@ -384,18 +400,68 @@ __global__ __launch_bounds__(256) void k_bp_vote(RecView r, const bk_split *__re
       best2 = o2;
     }
   }
-  if (best_cnt >= 2)  // :446
+  if (best_cnt >= 2 && lane == 0)  // :446
   {
     k.p1_exact = (uint32_t) best1;
     k.p2_exact = best2;
     k.n_sr = (uint32_t) best_cnt;
-    uint32_t d1 = base_depth(r, k.p1_tid, (unsigned long long) k.p1_exact, maxspan);
-    uint32_t d2 = base_depth(r, k.p2_tid, (unsigned long long) (long long) k.p2_exact, maxspan);
-    k.depth1 = d1;
-    k.depth2 = d2;
-    k.flags |= 2u;
-    if (lane == 0) cl[c] = k;
+    cl[c] = k;
+    voted[c] = 1;
   }
+}
+
+// phase 4 (per shard): cal_single_base_depth partial counts for the voted clusters
+__global__ __launch_bounds__(256) void k_bp_depth(RecView r, const bk_cluster *__restrict__ cl, uint32_t ncl, int maxspan, const uint32_t *__restrict__ voted,
+                                                  uint32_t *__restrict__ depth)
+{
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= ncl) return;
+  uint32_t d1 = 0, d2 = 0;
+  if (voted[c])
+  {
+    const bk_cluster k = cl[c];
+    for (int side = 0; side < 2; ++side)
+    {
+      // bam_iter_query(idx, tid, pos - 1, pos) with uint64 -> int conversions (util_bed.cc:154-181)
+      const unsigned long long pos = side ? (unsigned long long) (long long) k.p2_exact : (unsigned long long) k.p1_exact;
+      const int32_t tid = side ? k.p2_tid : k.p1_tid;
+      int beg = (int) (pos - 1ull), end = (int) pos;
+      if (beg < 0) beg = 0;
+      uint32_t d = 0;
+      if (!(end < beg || tid < 0))
+      {
+        Region rg;
+        rg.tid = tid;
+        rg.beg = beg;
+        rg.end = end;
+        rg.valid = true;
+        const int lane = threadIdx.x & 63;
+        uint64_t lo = rec_lower(r, tid, (long long) beg - maxspan), hi = rec_lower(r, tid, (long long) end);
+        long long acc = 0;
+        for (uint64_t i = lo + lane; i < hi; i += 64)
+        {
+          if (!in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) continue;
+          uint16_t f = r.flag[i];
+          if (r.mapq[i] > 0 && !(f & 0x400) && (f & 1)) ++acc;  // util_bed.cc:183
+        }
+        d = (uint32_t) wave_sum(acc);
+      }
+      if (side) d2 = d; else d1 = d;
+    }
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    depth[2 * c] = d1;
+    depth[2 * c + 1] = d2;
+  }
+}
+__global__ __launch_bounds__(256) void k_bp_finish(bk_cluster *__restrict__ cl, uint32_t ncl, const uint32_t *__restrict__ voted, const uint32_t *__restrict__ depth)
+{
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncl || !voted[c]) return;
+  cl[c].depth1 = depth[2 * c];
+  cl[c].depth2 = depth[2 * c + 1];
+  cl[c].flags |= 2u;
 }
 
 __global__ __launch_bounds__(256) void k_split_keys(const bk_split *__restrict__ sp, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -471,9 +537,16 @@ uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32
   return nk;
 }
 
-void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
-                       hipStream_t st)
+uint32_t *bp_cov_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl, double w, int maxspan, BpBufs &b, hipStream_t st)
 {
+  uint32_t *cov = b.cov.as<uint32_t>(2 * ncl + 2);
+  if (ncl) hipLaunchKernelGGL(k_bp_cov, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, cl, (uint32_t) ncl, (int) w, maxspan, cov);
+  return cov;
+}
+
+void bp_vote(const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const uint32_t *cov, const int32_t *hdr_id, BpBufs &b, hipStream_t st)
+{
+  uint32_t *voted = b.voted.as<uint32_t>(ncl + 1);
   if (ncl == 0) return;
   if (ncl > 0x7FFFFFFFull) throw bk_error(BK_ERR_LIMIT, "too many clusters");
   const int wi = (int) w;  // `const int w` parameter, BreakID.cc:390
@@ -481,7 +554,7 @@ void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cl
   uint32_t *nmatch = b.nmatch.as<uint32_t>(ncl + 1), *moff = b.moff.as<uint32_t>(ncl + 1);
   uint32_t *err = b.err.as<uint32_t>(4);
   HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
-  hipLaunchKernelGGL(k_bp_regions, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, sp, nsp, cl, (uint32_t) ncl, wi, maxspan, work, nmatch, err);
+  hipLaunchKernelGGL(k_bp_regions, dim3(cdiv(ncl, 4)), dim3(256), 0, st, sp, nsp, cl, (uint32_t) ncl, wi, maxspan, cov, work, nmatch, err);
   prims::exclusive_scan<uint32_t>(nmatch, moff, ncl, b.scan_tmp, st);
   uint32_t host[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(&host[0], moff + ncl, 4, hipMemcpyDeviceToHost, st));
@@ -491,5 +564,28 @@ void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cl
   int2 *emit = b.emit.as<int2>((uint64_t) host[0] + 1);
   uint32_t *ecount = b.ecount.as<uint32_t>(ncl + 1);
   HIP_CHECK(hipMemsetAsync(ecount, 0, (ncl + 1) * 4, st));
-  hipLaunchKernelGGL(k_bp_vote, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, sp, cl, (uint32_t) ncl, wi, maxspan, work, moff, emit, ecount, hdr_id);
+  hipLaunchKernelGGL(k_bp_vote, dim3(cdiv(ncl, 4)), dim3(256), 0, st, sp, cl, (uint32_t) ncl, wi, work, moff, emit, ecount, hdr_id, voted);
+}
+
+uint32_t *bp_depth_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl, int maxspan, BpBufs &b, hipStream_t st)
+{
+  uint32_t *depth = b.depth.as<uint32_t>(2 * ncl + 2);
+  if (ncl) hipLaunchKernelGGL(k_bp_depth, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, cl, (uint32_t) ncl, maxspan, b.voted.get<uint32_t>(), depth);
+  return depth;
+}
+
+void bp_finish(bk_cluster *cl, uint64_t ncl, const uint32_t *depth, BpBufs &b, hipStream_t st)
+{
+  if (ncl) hipLaunchKernelGGL(k_bp_finish, dim3(cdiv(ncl, 256)), dim3(256), 0, st, cl, (uint32_t) ncl, b.voted.get<uint32_t>(), depth);
+}
+
+// single table: all four phases back to back (the counts need no exchange)
+void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
+                       hipStream_t st)
+{
+  if (ncl == 0) return;
+  const uint32_t *cov = bp_cov_partial(r, cl, ncl, w, maxspan, b, st);
+  bp_vote(sp, nsp, cl, ncl, w, maxspan, cov, hdr_id, b, st);
+  const uint32_t *depth = bp_depth_partial(r, cl, ncl, maxspan, b, st);
+  bp_finish(cl, ncl, depth, b, st);
 }

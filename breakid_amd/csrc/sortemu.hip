@@ -117,6 +117,7 @@ struct LdsMem
   __device__ __forceinline__ hent ld(uint32_t i) const { return e[i]; }
   __device__ __forceinline__ void st(uint32_t i, hent v) const { e[i] = v; }
   __device__ __forceinline__ void step_sync() const { __builtin_amdgcn_wave_barrier(); }
+  __device__ __forceinline__ void launch_sync() const { __builtin_amdgcn_wave_barrier(); }
 };
 // global-memory variant for segments that do not fit LDS.  All lanes belong to one wavefront on one CU, so
 // plain accesses are coherent through that CU's write-through L1 (the same guarantee __syncthreads() gives a
@@ -127,6 +128,8 @@ struct GlbMem
   __device__ __forceinline__ hent ld(uint32_t i) const { return e[i]; }
   __device__ __forceinline__ void st(uint32_t i, hent v) const { e[i] = v; }
   __device__ __forceinline__ void step_sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  // the detached leaf L is out of reach of every in-flight pop (ancestor stall), so its store needs no drain of its own
+  __device__ __forceinline__ void launch_sync() const {}
 };
 
 __device__ __forceinline__ bool anc_or_self(uint32_t a, uint32_t b)  // is node a an ancestor of (or equal to) node b
@@ -229,7 +232,7 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
           len = L;
           active = true;
         }
-        mem.step_sync();
+        mem.launch_sync();
         since = 0;
         ++next_t;
         launched = true;
