@@ -74,3 +74,11 @@ def fetch_array(lib, handle, fn, stage):
     if ng.value or bool(goff):
         off = np.ctypeslib.as_array(goff, shape=(ng.value + 1,)).copy() if bool(goff) else None
     return arr, off
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("isize_sum", C.c_uint64), ("isize_n", C.c_uint64), ("sumsq", C.c_double), ("vmax", C.c_uint32),
+                ("max_span", C.c_uint32), ("n_cand", C.c_uint64), ("n_split", C.c_uint64)]
+
+
+BUF_CANDIDATES, BUF_TUPLES, BUF_CLUSTERS = 0, 1, 2

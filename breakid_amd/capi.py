@@ -36,7 +36,9 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort", "bk_debug_ahc"]
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort", "bk_debug_ahc", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
+           "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
+           "bk_shard_own_groups", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
 
 def lib():
@@ -73,6 +75,19 @@ def lib():
         L.bk_timing_enable.argtypes = [vp, C.c_int]
         L.bk_debug_std_sort.argtypes = [vp, vp, vp, C.c_uint32, vp]
         L.bk_debug_ahc.argtypes = [vp, vp, vp, C.c_uint32, C.c_double, vp, vp, C.POINTER(C.c_uint32)]
+        L.bk_shard_begin.argtypes = [vp, C.c_uint64, C.c_int]
+        L.bk_shard_get_stats.argtypes = [vp, C.POINTER(abi.ShardStats)]
+        L.bk_shard_set_stats.argtypes = [vp, C.POINTER(abi.ShardStats)]
+        L.bk_shard_sd_local.argtypes = [vp, u64p, C.POINTER(vp), u64p]
+        L.bk_shard_sd_finish.argtypes = [vp, vp, C.c_uint64, C.c_uint64, dp, dp]
+        L.bk_shard_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), u64p, C.POINTER(C.c_uint32)]
+        L.bk_shard_set_buffer.argtypes = [vp, C.c_int, vp, C.c_uint64]
+        L.bk_shard_group_sizes.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
+        L.bk_shard_own_groups.argtypes = [vp, vp, C.c_uint32]
+        L.bk_shard_bp_cov.argtypes = [vp, C.c_double, C.POINTER(vp), u64p]
+        L.bk_shard_bp_vote.argtypes = [vp, C.c_double, vp]
+        L.bk_shard_bp_depth.argtypes = [vp, C.POINTER(vp), u64p]
+        L.bk_shard_bp_finish.argtypes = [vp, vp]
         L.bk_qname_hash.restype = C.c_uint64
         L.bk_qname_hash.argtypes = [C.c_char_p, C.c_size_t]
         L.bk_bam_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]

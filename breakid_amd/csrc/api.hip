@@ -67,6 +67,16 @@ struct bk_ctx
   bool stream_done = false, splits_sorted = false;
   int mapq_min = 20;
   uint64_t cand_cap = 0, split_cap = 0, sa_cap = 0;
+  // sharded sample: this table is records [rec_base, rec_base + n) of the sample; gathered tables replace the local ones
+  uint64_t rec_base = 0;
+  const Cand *ext_cand = nullptr;
+  const bk_split *ext_split = nullptr;
+  bk_cluster *ext_clusters = nullptr;
+  std::vector<uint8_t> own_groups;  // per group (numeric key order): 1 = this rank clusters it; empty = all
+  DevBuf d_drop;
+  const Cand *cand_ptr() const { return ext_cand ? ext_cand : d_cand.get<Cand>(); }
+  const bk_split *split_raw_ptr() const { return ext_split ? ext_split : d_split_raw.get<bk_split>(); }
+  bk_cluster *clusters_ptr() const { return ext_clusters ? ext_clusters : d_clusters.get<bk_cluster>(); }
   SdBufs sdb;
   double mean = 0, sd = 0;
   bool stats_done = false;
@@ -226,6 +236,7 @@ void run_stream(bk_ctx *c)
     HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(StreamCounters), c->st));
     HIP_CHECK(hipMemsetAsync(dsd, 0, sizeof(SdState), c->st));
     a.n = n;
+    a.rec_base = c->rec_base;
     a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
     a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash;
     a.cigar_off = c->rec.cigar_off; a.cigar = c->rec.cigar; a.aux_off = c->rec.aux_off; a.aux = c->rec.aux;
@@ -279,7 +290,7 @@ void ensure_splits_sorted(bk_ctx *c)
   if (c->splits_sorted) return;
   Scope s(c, "split_sort");
   bk_split *sorted = c->d_split.as<bk_split>(c->hc.n_split + 1);
-  sort_splits(c->d_split_raw.get<bk_split>(), c->hc.n_split, sorted, c->bb, c->st);
+  sort_splits(const_cast<bk_split *>(c->split_raw_ptr()), c->hc.n_split, sorted, c->bb, c->st);
   c->splits_sorted = true;
 }
 }  // namespace
@@ -363,6 +374,11 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
     if (!s) throw bk_error(BK_ERR_ARG, "bk_upload_records: null table");
     if (s->n > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records in one context (shard across GPUs)");
     ctx->stream_done = ctx->stats_done = ctx->clustered = false;
+    ctx->ext_cand = nullptr;
+    ctx->ext_split = nullptr;
+    ctx->ext_clusters = nullptr;
+    ctx->own_groups.clear();
+    ctx->rec_base = 0;
     if (mem_space == BK_MEM_DEVICE)
     {
       ctx->rec = *s;
@@ -433,7 +449,7 @@ int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, 
     }
     {
       Scope s(ctx, "mate_join");
-      join_candidates(ctx->d_cand.get<Cand>(), ctx->hc.n_cand, w, ctx->d_tprefix.get<uint32_t>(), ctx->nt, ctx->jb, ctx->st, ctx->jr);
+      join_candidates(ctx->cand_ptr(), ctx->hc.n_cand, w, ctx->d_tprefix.get<uint32_t>(), ctx->nt, ctx->jb, ctx->st, ctx->jr);
     }
     const uint32_t ng = ctx->jr.n_groups;
     ctx->gkey_host.assign(ng, 0);
@@ -470,7 +486,19 @@ int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
   return guarded(ctx, [&] {
     {
       Scope s(ctx, "remove_isolated");
-      remove_isolated_all(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ctx->jr.n_groups, ctx->jr.n_pairs, w, ctx->list, ctx->cb, ctx->st);
+      const uint32_t *drop = nullptr;
+      if (!ctx->own_groups.empty())
+      {
+        // sharded sample: this rank masks and clusters only the chromosome-pair groups it owns
+        if (ctx->own_groups.size() != ctx->jr.n_groups) throw bk_error(BK_ERR_ARG, "bk_shard_own_groups: group count changed");
+        std::vector<uint32_t> d(ctx->jr.n_groups);
+        for (uint32_t g = 0; g < ctx->jr.n_groups; ++g) d[g] = ctx->own_groups[g] ? 0u : 1u;
+        uint32_t *dd = ctx->d_drop.as<uint32_t>((uint64_t) ctx->jr.n_groups + 1);
+        if (ctx->jr.n_groups) HIP_CHECK(hipMemcpyAsync(dd, d.data(), d.size() * 4, hipMemcpyHostToDevice, ctx->st));
+        HIP_CHECK(hipStreamSynchronize(ctx->st));
+        drop = dd;
+      }
+      remove_isolated_all(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ctx->jr.n_groups, ctx->jr.n_pairs, w, ctx->list, ctx->cb, ctx->st, drop);
     }
     ctx->iso_n = ctx->list.n;
     uint32_t *ii = ctx->iso_idx.as<uint32_t>(ctx->list.n + 1);
@@ -519,7 +547,7 @@ int bk_split_breakpoints(bk_ctx *ctx, double w, uint64_t *n_valid)
     r.cigar_off = ctx->rec.cigar_off; r.cigar = ctx->rec.cigar;
     {
       Scope s(ctx, "split_breakpoints");
-      split_breakpoints(r, ctx->d_split.get<bk_split>(), ctx->hc.n_split, ctx->d_clusters.get<bk_cluster>(), ctx->n_clusters, w, (int) ctx->hc.max_span,
+      split_breakpoints(r, ctx->d_split.get<bk_split>(), ctx->hc.n_split, ctx->clusters_ptr(), ctx->n_clusters, w, (int) ctx->hc.max_span,
                         ctx->d_hdr.get<int32_t>(), ctx->bb, ctx->st);
     }
     if (n_valid)
@@ -613,7 +641,7 @@ int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const u
     case BK_STAGE_CLUSTERS:
       ctx->f_clusters.resize(ctx->n_clusters);
       if (ctx->n_clusters)
-        HIP_CHECK(hipMemcpyAsync(ctx->f_clusters.data(), ctx->d_clusters.get<bk_cluster>(), ctx->n_clusters * sizeof(bk_cluster), hipMemcpyDeviceToHost, ctx->st));
+        HIP_CHECK(hipMemcpyAsync(ctx->f_clusters.data(), ctx->clusters_ptr(), ctx->n_clusters * sizeof(bk_cluster), hipMemcpyDeviceToHost, ctx->st));
       HIP_CHECK(hipStreamSynchronize(ctx->st));
       // device order is (numeric chr-pair key, id); the reference appends groups in std::map<string> order
       std::stable_sort(ctx->f_clusters.begin(), ctx->f_clusters.end(), [](const bk_cluster &a, const bk_cluster &b) { return a.group < b.group; });
@@ -634,6 +662,179 @@ int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const u
     default:
       throw bk_error(BK_ERR_ARG, "bk_fetch: unknown stage");
     }
+  });
+}
+
+// ---- single-sample sharding: one context per GPU holds a contiguous range of the sample's records ----------
+int bk_shard_begin(bk_ctx *ctx, uint64_t rec_base, int mapq_min)
+{
+  return guarded(ctx, [&] {
+    ctx->rec_base = rec_base;
+    ctx->mapq_min = mapq_min;
+    ctx->ext_cand = nullptr;
+    ctx->ext_split = nullptr;
+    ctx->ext_clusters = nullptr;
+    run_stream(ctx);
+  });
+}
+
+int bk_shard_get_stats(bk_ctx *ctx, bk_shard_stats *out)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done || !out) throw bk_error(BK_ERR_ARG, "bk_shard_get_stats: call bk_shard_begin first");
+    out->isize_sum = ctx->hc.isize_sum;
+    out->isize_n = ctx->hc.isize_n;
+    out->sumsq = ctx->hsd.sumsq;
+    out->vmax = ctx->hsd.vmax;
+    out->max_span = ctx->hc.max_span;
+    out->n_cand = ctx->hc.n_cand;
+    out->n_split = ctx->hc.n_split;
+  });
+}
+
+int bk_shard_set_stats(bk_ctx *ctx, const bk_shard_stats *total)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done || !total) throw bk_error(BK_ERR_ARG, "bk_shard_set_stats: call bk_shard_begin first");
+    ctx->hc.isize_sum = total->isize_sum;
+    ctx->hc.isize_n = total->isize_n;
+    ctx->hsd.sumsq = total->sumsq;
+    ctx->hsd.vmax = total->vmax;
+    ctx->hc.max_span = total->max_span;
+    ctx->stats_done = false;
+  });
+}
+
+static void sd_mean_thr(bk_ctx *ctx, double &m, double &thr)
+{
+  const double n = (double) ctx->hc.isize_n;
+  m = (double) (long long) ctx->hc.isize_sum / n;  // (double) long / (double) size_t, BreakID.cc:1941
+  double sum_d = ctx->hsd.sumsq - 2.0 * m * (double) ctx->hc.isize_sum + n * m * m;
+  if (!(sum_d > 0)) sum_d = 0;
+  double da = (double) ctx->hsd.vmax - m, dmax = da * da + m * m;
+  double bound = 2.0 * sum_d + 2.0 * n + 2.0 * dmax + 4.0;
+  int k = std::ilogb(bound) + 1;
+  thr = k >= 51 ? 1.0e300 : std::ldexp(1.0, k - 53);
+}
+
+int bk_shard_sd_local(bk_ctx *ctx, uint64_t *l_total, void **ex_dev, uint64_t *n_ex)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done) throw bk_error(BK_ERR_ARG, "bk_shard_sd_local: call bk_shard_begin / bk_shard_set_stats first");
+    double m, thr;
+    sd_mean_thr(ctx, m, thr);
+    unsigned long long lt = 0, ne = 0;
+    launch_sd_local(ctx->rec.flag, ctx->rec.isize, ctx->rec.n, m, thr, ctx->sdb, ctx->st, &lt, &ne);
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    if (l_total) *l_total = lt;
+    if (n_ex) *n_ex = ne;
+    if (ex_dev) *ex_dev = ctx->sdb.exceptions.p;
+  });
+}
+
+int bk_shard_sd_finish(bk_ctx *ctx, const void *all_ex_dev, uint64_t n_all, uint64_t l_grand, double *mean, double *sd)
+{
+  return guarded(ctx, [&] {
+    double m, thr;
+    sd_mean_thr(ctx, m, thr);
+    launch_sd_walk((const SdException *) all_ex_dev, n_all, l_grand, ctx->d_sd.get<SdState>(), ctx->st);
+    HIP_CHECK(hipMemcpyAsync(&ctx->hsd.t_final, &ctx->d_sd.get<SdState>()->t_final, 8, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    ctx->mean = m;
+    ctx->sd = std::sqrt((double) ctx->hsd.t_final / (double) ctx->hc.isize_n);
+    ctx->stats_done = true;
+    if (mean) *mean = ctx->mean;
+    if (sd) *sd = ctx->sd;
+  });
+}
+
+int bk_shard_buffer(bk_ctx *ctx, int which, void **dev, uint64_t *count, uint32_t *elem_bytes)
+{
+  return guarded(ctx, [&] {
+    if (!dev || !count || !elem_bytes) throw bk_error(BK_ERR_ARG, "bk_shard_buffer: null output");
+    switch (which)
+    {
+    case BK_BUF_CANDIDATES: *dev = ctx->d_cand.p; *count = ctx->ext_cand ? 0 : ctx->hc.n_cand; *elem_bytes = sizeof(Cand); break;
+    case BK_BUF_TUPLES: *dev = ctx->d_split_raw.p; *count = ctx->ext_split ? 0 : ctx->hc.n_split; *elem_bytes = sizeof(bk_split); break;
+    case BK_BUF_CLUSTERS: *dev = ctx->d_clusters.p; *count = ctx->ext_clusters ? 0 : ctx->n_clusters; *elem_bytes = sizeof(bk_cluster); break;
+    default: throw bk_error(BK_ERR_ARG, "bk_shard_buffer: unknown buffer");
+    }
+  });
+}
+
+int bk_shard_set_buffer(bk_ctx *ctx, int which, const void *dev, uint64_t count)
+{
+  return guarded(ctx, [&] {
+    switch (which)
+    {
+    case BK_BUF_CANDIDATES: ctx->ext_cand = (const Cand *) dev; ctx->hc.n_cand = count; break;
+    case BK_BUF_TUPLES: ctx->ext_split = (const bk_split *) dev; ctx->hc.n_split = count; ctx->splits_sorted = false; break;
+    case BK_BUF_CLUSTERS: ctx->ext_clusters = (bk_cluster *) dev; ctx->n_clusters = count; break;
+    default: throw bk_error(BK_ERR_ARG, "bk_shard_set_buffer: unknown buffer");
+    }
+  });
+}
+
+int bk_shard_group_sizes(bk_ctx *ctx, const uint64_t **starts, uint32_t *n_groups)
+{
+  return guarded(ctx, [&] {
+    if (starts) *starts = ctx->gstart_host.data();
+    if (n_groups) *n_groups = ctx->jr.n_groups;
+  });
+}
+
+int bk_shard_own_groups(bk_ctx *ctx, const uint8_t *own, uint32_t n_groups)
+{
+  return guarded(ctx, [&] {
+    if (n_groups != ctx->jr.n_groups) throw bk_error(BK_ERR_ARG, "bk_shard_own_groups: wrong group count");
+    ctx->own_groups.assign(own, own + n_groups);
+  });
+}
+
+static RecView rec_view(const bk_ctx *ctx)
+{
+  RecView r;
+  r.n = ctx->rec.n;
+  r.tid = ctx->rec.tid; r.pos = ctx->rec.pos; r.flag = ctx->rec.flag; r.mapq = ctx->rec.mapq;
+  r.cigar_off = ctx->rec.cigar_off; r.cigar = ctx->rec.cigar;
+  return r;
+}
+
+int bk_shard_bp_cov(bk_ctx *ctx, double w, void **cov_dev, uint64_t *n)
+{
+  return guarded(ctx, [&] {
+    uint32_t *cov = bp_cov_partial(rec_view(ctx), ctx->clusters_ptr(), ctx->n_clusters, w, (int) ctx->hc.max_span, ctx->bb, ctx->st);
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    if (cov_dev) *cov_dev = cov;
+    if (n) *n = 2 * ctx->n_clusters;
+  });
+}
+
+int bk_shard_bp_vote(bk_ctx *ctx, double w, const void *cov_total_dev)
+{
+  return guarded(ctx, [&] {
+    ensure_splits_sorted(ctx);
+    bp_vote(ctx->d_split.get<bk_split>(), ctx->hc.n_split, ctx->clusters_ptr(), ctx->n_clusters, w, (int) ctx->hc.max_span, (const uint32_t *) cov_total_dev,
+            ctx->d_hdr.get<int32_t>(), ctx->bb, ctx->st);
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+  });
+}
+
+int bk_shard_bp_depth(bk_ctx *ctx, void **depth_dev, uint64_t *n)
+{
+  return guarded(ctx, [&] {
+    uint32_t *d = bp_depth_partial(rec_view(ctx), ctx->clusters_ptr(), ctx->n_clusters, (int) ctx->hc.max_span, ctx->bb, ctx->st);
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    if (depth_dev) *depth_dev = d;
+    if (n) *n = 2 * ctx->n_clusters;
+  });
+}
+
+int bk_shard_bp_finish(bk_ctx *ctx, const void *depth_total_dev)
+{
+  return guarded(ctx, [&] {
+    bp_finish(ctx->clusters_ptr(), ctx->n_clusters, (const uint32_t *) depth_total_dev, ctx->bb, ctx->st);
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
   });
 }
 

@@ -23,7 +23,8 @@ struct ClusterBufs
 };
 
 // remove_isolated_pairs for every group; L receives the surviving list (x-sorted, duplicates included)
-void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st);
+void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
+                         const uint32_t *drop_group = nullptr);  // drop_group[g] != 0: group g is left to another rank
 // removes the groups that keep fewer than 2 pairs (they are not clustered, BreakID.cc:125)
 void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st);
 // find_cluster_pairs_enspan_fast for every group with >= 2 pairs; L becomes the clustered list, cluster_out[p] its cluster number

@@ -233,6 +233,7 @@ uint64_t PairList::total(hipStream_t st) const
 }
 
 static inline unsigned nb(uint64_t n) { return cdiv(n ? n : 1, 256); }
+static void filter_groups(PairList &L, const uint32_t *drop, ClusterBufs &b, hipStream_t st);
 
 // sort list by x or y exactly like std::sort; all element attributes follow
 static void sort_list(const bk_pair *pairs, PairList &L, int use_y, uint32_t **extra, int n_extra, ClusterBufs &b, hipStream_t st)
@@ -271,7 +272,8 @@ static void mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs 
   L.n = total;
 }
 
-void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st)
+void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
+                         const uint32_t *drop_group)
 {
   L.n = n;
   L.ng = ng;
@@ -282,6 +284,7 @@ void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint6
   hipLaunchKernelGGL(k_iota, dim3(nb(n)), dim3(256), 0, st, idx, n);
   HIP_CHECK(hipMemcpyAsync(gof, gof0, n * 4, hipMemcpyDeviceToDevice, st));
   HIP_CHECK(hipMemcpyAsync(goff, gstart, ((uint64_t) ng + 1) * 8, hipMemcpyDeviceToDevice, st));
+  if (drop_group) filter_groups(L, drop_group, b, st);
   const long dist = (long) w;  // remove_isolated_pairs passes double w to a `long distance` parameter
   sort_list(pairs, L, 0, nullptr, 0, b, st);
   mask_list(pairs, L, dist, b, st);
@@ -332,14 +335,12 @@ static void fast_pass(const bk_pair *pairs, PairList &L, int use_y, double w, De
   L.n = total;
 }
 
-void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st)
+// removes every element whose group is flagged in drop[] (device, one u32 per group)
+static void filter_groups(PairList &L, const uint32_t *drop, ClusterBufs &b, hipStream_t st)
 {
-  // groups with fewer than 2 pairs after masking are not clustered at all (BreakID.cc:125)
   if (L.n == 0) return;
-  uint32_t *small = b.small.as<uint32_t>((uint64_t) L.ng + 1);
-  hipLaunchKernelGGL(k_group_small, dim3(cdiv(L.ng, 256)), dim3(256), 0, st, L.goff.get<uint64_t>(), L.ng, small);
   uint32_t *keep = b.cnt.as<uint32_t>(L.n + 1), *off = b.off.as<uint32_t>(L.n + 1);
-  hipLaunchKernelGGL(k_drop_small, dim3(nb(L.n)), dim3(256), 0, st, L.gof.get<uint32_t>(), small, L.n, keep);
+  hipLaunchKernelGGL(k_drop_small, dim3(nb(L.n)), dim3(256), 0, st, L.gof.get<uint32_t>(), drop, L.n, keep);
   prims::exclusive_scan<uint32_t>(keep, off, L.n, b.scan_tmp, st);
   uint32_t total = 0;
   HIP_CHECK(hipMemcpyAsync(&total, off + L.n, 4, hipMemcpyDeviceToHost, st));
@@ -356,6 +357,15 @@ void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st)
     std::swap(L.goff, b.goff2);
     L.n = total;
   }
+}
+
+void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st)
+{
+  // groups with fewer than 2 pairs after masking are not clustered at all (BreakID.cc:125)
+  if (L.n == 0) return;
+  uint32_t *small = b.small.as<uint32_t>((uint64_t) L.ng + 1);
+  hipLaunchKernelGGL(k_group_small, dim3(cdiv(L.ng, 256)), dim3(256), 0, st, L.goff.get<uint64_t>(), L.ng, small);
+  filter_groups(L, small, b, st);
 }
 
 void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluster_out, ClusterBufs &b, hipStream_t st)

@@ -35,6 +35,7 @@ struct NameTableDev
 struct StreamArgs
 {
   uint64_t n;
+  uint64_t rec_base;  // index of record 0 of this table in the whole sample (0 unless the sample is sharded)
   const int32_t *tid, *pos, *mtid, *mpos, *isize;
   const uint16_t *flag;
   const uint8_t *mapq;
@@ -56,4 +57,7 @@ struct StreamArgs
 void launch_stream(const StreamArgs &a, hipStream_t st);
 void launch_split_records(const StreamArgs &a, unsigned long long n_sa, hipStream_t st);
 // mean: host-computed (double) sum / (double) n; thr: exception threshold 2^(kmax-53) (or huge = replay all)
+void launch_sd_local(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdBufs &b, hipStream_t st, unsigned long long *l_total,
+                     unsigned long long *n_ex_out);
+void launch_sd_walk(const SdException *ex, unsigned long long n_ex, unsigned long long l_total, SdState *sd, hipStream_t st);
 void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st);

@@ -246,7 +246,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
     int c1_s = tmp.begin + tmp.tail, c2_s = sac.tail + sac.begin;
     if (!((c1_m <= c2_s + 10 && c1_m >= c2_s - 10) && (c1_m + c1_s == c2_m + c2_s))) return false;
   }
-  t.rec = (uint32_t) i;
+  t.rec = (uint32_t) (a.rec_base + i);
   t.tid = tid;
   t.pos = pos;
   t.endpos = endpos;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
           const uint64_t i = i0 + k;
           Cand cd;
           cd.qhash = a.qhash[i];
-          cd.rec = (uint32_t) i;
+          cd.rec = (uint32_t) (a.rec_base + i);
           cd.tid = tidv[k];
           cd.pos = posv[k];
           cd.mtid = a.mtid[i];
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     if (cand)
     {
       Cand cd;
-      cd.qhash = a.qhash[i]; cd.rec = (uint32_t) i; cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
+      cd.qhash = a.qhash[i]; cd.rec = (uint32_t) (a.rec_base + i); cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
       cd.flag = flag; cd.mapq = mapq; cd.pad = 0;
       unsigned long long g = atomicAdd(&a.counters->n_cand, 1ull);
       if (g < a.cand_cap) a.cand[g] = cd;
@@ -730,10 +730,8 @@ __global__ __launch_bounds__(256) void k_sd_emit(const uint16_t *__restrict__ fl
 }
 
 // one wave: replay the exceptions in record order
-__global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ ex, const unsigned long long *n_ex_p, const unsigned long long *l_total_p,
-                                                SdState *s)
+__global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ ex, unsigned long long n_ex, unsigned long long l_total, SdState *s)
 {
-  const unsigned long long n_ex = *n_ex_p;
   const int lane = threadIdx.x;
   long long corr = 0;
   for (unsigned long long base = 0; base < n_ex; base += 64)
@@ -756,10 +754,7 @@ __global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ 
       corr += (tnew - tprev) - (long long) floor(dj);
     }
   }
-  if (lane == 0)
-  {
-    s->t_final = (long long) *l_total_p + corr;
-  }
+  if (lane == 0) s->t_final = (long long) l_total + corr;
 }
 }  // namespace
 
@@ -778,7 +773,9 @@ void launch_split_records(const StreamArgs &a, unsigned long long n_sa, hipStrea
   hipLaunchKernelGGL(k_split_records, dim3(cdiv(n_sa, 256)), dim3(256), 0, st, a, n_sa);
 }
 
-void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st)
+// per-table part: floor sums and the ordered exception list (l_before relative to this table)
+void launch_sd_local(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdBufs &b, hipStream_t st, unsigned long long *l_total,
+                     unsigned long long *n_ex_out)
 {
   uint32_t nb = cdiv(n, SD_TILE);
   if (nb == 0) nb = 1;
@@ -787,12 +784,27 @@ void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double me
   hipLaunchKernelGGL(k_sd_count, dim3(nb), dim3(256), 0, st, flag, isize, n, mean, thr, blockL, blockE);
   prims::exclusive_scan<unsigned long long>(blockL, blockL, nb, b.scan_tmp, st);
   prims::exclusive_scan<unsigned long long>(blockE, blockE, nb, b.scan_tmp2, st);
-  // exception capacity: read the total back (tiny sync) so the list can be sized exactly
-  unsigned long long n_ex = 0;
-  HIP_CHECK(hipMemcpyAsync(&n_ex, blockE + nb, sizeof n_ex, hipMemcpyDeviceToHost, st));
+  // exception capacity: read the totals back (tiny sync) so the list can be sized exactly
+  unsigned long long host[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(&host[0], blockE + nb, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&host[1], blockL + nb, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
-  SdException *ex = b.exceptions.as<SdException>(n_ex + 1);
-  if (n_ex) hipLaunchKernelGGL(k_sd_emit, dim3(nb), dim3(256), 0, st, flag, isize, n, mean, thr, blockL, blockE, ex);
-  hipLaunchKernelGGL(k_sd_walk, dim3(1), dim3(64), 0, st, ex, blockE + nb, blockL + nb, sd);
-  b.last_exceptions = n_ex;
+  SdException *ex = b.exceptions.as<SdException>(host[0] + 1);
+  if (host[0]) hipLaunchKernelGGL(k_sd_emit, dim3(nb), dim3(256), 0, st, flag, isize, n, mean, thr, blockL, blockE, ex);
+  b.last_exceptions = host[0];
+  *n_ex_out = host[0];
+  *l_total = host[1];
+}
+
+// replay of the (possibly gathered) exception list: l_before must already be global
+void launch_sd_walk(const SdException *ex, unsigned long long n_ex, unsigned long long l_total, SdState *sd, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_sd_walk, dim3(1), dim3(64), 0, st, ex, n_ex, l_total, sd);
+}
+
+void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st)
+{
+  unsigned long long l_total = 0, n_ex = 0;
+  launch_sd_local(flag, isize, n, mean, thr, b, st, &l_total, &n_ex);
+  launch_sd_walk(b.exceptions.get<SdException>(), n_ex, l_total, sd, st);
 }

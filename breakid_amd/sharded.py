@@ -1,0 +1,172 @@
+"""One sample sharded over several GPUs: every rank holds a contiguous range of the
+coordinate-sorted records in its own libbreakid_hip context; the small derived tables move between the ranks
+with torch.distributed collectives (backend "nccl" = RCCL over xGMI on a node; "gloo" stages through the host
+and is what the 2-rank tests use).  Exchange steps:
+
+  all-reduce   insert-size sums / spans                      (4 scalars)
+  all-gather   sd exceptions (16 B x ~2e-4 n)                 bit-exact `long += double` replay in record order
+  all-gather   discordant candidates (32 B x ~5 % n)          mates live on other shards
+  all-gather   split-evidence tuples (80 B x ~0.5 % n), cluster summaries of the owned chr-pair groups
+  all-reduce   coverage and depth counts per cluster          range counts add over record shards
+
+Chromosome-pair groups are independent in the reference (BreakID.cc:119-167), so after the replicated mate join
+each group is clustered by exactly one rank (LPT on pair counts)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import abi, capi
+
+
+class _Raw:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def tensor_from_ptr(ptr, nbytes, device):
+    """uint8 view of raw device memory owned by the library (no copy)."""
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_Raw(ptr, nbytes), device=device)
+
+
+class Comm:
+    """torch.distributed wrapper that works with device tensors (nccl) or stages them through the host (gloo)."""
+
+    def __init__(self, device, group=None):
+        self.device = device
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.host_staged = self.on and dist.get_backend(group) == "gloo"
+
+    def _to_comm(self, t):
+        return t.cpu() if self.host_staged else t
+
+    def all_reduce(self, t, op="sum"):
+        if not self.on or self.world == 1:
+            return t
+        x = self._to_comm(t.contiguous())
+        dist.all_reduce(x, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
+        return x.to(t.device)
+
+    def all_gather_scalars(self, vals):
+        """list of python ints -> int64 tensor [world, len(vals)] on the host."""
+        t = torch.tensor(list(vals), dtype=torch.int64)
+        if not self.on or self.world == 1:
+            return t.unsqueeze(0)
+        x = t.to(self.device) if not self.host_staged else t
+        out = [torch.empty_like(x) for _ in range(self.world)]
+        dist.all_gather(out, x, group=self.group)
+        return torch.stack([o.cpu() for o in out])
+
+    def all_gather_var(self, t):
+        """uint8 tensor of rank-dependent length -> concatenation in rank order (device tensor)."""
+        if not self.on or self.world == 1:
+            return t
+        sizes = self.all_gather_scalars([t.numel()])[:, 0].tolist()
+        mx = max(sizes)
+        if mx == 0:
+            return t
+        pad = torch.zeros(mx, dtype=torch.uint8, device=t.device)
+        pad[: t.numel()] = t
+        x = self._to_comm(pad)
+        out = [torch.empty_like(x) for _ in range(self.world)]
+        dist.all_gather(out, x, group=self.group)
+        return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(t.device)
+
+
+def lpt_owner(sizes, world):
+    """Longest-processing-time assignment of chr-pair groups to ranks (deterministic on every rank)."""
+    order = sorted(range(len(sizes)), key=lambda g: (-int(sizes[g]), g))
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for g in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[g] = r
+        load[r] += int(sizes[g])
+    return owner
+
+
+class ShardedRun:
+    """Drives one rank's context through the sharded pipeline.  After run() every rank's context holds the whole
+    cluster table (ctx.fetch(STAGE_CLUSTERS))."""
+
+    def __init__(self, ctx: capi.Context, comm: Comm):
+        self.ctx, self.comm = ctx, comm
+        self._keep = []
+
+    def _buffer(self, which):
+        L, h = self.ctx.L, self.ctx.h
+        ptr, n, eb = C.c_void_p(), C.c_uint64(), C.c_uint32()
+        self.ctx._check(L.bk_shard_buffer(h, which, C.byref(ptr), C.byref(n), C.byref(eb)))
+        return tensor_from_ptr(ptr.value, n.value * eb.value, self.comm.device), eb.value
+
+    def _gather_into(self, which):
+        L, h = self.ctx.L, self.ctx.h
+        local, eb = self._buffer(which)
+        allt = self.comm.all_gather_var(local.clone() if self.comm.world > 1 else local)
+        self._keep.append(allt)
+        self.ctx._check(L.bk_shard_set_buffer(h, which, C.c_void_p(allt.data_ptr() if allt.numel() else 0), allt.numel() // eb))
+        return allt.numel() // eb
+
+    def run(self, rec_base, qual=20, fast=True):
+        ctx, comm = self.ctx, self.comm
+        L, h, dev = ctx.L, ctx.h, comm.device
+        self._keep = []
+        ctx._check(L.bk_shard_begin(h, rec_base, qual))
+        st = abi.ShardStats()
+        ctx._check(L.bk_shard_get_stats(h, C.byref(st)))
+        sums = comm.all_reduce(torch.tensor([st.isize_sum, st.isize_n], dtype=torch.int64, device=dev))
+        sq = comm.all_reduce(torch.tensor([st.sumsq], dtype=torch.float64, device=dev))
+        mx = comm.all_reduce(torch.tensor([st.vmax, st.max_span], dtype=torch.int64, device=dev), op="max")
+        st.isize_sum, st.isize_n = int(sums[0]), int(sums[1])
+        st.sumsq = float(sq[0])
+        st.vmax, st.max_span = int(mx[0]), int(mx[1])
+        ctx._check(L.bk_shard_set_stats(h, C.byref(st)))
+        # bit-exact sd: exceptions of all shards replayed in global record order
+        lt, exp, nex = C.c_uint64(), C.c_void_p(), C.c_uint64()
+        ctx._check(L.bk_shard_sd_local(h, C.byref(lt), C.byref(exp), C.byref(nex)))
+        per = comm.all_gather_scalars([lt.value, nex.value])
+        offset = int(per[: comm.rank, 0].sum())
+        ex = tensor_from_ptr(exp.value, nex.value * 16, dev).clone()
+        if nex.value and offset:
+            v = ex.view(torch.int64).view(-1, 2)
+            v[:, 0] += offset  # l_before becomes global (two's complement add on the u64 bits)
+        all_ex = comm.all_gather_var(ex)
+        self._keep.append(all_ex)
+        mean, sd = C.c_double(), C.c_double()
+        ctx._check(L.bk_shard_sd_finish(h, C.c_void_p(all_ex.data_ptr() if all_ex.numel() else 0), all_ex.numel() // 16, int(per[:, 0].sum()),
+                                        C.byref(mean), C.byref(sd)))
+        w = capi.w_from(mean.value, sd.value)
+        # candidates -> replicated mate join
+        self._gather_into(abi.BUF_CANDIDATES)
+        ctx.discordant_pairs(qual, w)
+        starts, ng = C.POINTER(C.c_uint64)(), C.c_uint32()
+        ctx._check(L.bk_shard_group_sizes(h, C.byref(starts), C.byref(ng)))
+        sizes = [int(starts[g + 1] - starts[g]) for g in range(ng.value)]
+        owner = lpt_owner(sizes, comm.world)
+        own = np.asarray([1 if o == comm.rank else 0 for o in owner], dtype=np.uint8)
+        ctx._check(L.bk_shard_own_groups(h, own.ctypes.data if len(own) else None, ng.value))
+        ctx.mask_and_cluster(w, fast)
+        ctx.cluster_summary(w)
+        # tuples and cluster summaries to everybody
+        self._gather_into(abi.BUF_TUPLES)
+        ncl = self._gather_into(abi.BUF_CLUSTERS)
+        # breakpoints: range counts add over the record shards
+        p, n = C.c_void_p(), C.c_uint64()
+        ctx._check(L.bk_shard_bp_cov(h, w, C.byref(p), C.byref(n)))
+        cov = comm.all_reduce(tensor_from_ptr(p.value, n.value * 4, dev).view(torch.int32).clone())
+        self._keep.append(cov)
+        ctx._check(L.bk_shard_bp_vote(h, w, C.c_void_p(cov.data_ptr() if cov.numel() else 0)))
+        ctx._check(L.bk_shard_bp_depth(h, C.byref(p), C.byref(n)))
+        dep = comm.all_reduce(tensor_from_ptr(p.value, n.value * 4, dev).view(torch.int32).clone())
+        self._keep.append(dep)
+        ctx._check(L.bk_shard_bp_finish(h, C.c_void_p(dep.data_ptr() if dep.numel() else 0)))
+        self.mean, self.sd, self.w, self.n_clusters = mean.value, sd.value, w, ncl
+        return w

@@ -223,3 +223,208 @@ def to_numpy_cols(cols):
     out["cigar"] = out["cigar"][: cols["n_cigar_words"]]
     out["aux"] = out["aux"][: cols["n_aux_bytes"]]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One sample sharded over `world` ranks: rank r generates only the records whose genome-wide coordinate falls into
+# its contiguous range, from counter-based random numbers, so that mates / split partners that live on other
+# shards carry consistent positions without any rank materialising the whole sample.
+def _h64(*parts):
+    """splitmix64 of a tuple of broadcastable uint64 arrays / ints (vectorised, wraparound arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = np.uint64(0x9E3779B97F4A7C15)
+        for p in parts:
+            x = (x ^ np.asarray(p, dtype=np.uint64)) * np.uint64(0xBF58476D1CE4E5B9)
+            x = x ^ (x >> np.uint64(29))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _site(seed, salt, idx, lens, prefix, margin=5000):
+    """deterministic (tid, pos, gpos) of site `idx`."""
+    G = int(prefix[-1] + lens[-1])
+    g = (_h64(seed, salt, idx) % np.uint64(G)).astype(np.int64)
+    t = np.searchsorted(prefix, g, side="right") - 1
+    p = np.clip(g - prefix[t], margin, lens[t] - margin)
+    return t, p, prefix[t] + p
+
+
+def make_wgs_shard(n_per_rank: int, seed: int, device, rank: int, world: int, contigs=HG19, read_len=150, disc_frac=0.05,
+                   pairs_per_locus=50, split_every=2, splits_per_locus=8, jitter=400, ins_mean=350.0, ins_sd=40.0):
+    """Records of rank `rank` (genome range [rank, rank+1) * G / world) of one world*n_per_rank-record sample."""
+    lens = np.asarray([l for _, l in contigs], dtype=np.int64)
+    names = np.asarray([n for n, _ in contigs])
+    prefix = np.cumsum(lens) - lens
+    G = int(lens.sum())
+    lo, hi = rank * G // world, (rank + 1) * G // world
+    n_total = n_per_rank * world
+    disc_pairs = int(n_total * disc_frac) // 2
+    n_loci = max(1, int(disc_pairs * 0.8) // pairs_per_locus)
+    noise_pairs = max(0, disc_pairs - n_loci * pairs_per_locus)
+    sd = np.uint64(seed)
+    cols = {k: [] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "pairid", "c0", "c1", "sa")}
+
+    def add(mask, tid, pos, mtid, mpos, isize, flag, mapq, pairid, c0, c1=None, sa=None):
+        k = int(mask.sum())
+        if k == 0:
+            return
+        f = lambda a: (np.full(len(mask), a) if np.isscalar(a) else np.asarray(a))[mask]
+        cols["tid"].append(f(tid).astype(np.int32)); cols["pos"].append(f(pos).astype(np.int32))
+        cols["mtid"].append(f(mtid).astype(np.int32)); cols["mpos"].append(f(mpos).astype(np.int32))
+        cols["isize"].append(f(isize).astype(np.int32)); cols["flag"].append(f(flag).astype(np.uint16))
+        cols["mapq"].append(f(mapq).astype(np.uint8)); cols["pairid"].append(f(pairid).astype(np.int64))
+        cols["c0"].append(f(c0).astype(np.uint32))
+        cols["c1"].append(np.zeros(k, np.uint32) if c1 is None else f(c1).astype(np.uint32))
+        cols["sa"].append(np.full(k, "", dtype="U48") if sa is None else np.asarray(sa)[mask].astype("U48"))
+
+    M = lambda n: (n << 4) | 0
+    S = lambda n: (n << 4) | 4
+    own = lambda t, p: ((prefix[t] + p) >= lo) & ((prefix[t] + p) < hi)
+    li_all = np.arange(n_loci, dtype=np.int64)
+    la_t, la_p, la_g = _site(sd, 1, li_all, lens, prefix)
+    lb_t, lb_p, lb_g = _site(sd, 2, li_all, lens, prefix)
+    same = (_h64(sd, 3, li_all) % np.uint64(10)) < 3
+    lb_t = np.where(same, la_t, lb_t)
+    lb_p = np.where(same, (la_p + 50000 + (_h64(sd, 4, li_all) % np.uint64(1000000)).astype(np.int64)) % (lens[lb_t] - 10000) + 5000, lb_p)
+    rev_a = (_h64(sd, 5, li_all) & np.uint64(1)).astype(bool)
+    rev_b = (_h64(sd, 6, li_all) & np.uint64(1)).astype(bool)
+    span = jitter + 10
+    near = lambda t, p: ((prefix[t] + p + span) >= lo) & ((prefix[t] + p - span) < hi)
+    mine = np.nonzero(near(la_t, la_p) | near(lb_t, lb_p))[0]
+    # loci pairs
+    li = np.repeat(mine, pairs_per_locus)
+    kk = np.tile(np.arange(pairs_per_locus, dtype=np.int64), len(mine))
+    ta, tb = la_t[li], lb_t[li]
+    pa = la_p[li] + (_h64(sd, 7, li, kk) % np.uint64(2 * jitter + 1)).astype(np.int64) - jitter
+    pb = lb_p[li] + (_h64(sd, 8, li, kk) % np.uint64(2 * jitter + 1)).astype(np.int64) - jitter
+    r9 = _h64(sd, 9, li, kk)
+    mq = np.where((r9 % np.uint64(100)) < 2, ((r9 >> np.uint64(8)) % np.uint64(20)).astype(np.int64), 60)
+    dup = ((r9 >> np.uint64(20)) % np.uint64(100)) < 1
+    ra, rb = rev_a[li], rev_b[li]
+    pid = li * 64 + kk + (1 << 40)
+    fa = 0x1 | 0x40 | np.where(ra, 0x10, 0) | np.where(rb, 0x20, 0) | np.where(dup, 0x400, 0)
+    fb = 0x1 | 0x80 | np.where(rb, 0x10, 0) | np.where(ra, 0x20, 0)
+    isz = np.where(ta == tb, pb - pa + read_len, 0)
+    add(own(ta, pa), ta, pa, tb, pb, isz, fa, mq, pid, M(read_len))
+    add(own(tb, pb), tb, pb, ta, pa, -isz, fb, mq, pid, M(read_len))
+    # noise pairs (every rank evaluates the cheap site hashes of all of them and keeps its own)
+    if noise_pairs:
+        ni = np.arange(noise_pairs, dtype=np.int64)
+        ta, pa, _ = _site(sd, 11, ni, lens, prefix)
+        tb, pb, _ = _site(sd, 12, ni, lens, prefix)
+        ra = (_h64(sd, 13, ni) & np.uint64(1)).astype(bool)
+        rb = (_h64(sd, 14, ni) & np.uint64(1)).astype(bool)
+        pid = ni + (2 << 40)
+        fa = 0x1 | 0x40 | np.where(ra, 0x10, 0) | np.where(rb, 0x20, 0)
+        fb = 0x1 | 0x80 | np.where(rb, 0x10, 0) | np.where(ra, 0x20, 0)
+        isz = np.where(ta == tb, pb - pa + read_len, 0)
+        add(own(ta, pa), ta, pa, tb, pb, isz, fa, 60, pid, M(read_len))
+        add(own(tb, pb), tb, pb, ta, pa, -isz, fb, 60, pid, M(read_len))
+    # split triplets
+    sl = mine[mine % split_every == 0] if split_every else mine[:0]
+    if len(sl) and splits_per_locus:
+        m1, m2 = 90, 60
+        li = np.repeat(sl, splits_per_locus)
+        kk = np.tile(np.arange(splits_per_locus, dtype=np.int64), len(sl))
+        ta, tb = la_t[li], lb_t[li]
+        bpa, bpb = la_p[li] + 30, lb_p[li] + 30
+        pos_a, pos_b = bpa - m1, bpb - 1
+        pid = li * 64 + kk + (3 << 40)
+        c1t, c2t = "%dM%dS" % (m1, m2), "%dS%dM" % (m1, m2)
+        sa1 = np.char.add(np.char.add(np.char.add(names[tb], ","), (pos_b + 1).astype("U12")), ",+,%s,60,0;" % c2t)
+        sa2 = np.char.add(np.char.add(np.char.add(names[ta], ","), (pos_a + 1).astype("U12")), ",+,%s,60,0;" % c1t)
+        add(own(ta, pos_a), ta, pos_a, ta, pos_a + 200, 300, 0x1 | 0x2 | 0x40 | 0x20, 60, pid, M(m1), S(m2), sa1)
+        add(own(tb, pos_b), tb, pos_b, ta, pos_a + 200, 0, 0x1 | 0x40 | 0x20 | 0x100, 60, pid, S(m1), M(m2), sa2)
+        add(own(ta, pos_a + 200), ta, pos_a + 200, ta, pos_a, -300, 0x1 | 0x2 | 0x80 | 0x10, 60, pid, M(100))
+    sp = {k: (np.concatenate(v) if v else np.zeros(0, dtype=(np.int64 if k != "sa" else "U48"))) for k, v in cols.items()}
+    n_special = len(sp["tid"])
+    # proper pairs: both mates inside this rank's range
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 1000 + rank)
+    P = max(0, (n_per_rank - n_special) // 2)
+    tlens = torch.tensor(lens, dtype=torch.int64, device=device)
+    tprefix = torch.tensor(prefix, dtype=torch.int64, device=device)
+    gs = lo + (torch.rand(P, generator=g, device=device, dtype=torch.float64) * max(1, hi - lo - 1)).to(torch.int64)
+    tid = torch.searchsorted(tprefix, gs, right=True) - 1
+    pos = gs - tprefix[tid]
+    ins = torch.clamp(torch.round(torch.randn(P, generator=g, device=device) * ins_sd + ins_mean).to(torch.int64), min=read_len + 1)
+    ub = torch.minimum(tlens[tid], hi - tprefix[tid]) - ins - 1   # keep the mate on the contig and inside the range
+    lb = torch.clamp(lo - tprefix[tid], min=0)
+    pos = torch.maximum(torch.minimum(pos, ub), lb)
+    mpos = pos + ins - read_len
+    pid = torch.arange(P, device=device, dtype=torch.int64) + (rank << 34)
+    return _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len)
+
+
+def _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len):
+    """Shared tail of the generators: concatenate proper pairs (device) with the special records (numpy), sort by
+    coordinate, build cigar/aux columns."""
+    n_special = len(sp["tid"])
+
+    def cat(a, b, special, dt):
+        return torch.cat([a.to(dt), b.to(dt), torch.from_numpy(np.ascontiguousarray(special)).to(device).to(dt)])
+
+    c_tid = cat(tid, tid, sp["tid"], torch.int32)
+    c_pos = cat(pos, mpos, sp["pos"], torch.int32)
+    c_mtid = cat(tid, tid, sp["mtid"], torch.int32)
+    c_mpos = cat(mpos, pos, sp["mpos"], torch.int32)
+    c_isize = cat(ins, -ins, sp["isize"], torch.int32)
+    f1 = torch.full((P,), 0x63, device=device, dtype=torch.int32)
+    f2 = torch.full((P,), 0x93, device=device, dtype=torch.int32)
+    c_flag = cat(f1, f2, sp["flag"].astype(np.int32), torch.int32)
+    m = torch.full((P,), 60, device=device, dtype=torch.uint8)
+    c_mapq = cat(m, m, sp["mapq"].astype(np.uint8), torch.uint8)
+    salt = ((seed & 0x7FFF) << 48) ^ 0x1E3779B97F4A7C15
+    c_qh = _mix64(cat(pid, pid, sp["pairid"].astype(np.int64), torch.int64) ^ salt)
+    w150 = torch.full((P,), (read_len << 4), device=device, dtype=torch.int64)
+    c_c0 = cat(w150, w150, sp["c0"].astype(np.int64), torch.int64)
+    zeros = torch.zeros(P, device=device, dtype=torch.int64)
+    c_c1 = cat(zeros, zeros, sp["c1"].astype(np.int64), torch.int64)
+    n = c_tid.numel()
+    key = (c_tid.to(torch.int64) << 32) | c_pos.to(torch.int64)
+    perm = torch.sort(key, stable=True)[1]
+    del key
+    take = lambda t: t[perm].contiguous()
+    out = {"tid": take(c_tid), "pos": take(c_pos), "mtid": take(c_mtid), "mpos": take(c_mpos), "isize": take(c_isize)}
+    out["flag"] = take(c_flag).to(torch.int16)
+    out["mapq"] = take(c_mapq)
+    out["qhash"] = take(c_qh)
+    c0 = take(c_c0)
+    c1 = take(c_c1)
+    ncig = 1 + (c1 != 0).to(torch.int64)
+    coff = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(ncig, 0, out=coff[1:])
+    nwords = int(coff[-1].item()) if n else 0
+    cigar = torch.zeros(max(nwords, 1), dtype=torch.int64, device=device)
+    if n:
+        cigar[coff[:-1]] = c0
+        two = (c1 != 0).nonzero().squeeze(1)
+        cigar[coff[two] + 1] = c1[two]
+    out["cigar_off"] = coff.to(torch.int32)
+    out["cigar"] = cigar.to(torch.int32)
+    sa = sp["sa"]
+    has = np.nonzero(sa != "")[0] if n_special else np.zeros(0, np.int64)
+    aux_len_special = np.zeros(n_special, np.int64)
+    sab = np.char.encode(sa[has], "ascii") if len(has) else np.zeros(0, "S1")
+    lens_sa = np.char.str_len(sab).astype(np.int64) if len(has) else np.zeros(0, np.int64)
+    aux_len_special[has] = lens_sa
+    aux_len = torch.cat([torch.zeros(2 * P, dtype=torch.int64, device=device), torch.from_numpy(aux_len_special).to(device)])[perm]
+    aoff = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(aux_len, 0, out=aoff[1:])
+    nbytes = int(aoff[-1].item()) if n else 0
+    src_np = (perm[(aux_len > 0).nonzero().squeeze(1)] - 2 * P).cpu().numpy()
+    if len(has):
+        rank_in_has = np.searchsorted(has, src_np)
+        width = int(lens_sa.max())
+        mat = np.frombuffer(sab.astype("S%d" % width).tobytes(), dtype=np.uint8).reshape(len(has), width)[rank_in_has]
+        blob = mat[np.arange(width)[None, :] < lens_sa[rank_in_has][:, None]]
+    else:
+        blob = np.zeros(0, np.uint8)
+    assert len(blob) == nbytes
+    out["aux_off"] = aoff.to(torch.int32)
+    out["aux"] = torch.from_numpy(np.ascontiguousarray(blob) if nbytes else np.zeros(1, np.uint8)).to(device)
+    out["n"] = n
+    out["n_cigar_words"] = nwords
+    out["n_aux_bytes"] = nbytes
+    return list(contigs), out

@@ -149,6 +149,41 @@ int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const u
 int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const uint64_t **bytes, int *n);
 int bk_timing_enable(bk_ctx *ctx, int on);
 
+/* ---- one sample sharded over several GPUs -----------------------------------------------------
+ * One context per GPU holds a contiguous range of the sample's coordinate-sorted records.  The library does the
+ * per-shard work; the caller moves the small tables between the contexts (RCCL all-gather / all-reduce over xGMI
+ * from torch.distributed in breakid_amd/sharded.py).  Sequence:
+ *   bk_upload_records; bk_shard_begin                       stream pass, record indices are global (rec_base + i)
+ *   bk_shard_get_stats -> all-reduce -> bk_shard_set_stats  insert-size sums, spans
+ *   bk_shard_sd_local -> all-gather -> bk_shard_sd_finish   bit-exact sd: exceptions replayed in global record order
+ *   BK_BUF_CANDIDATES: bk_shard_buffer -> all-gather -> bk_shard_set_buffer; bk_discordant_pairs (replicated join)
+ *   bk_shard_group_sizes -> owner per group -> bk_shard_own_groups; bk_mask_and_cluster; bk_cluster_summary
+ *   BK_BUF_TUPLES, BK_BUF_CLUSTERS: gather as above
+ *   bk_shard_bp_cov -> all-reduce(sum) -> bk_shard_bp_vote -> bk_shard_bp_depth -> all-reduce(sum) -> bk_shard_bp_finish
+ * after which every context holds the complete cluster table (bk_fetch).  The whole sample must stay below 2^32 records. */
+typedef struct bk_shard_stats {
+  uint64_t isize_sum, isize_n;
+  double sumsq;
+  uint32_t vmax, max_span;
+  uint64_t n_cand, n_split;
+} bk_shard_stats;
+#define BK_BUF_CANDIDATES 0 /* 32-byte candidates of the discordant filter */
+#define BK_BUF_TUPLES 1     /* bk_split, unsorted */
+#define BK_BUF_CLUSTERS 2   /* bk_cluster of the groups this rank owns */
+int bk_shard_begin(bk_ctx *ctx, uint64_t rec_base, int mapq_min);
+int bk_shard_get_stats(bk_ctx *ctx, bk_shard_stats *out);
+int bk_shard_set_stats(bk_ctx *ctx, const bk_shard_stats *total);
+int bk_shard_sd_local(bk_ctx *ctx, uint64_t *l_total, void **ex_dev, uint64_t *n_ex); /* exceptions: 16 B {u64 l_before, f64 d}, device */
+int bk_shard_sd_finish(bk_ctx *ctx, const void *all_ex_dev, uint64_t n_all, uint64_t l_grand, double *mean, double *sd);
+int bk_shard_buffer(bk_ctx *ctx, int which, void **dev, uint64_t *count, uint32_t *elem_bytes);
+int bk_shard_set_buffer(bk_ctx *ctx, int which, const void *dev, uint64_t count); /* gathered table, device, caller keeps it alive */
+int bk_shard_group_sizes(bk_ctx *ctx, const uint64_t **starts, uint32_t *n_groups); /* n_groups+1 pair offsets, numeric key order */
+int bk_shard_own_groups(bk_ctx *ctx, const uint8_t *own, uint32_t n_groups);
+int bk_shard_bp_cov(bk_ctx *ctx, double w, void **cov_dev, uint64_t *n);   /* u32[2*n_clusters] partial coverage counts */
+int bk_shard_bp_vote(bk_ctx *ctx, double w, const void *cov_total_dev);
+int bk_shard_bp_depth(bk_ctx *ctx, void **depth_dev, uint64_t *n);         /* u32[2*n_clusters] partial depth counts */
+int bk_shard_bp_finish(bk_ctx *ctx, const void *depth_total_dev);
+
 /* Test hook: orders every group [group_off[g], group_off[g+1]) of `key` exactly as
  * std::sort(first, last, [](a, b){ return a.key < b.key; }) of libstdc++ does (the reference's unstable sorts,
  * BreakID.cc:1274-1282,1091,1127) and returns the permutation (perm_out[p] = original index of the element now at p). */

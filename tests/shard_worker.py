@@ -1,0 +1,72 @@
+"""Worker of the 2-rank sharded-sample test: run under torch.distributed.run (gloo), every rank on cuda:0.
+Rank 0 rebuilds the whole sample from the deterministic shard generator and checks the sharded result against
+the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from breakid_amd import abi, capi, sharded, synth_gpu  # noqa: E402
+
+
+def concat_shards(hosts):
+    full = {k: np.concatenate([h[k] for h in hosts]) for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "qhash")}
+    cb = ab = 0
+    co, ao = [], []
+    for h in hosts:
+        co.append(h["cigar_off"][:-1].astype(np.int64) + cb)
+        cb += int(h["cigar_off"][-1])
+        ao.append(h["aux_off"][:-1].astype(np.int64) + ab)
+        ab += int(h["aux_off"][-1])
+    full["cigar_off"] = np.concatenate(co + [np.array([cb])]).astype(np.uint32)
+    full["aux_off"] = np.concatenate(ao + [np.array([ab])]).astype(np.uint32)
+    full["cigar"] = np.concatenate([h["cigar"] for h in hosts])
+    full["aux"] = np.concatenate([h["aux"] for h in hosts])
+    return full
+
+
+def main():
+    n_per_rank, seed, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs_shard(n_per_rank, seed, dev, rank, world)
+    comm = sharded.Comm(dev)
+    counts = comm.all_gather_scalars([cols["n"]])[:, 0].tolist()
+    rec_base = int(sum(counts[:rank]))
+    ctx = capi.Context(contigs, device=0)
+    ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    run = sharded.ShardedRun(ctx, comm)
+    w = run.run(rec_base, qual=20, fast=(mode == "fast"))
+    got, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+    ok = True
+    if rank == 0:
+        from oracle import pyoracle
+        hosts = [synth_gpu.to_numpy_cols(synth_gpu.make_wgs_shard(n_per_rank, seed, dev, r, world)[1]) for r in range(world)]
+        o = pyoracle.Oracle(contigs, concat_shards(hosts))
+        ow, rc = o.run(20, fast=(mode == "fast"))
+        exp, _ = o.fetch(abi.STAGE_CLUSTERS)
+        ok = rc == 0 and w == ow and np.array_equal(got, exp)
+        print("SHARD_CHECK", "OK" if ok else "MISMATCH", "w", w, ow, "clusters", len(got), len(exp), "valid", int(((got["flags"] & 2) != 0).sum()), flush=True)
+        if not ok and len(got) == len(exp):
+            bad = [i for i in range(len(got)) if got[i] != exp[i]][:5]
+            print(got[bad], exp[bad], flush=True)
+    # every rank must hold the same final table
+    import zlib
+    h = torch.tensor([zlib.crc32(got.tobytes())], dtype=torch.int64)
+    hs = [torch.zeros_like(h) for _ in range(world)]
+    dist.all_gather(hs, h)
+    same = all(int(x) == int(hs[0]) for x in hs)
+    if rank == 0:
+        print("SHARD_REPLICAS", "OK" if same else "DIFFER", flush=True)
+    ctx.close()
+    dist.destroy_process_group()
+    sys.exit(0 if (ok and same) else 1)
+
+
+if __name__ == "__main__":
+    main()

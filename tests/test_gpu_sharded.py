@@ -1,0 +1,43 @@
+"""One sample sharded over ranks (breakid_amd/sharded.py): world-size-1 path against the plain pipeline, and a
+real 2-rank run (gloo, both ranks on cuda:0) against the CPU oracle on the concatenated sample."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from breakid_amd import abi, capi, sharded, synth_gpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_world1_sharded_equals_plain_run():
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs(1_500_000, 4242, dev)
+    ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+    a = capi.Context(contigs)
+    a.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w, _ = a.run(qual=20, fast=True)
+    b = capi.Context(contigs)
+    b.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w2 = sharded.ShardedRun(b, sharded.Comm(dev)).run(0, qual=20, fast=True)
+    assert w == w2
+    for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_SPLITS, abi.STAGE_CLUSTERS):
+        x, xo = a.fetch(st)
+        y, yo = b.fetch(st)
+        assert np.array_equal(x, y), st
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "ahc"])
+def test_two_rank_sharded_sample_matches_oracle(mode):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611" if mode == "fast" else "29612")
+    n = "600000" if mode == "fast" else "150000"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "shard_worker.py"), n, "77", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
