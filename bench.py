@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000_000, help="records in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--mode", default="fast", choices=["fast", "ahc"])
     ap.add_argument("--seed", type=int, default=12346)
+    ap.add_argument("--sharded", type=int, default=-1, help="1: one sample sharded over the ranks (default when --gpus > 1), 0: plain single-table run")
     args = ap.parse_args()
 
     import numpy as np
@@ -46,17 +47,25 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_shards = args.sharded == 1 or (args.sharded < 0 and world > 1)
+    if world > 1 or use_shards:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # size the table to the card (configs[1] needs ~60 GB including generator temporaries)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     n_rec = args.records
+    if use_shards:
+        n_rec = min(n_rec, (0xFFFF0000 // max(world, 1)) // 1_000_000 * 1_000_000, 500_000_000)  # the whole sample stays below 2^32 records
     while n_rec * 110 > free_b and n_rec > 1_000_000:
         n_rec //= 2
     t0 = time.time()
-    contigs, cols = synth_gpu.make_wgs(n_rec, args.seed + rank, dev)
+    if use_shards:
+        from breakid_amd import sharded
+        contigs, cols = synth_gpu.make_wgs_shard(n_rec, args.seed, dev, rank, world)
+    else:
+        contigs, cols = synth_gpu.make_wgs(n_rec, args.seed + rank, dev)
     torch.cuda.synchronize(dev)
     gen_s = time.time() - t0
     n = cols["n"]
@@ -65,10 +74,21 @@ def main():
     ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
     ctx.attach_device(ptrs, n, cols["n_cigar_words"], cols["n_aux_bytes"])
     fast = args.mode == "fast"
+    n_total = n * world
+    if use_shards:
+        comm = sharded.Comm(dev)
+        counts = comm.all_gather_scalars([n])[:, 0].tolist()
+        rec_base, n_total = int(sum(counts[:rank])), int(sum(counts))
+        runner = sharded.ShardedRun(ctx, comm)
 
     def step():
         # bk_upload_records(BK_MEM_DEVICE) is zero copy; re-attaching invalidates every cached stage result
         ctx.attach_device(ptrs, n, cols["n_cigar_words"], cols["n_aux_bytes"])
+        if use_shards:
+            w = runner.run(rec_base, qual=20, fast=fast)
+            cl, _ = ctx.fetch(abi.STAGE_CLUSTERS) if rank == 0 else (None, None)
+            nv = int(((cl["flags"] & 2) != 0).sum()) if cl is not None else 0
+            return w, nv
         w, nv = ctx.run(qual=20, fast=fast)
         return w, nv
 
@@ -113,7 +133,7 @@ def main():
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass
-        value = (n * world * args.steps) / dt / 1e6
+        value = (n_total * args.steps) / dt / 1e6
         out = {
             "metric": "M reads/s clustered+split-scanned", "value": round(value, 3), "unit": "M records/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -122,14 +142,15 @@ def main():
             "config": {"workload": "configs[1]: 30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" % args.mode,
                        "records_per_gpu": int(n), "bytes_per_record_algorithmic": round(ks[1] / max(1, ks[2]) / n, 2),
                        "valid_clusters": int(n_valid), "w": w, "generator_s": round(gen_s, 2),
-                       "sharding": "independent tables per rank (weak)" if world > 1 else "single GPU"},
+                       "sharding": ("one sample of %d records, contiguous record range per rank; RCCL all-gather of candidates/tuples/cluster "
+                                    "summaries, all-reduce of coverage/depth counts; chr-pair groups owned by LPT" % n_total) if use_shards else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_stream", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "avg_launch_ms": round(ks[0] / max(1, ks[2]), 4), "algorithmic_bytes_per_launch": int(ks[1] / max(1, ks[2]))},
             "stage_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in per.items()},
         }
         # CPU baseline: the oracle port on a bounded sample of the same workload (rank 0, N = 1 only)
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and not use_shards and args.cpu_sample > 0:
             from oracle import pyoracle
             ns = min(args.cpu_sample, n)
             c2, scols = synth_gpu.make_wgs(ns, args.seed + 1000, dev)
@@ -152,7 +173,7 @@ def main():
             o.close()
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
