@@ -177,12 +177,12 @@ template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint3
   return false;
 }
 
-// executed by one full wavefront (64 lanes, all active)
-template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
+// the routines below are executed by one full wavefront (64 lanes, all active)
+// make_heap, bottom level first (nodes of one depth own disjoint subtrees)
+template <class M> __device__ void make_heap_wave(const M &mem, const uint32_t m)
 {
   if (m < 2) return;
   const uint32_t lane = threadIdx.x & 63;
-  // make_heap, bottom level first
   const uint32_t lastp = (m - 2) / 2;
   for (int d = 31 - __clz(lastp + 1); d >= 0; --d)
   {
@@ -203,14 +203,20 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
       mem.step_sync();
     }
   }
-  // sort_heap: pop t detaches leaf L = m - t, stores the maximum there and sifts the leaf's old value from the root
+}
+
+// sort_heap with a slower memory (global): pops follow each other two steps apart (lag-2 pipeline) until the heap
+// has shrunk to `stop` elements; every pop has finished when this returns.
+template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m, const uint32_t stop)
+{
+  if (m < 2 || m <= stop) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t_end = m - (stop < 1 ? 1 : stop) + 1;  // pops t = 1 .. t_end-1 detach leaves m-1 .. stop
   bool active = false;
   uint32_t hole = 0, len = 0;
   hent v = 0;
   uint32_t next_t = 1;
   int since = 2;
-  // every pop needs at most ~depth steps and a new one starts every other step unless stalled; the bound only
-  // guards against a non-terminating wave (it cannot be reached by a correct run)
   const unsigned long long max_iter = 64ull * m + 4096ull;
   for (unsigned long long iter = 0; iter < max_iter; ++iter)
   {
@@ -218,7 +224,7 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
     mem.step_sync();
     ++since;
     bool launched = false;
-    if (next_t < m)
+    if (next_t < t_end)
     {
       const uint32_t L = m - next_t;
       const bool blocks = active && anc_or_self(hole, L);
@@ -238,8 +244,9 @@ template <class M> __device__ void heapsort_wave(const M &mem, const uint32_t m)
         launched = true;
       }
     }
-    if (!launched && next_t >= m && __ballot(active) == 0ull) break;
+    if (!launched && next_t >= t_end && __ballot(active) == 0ull) break;
   }
+  mem.step_sync();
 }
 
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
@@ -263,15 +270,25 @@ template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const Hea
   __syncthreads();
   if (CLS == 2)
   {
-    GlbMem mem{buf};
+    // too large for LDS: heapify and pop in global memory until the heap fits, then finish in LDS
+    GlbMem gmem{buf};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    heapsort_wave(mem, m);
+    make_heap_wave(gmem, m);
+    sort_heap_lag2(gmem, m, HEAP_LARGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) dyn[i] = buf[i];
+    __syncthreads();
+    LdsMem lmem{dyn};
+    sort_heap_lag2(lmem, HEAP_LARGE, 1);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) buf[i] = dyn[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   else
   {
     LdsMem mem{buf};
-    heapsort_wave(mem, m);
+    make_heap_wave(mem, m);
+    sort_heap_lag2(mem, m, 1);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += 64)
@@ -493,7 +510,16 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         }
         hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh), dim3(64), HEAP_LARGE * 8, st, hl, nh, key, idx, hscratch);
       }
-      if (e[1] > HEAP_LARGE) hipLaunchKernelGGL(k_se_heapsort<2>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch);
+      if (e[1] > HEAP_LARGE)
+      {
+        static bool attr2_set = false;
+        if (!attr2_set)
+        {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_LARGE * 8));
+          attr2_set = true;
+        }
+        hipLaunchKernelGGL(k_se_heapsort<2>, dim3(nh), dim3(64), HEAP_LARGE * 8, st, hl, nh, key, idx, hscratch);
+      }
     }
     if (getenv("BK_DEBUG_SORT"))
     fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
