@@ -255,3 +255,78 @@ def make_cfg(seed: int, contigs: Sequence[Tuple[str, int]], n_records: int, n_lo
         ds.recs += _proper_pair(rng, i, t, 1000, lens[t] - 1000, read_len, ins_mean, ins_sd)
     ds.sort()
     return ds
+
+
+def make_edge(seed: int = 4321) -> Dataset:
+    """Edge cases of the mate join (H3) and of the per-read evidence (A12/A13): three records per read name,
+    a mate below the mapq threshold, mate coordinates that disagree, OC tags, hard clips, =/X ops, SA text with
+    several entries / leading zeros / empty fields, left-clipped primaries, 0x800 partners, duplicates."""
+    rng = np.random.default_rng(seed)
+    names = ["chr%d" % i for i in range(1, 5)]
+    ds = Dataset([(n, 400_000) for n in names])
+    for i in range(3000):
+        ds.recs += _proper_pair(rng, i, int(rng.integers(0, 4)), 1000, 399_000, 100, 330, 35)
+    # three loci with well formed discordant pairs
+    loci = [(0, 100_000, 1, 200_000), (0, 250_000, 2, 120_000), (1, 60_000, 1, 300_000)]
+    for li, (ta, pa, tb, pb) in enumerate(loci):
+        for k in range(14):
+            ja, jb = pa + int(rng.integers(-200, 200)), pb + int(rng.integers(-200, 200))
+            ds.recs += _discordant_pair("e%d_%d" % (li, k), ta, ja, tb, jb, 100, bool(k & 1), bool(k & 2))
+    # --- join quirks ---
+    # (1) third record with the same name (supplementary 0x800 is not filtered): buffered again, pairs with a fourth
+    a, b = _discordant_pair("trip", 0, 100_050, 1, 200_050, 100)
+    sup = Rec("trip", 0x1 | 0x40 | 0x800, 2, 50_000, 60, "50S50M", 1, 200_050, 0)
+    late = Rec("trip", 0x1 | 0x80, 3, 70_000, 60, "100M", 2, 50_000, 0)
+    ds.recs += [a, b, sup, late]
+    # (2) mate fails mapq: never pairs; (3) mate's mpos differs from the mate's pos; (4) same chr, closer than w
+    a, b = _discordant_pair("lowq", 0, 100_060, 1, 200_060, 100)
+    b.mapq = 3
+    ds.recs += [a, b]
+    a, b = _discordant_pair("skew", 0, 100_070, 1, 200_070, 100)
+    b.mpos = 150_000
+    a.mpos = 210_000
+    ds.recs += [a, b]
+    a, b = _discordant_pair("near", 2, 30_000, 2, 30_400, 100)
+    ds.recs += [a, b]
+    a, b = _discordant_pair("dupl", 0, 100_080, 1, 200_080, 100)
+    a.flag |= 0x400
+    ds.recs += [a, b]
+    # --- split-read variants at locus 0 (chr1:100000 / chr2:200000) ---
+    def sp(q, cig1, cig2, sa1_extra="", oc1="", oc2="", flag2=0x100, pos_a=99_950, pos_b=199_999, sa1=None, sa2=None, dup=False):
+        s1 = sa1 if sa1 is not None else "chr2,%d,+,%s,60,0;%s" % (pos_b + 1, cig2, sa1_extra)
+        s2 = sa2 if sa2 is not None else "chr1,%d,+,%s,60,0;" % (pos_a + 1, cig1)
+        prim = Rec(q, 0x1 | 0x2 | 0x40 | 0x20 | (0x400 if dup else 0), 0, pos_a, 60, cig1, 0, pos_a + 150, 250, sa=s1, oc=oc1)
+        part = Rec(q, 0x1 | 0x40 | 0x20 | flag2, 1, pos_b, 60, cig2, 0, pos_a + 150, 0, sa=s2, oc=oc2)
+        mate = Rec(q, 0x1 | 0x2 | 0x80 | 0x10, 0, pos_a + 150, 60, "100M", 0, pos_a, -250)
+        return [prim, part, mate]
+    for i in range(4):
+        ds.recs += sp("ok%d" % i, "60M40S", "60S40M")
+    ds.recs += sp("multi", "60M40S", "60S40M", sa1_extra="chr3,500,-,30M70S,20,1;")
+    ds.recs += sp("left", "40S60M", "40M60S", pos_a=100_010, pos_b=199_950)
+    ds.recs += sp("left2", "40S60M", "40M60S", pos_a=100_010, pos_b=199_950)
+    ds.recs += sp("eqx", "30=30X40S", "60S40M")
+    ds.recs += sp("hard", "60M40H", "60H40M")
+    ds.recs += sp("ocp", "55M45S", "60S40M", oc1="60M40S")               # OC replaces the BAM cigar of the primary
+    ds.recs += sp("ocs", "60M40S", "58S42M", oc2="60S40M")               # ... and of the 0x100 partner
+    ds.recs += sp("ocmerge", "50M50S", "60S40M", oc1="30M30M40S")
+    ds.recs += sp("zeros", "60M40S", "60S40M", sa1="chr2,200000,+,060S040M,60,0;")
+    # (an SA text with fewer than 4 comma fields makes the reference index past the end of a vector: undefined, not pinned)
+    ds.recs += sp("empt", "60M40S", "60S40M", sa1="chr2,,200000,+,,60S40M,60,0;")
+    ds.recs += sp("supp", "60M40S", "60S40M", flag2=0x800)
+    ds.recs += sp("dupp", "60M40S", "60S40M", dup=True)
+    ds.recs += sp("three", "50M10I40S", "60S40M")
+    ds.recs += sp("nocomp", "90M10S", "60S40M")
+    ds.recs += sp("ins", "60M40S", "60S10I30M")
+    ds.recs += sp("unk", "60M40S", "60S40M", sa1="chrUn_x,77,+,60S40M,60,0;", sa2="chr1,99951,+,60M40S,60,0;")
+    ds.sort()
+    return ds
+
+
+def make_poison() -> Dataset:
+    """A complementary pair whose SA cigar rolls to a single clip-free op (50M50M -> 100M): the reference prints
+    "error cigar" and exits with -1 (BreakID.cc:954-968) once the read is inside a queried region."""
+    ds = make_edge()
+    bad = Rec("bad", 0x1 | 0x2 | 0x40 | 0x20, 0, 99_960, 60, "5M95S", 0, 100_100, 250, sa="chr2,200001,+,50M50M,60,0;")
+    ds.recs.append(bad)
+    ds.sort()
+    return ds

@@ -1187,6 +1187,30 @@ int ora_unit_std_sort(const uint32_t *key, const uint64_t *group_off, uint32_t n
   return 0;
 }
 
+// find_sa_reads on one region (BreakID.cc:868-1037): tuples after the region verdict, as bk_split rows
+int ora_unit_region(ora *o, int tid, uint32_t start, uint32_t end, bk_split *out, uint32_t cap)
+{
+  std::vector<VoteIn> v;
+  bool poison = false;
+  sa_region(*o, tid, start, end, v, poison);
+  uint32_t n = 0;
+  for (auto &t : v)
+  {
+    if (n >= cap) break;
+    bk_split s;
+    memset(&s, 0, sizeof s);
+    s.qhash = t.qhash;
+    s.flags = t.secondary;
+    s.prim_chr = t.prim_chr; s.sec_chr = t.sec_chr;
+    s.prim_start = t.prim_start; s.prim_end = t.prim_end; s.prim_bp = t.prim_bp;
+    s.sec_start = t.sec_start; s.sec_end = t.sec_end; s.sec_bp = t.sec_bp;
+    s.prim_cigar = t.prim_cigar; s.sec_cigar = t.sec_cigar;
+    out[n++] = s;
+  }
+  return (int) v.size();
+}
+uint32_t ora_unit_depth(ora *o, int tid, uint64_t pos) { return base_depth(*o, tid, pos); }
+
 uint64_t ora_text_hash(const char *s, size_t len) { return text_hash(s, len); }
 int ora_name_id(ora *o, const char *name) { return o->intern(name); }
 

@@ -45,6 +45,9 @@ def lib():
                                       C.c_void_p, C.POINTER(C.c_int)]
         L.ora_unit_vote.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.ora_unit_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.ora_unit_region.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.ora_unit_depth.restype = C.c_uint32
+        L.ora_unit_depth.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.ora_text_hash.restype = C.c_uint64
         L.ora_text_hash.argtypes = [C.c_char_p, C.c_size_t]
         L.ora_name_id.argtypes = [C.c_void_p, C.c_char_p]
@@ -111,6 +114,14 @@ class Oracle:
 
     def fetch(self, stage):
         return abi.fetch_array(self.L, self.h, self.L.ora_fetch, stage)
+
+    def region(self, tid, start, end, cap=4096):
+        out = np.zeros(cap, abi.SPLIT)
+        n = self.L.ora_unit_region(self.h, tid, start, end, out.ctypes.data, cap)
+        return out[:min(n, cap)].copy()
+
+    def depth(self, tid, pos):
+        return int(self.L.ora_unit_depth(self.h, tid, pos))
 
     def name_id(self, name):
         return self.L.ora_name_id(self.h, name.encode())

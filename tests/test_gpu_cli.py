@@ -23,7 +23,7 @@ def _dataset(name):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["g1", "g2", "small", "ties"])
+@pytest.mark.parametrize("name", ["g1", "g2", "small", "ties", "edge"])
 @pytest.mark.parametrize("mode", ["fast", "ahc"])
 def test_cli_txt_outputs_match_reference(golden_dir, name, mode):
     ds, refgene = _dataset(name)

@@ -11,7 +11,7 @@ from tests import refdump
 
 pytestmark = pytest.mark.gpu
 
-DATASETS = ["g1", "g2", "small", "ties"]
+DATASETS = ["g1", "g2", "small", "ties", "edge"]
 
 
 def _run_gpu(contigs, cols, fast, qual=20):
@@ -217,3 +217,24 @@ def test_ahc_units_vs_oracle(case):
     ei, ec = _expected_ahc_list(x, y, T)
     assert np.array_equal(gi, ei) and np.array_equal(gc, ec), (case, len(gi), len(ei))
     ctx.close()
+
+
+def test_error_cigar_is_reported_like_the_reference(golden_dir):
+    contigs, cols = refdump.load_soa(golden_dir, "poison")
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.run(qual=20, fast=True)
+    assert e.value.code == abi.BK_ERR_CIGAR and "error cigar" in str(e.value)
+    ctx.close()
+
+
+@pytest.mark.parametrize("qual", [0, 5, 61])
+def test_other_mapq_thresholds(golden_dir, qual):
+    contigs, cols = refdump.load_soa(golden_dir, "edge")
+    ctx, mean, sd, w = _run_gpu(contigs, cols, fast=True, qual=qual)
+    o = pyoracle.Oracle(contigs, cols)
+    o.run(qual, fast=True)
+    _compare_stages(ctx, o)
+    ctx.close()
+    o.close()

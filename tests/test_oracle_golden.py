@@ -10,7 +10,7 @@ from breakid_amd import abi
 from oracle import pyoracle
 from tests import refdump
 
-DATASETS = ["g1", "g2", "small", "ties"]
+DATASETS = ["g1", "g2", "small", "ties", "edge"]
 
 
 @pytest.mark.parametrize("name", DATASETS)
@@ -99,3 +99,44 @@ def test_units_vote(golden_dir):
     for case in u:
         got = pyoracle.unit_vote(_tuples(case["s1"], ids), _tuples(case["s2"], ids), ids[case["p1_chr"]])
         assert list(got) == [int(v) for v in case["ref"].split()], (case, got)
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_region_queries_match_reference(golden_dir, name):
+    """find_sa_reads / cal_single_base_depth on raw regions (htslib overlap predicate, region verdict, H6)."""
+    contigs, cols = refdump.load_soa(golden_dir, name)
+    names = [n for n, _ in contigs]
+    o = pyoracle.Oracle(contigs, cols)
+    L = pyoracle.lib()
+    regions = json.load(open(os.path.join(golden_dir, name + ".regions.json")))
+    assert regions
+    n_nonempty = 0
+    for r in regions:
+        tid = names.index(r["chr"])
+        got = o.region(tid, r["start"], r["end"])
+        lines = r["sa"].strip().split("\n")
+        assert lines[0] == "tuples %d" % len(got), (r["chr"], r["start"], r["end"], lines[0], len(got))
+        exp = []
+        for ln in lines[1:]:
+            f = ln.split()
+            exp.append((int(f[2]), o.name_id(f[3]), int(f[4]), int(f[5]), L.ora_text_hash(f[6].encode(), len(f[6])), int(f[7]),
+                        o.name_id(f[8]), int(f[9]), int(f[10]), L.ora_text_hash(f[11].encode(), len(f[11])), int(f[12])))
+        mine = [(int(t["flags"] & 1), int(t["prim_chr"]), int(t["prim_start"]), int(t["prim_end"]), int(t["prim_cigar"]), int(t["prim_bp"]),
+                 int(t["sec_chr"]), int(t["sec_start"]), int(t["sec_end"]), int(t["sec_cigar"]), int(t["sec_bp"])) for t in got]
+        assert sorted(exp) == sorted(mine)
+        n_nonempty += bool(exp)
+        assert float.fromhex(r["depth_at_start"]) == float(o.depth(tid, max(1, r["start"])))
+    if name in ("g1", "small", "ties"):
+        assert n_nonempty > 0
+    o.close()
+
+
+def test_error_cigar_exit_matches_reference(golden_dir):
+    """the reference exits with -1 ("error cigar") on a clip-free complementary pair inside a queried region"""
+    exp = json.load(open(os.path.join(golden_dir, "poison.json")))
+    assert exp["returncode"] == 255 and "error cigar" in exp["stderr_tail"]
+    contigs, cols = refdump.load_soa(golden_dir, "poison")
+    o = pyoracle.Oracle(contigs, cols)
+    w, rc = o.run(20, fast=True)
+    assert rc == abi.BK_ERR_CIGAR
+    o.close()

@@ -34,9 +34,16 @@ def datasets():
     yield "g2", synth.make_g1(partner_flag=0x800), synth.G1_REFGENE
     yield "small", synth.make_cfg(101, small, 24_000, 40, 24, 150, jitter=300, read_len=100), SMALL_REFGENE
     # heavy x/y key ties (H2): tiny jitter, panel-like
+    yield "edge", synth.make_edge(), EDGE_REFGENE
     yield "ties", synth.make_cfg(202, small[:2], 12_000, 12, 60, 40, jitter=6, read_len=100, split_every=1,
                                  splits_per_locus=5), SMALL_REFGENE
 
+
+EDGE_REFGENE = [
+    "0\tNM_200001\tchr1\t+\t50000\t350000\t50500\t349000\t3\t50000,99000,200000,\t90000,150000,350000,\t0\tEA\tcmpl\tcmpl\t0,0,0,",
+    "0\tNM_200002\tchr2\t-\t100000\t390000\t100500\t389000\t2\t100000,199000,\t190000,390000,\t0\tEB\tcmpl\tcmpl\t0,0,",
+    "0\tNM_200003\tchr3\t+\t10000\t200000\t10500\t199000\t1\t10000,\t200000,\t0\tEC\tcmpl\tcmpl\t0,",
+]
 
 SMALL_REFGENE = [
     "0\tNM_100001\tchr1\t+\t100000\t2900000\t100500\t2899000\t3\t100000,1000000,2000000,\t500000,1500000,2900000,\t0\tGA\tcmpl\tcmpl\t0,0,0,",
@@ -206,10 +213,28 @@ def unit_vectors():
         json.dump(out, f, indent=0)
 
 
+def make_poison_golden():
+    ds = synth.make_poison()
+    with tempfile.TemporaryDirectory() as tmp:
+        bam = os.path.join(tmp, "poison.bam")
+        ds.write_bam(bam)
+        side = synth.write_side_files(ds, tmp, refgene_lines=EDGE_REFGENE)
+        run([os.path.join(REF, "ref_index"), bam])
+        env = dict(os.environ, BREAKID_REF_INSTALLDIR=side["install"])
+        r = subprocess.run([os.path.join(REF, "BreakID_ref"), "-i", bam, "-o", os.path.join(tmp, "o"), "-n", side["nib"], "-fast"],
+                           env=env, capture_output=True, text=True)
+        soa = ds.to_soa()
+        np.savez_compressed(os.path.join(GOLD, "poison.soa.npz"), names=np.array([n for n, _ in ds.contigs]), **soa)
+        with open(os.path.join(GOLD, "poison.json"), "w") as f:
+            json.dump({"returncode": r.returncode, "stderr_tail": r.stderr[-200:]}, f)
+        print("golden: poison exit", r.returncode, repr(r.stderr[-60:]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     unit_vectors()
+    make_poison_golden()
     for name, ds, refgene in datasets():
         make_dataset_golden(name, ds, refgene)
         print("golden:", name, len(ds.recs), "records")
