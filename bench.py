@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000_000, help="records in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--mode", default="fast", choices=["fast", "ahc"])
     ap.add_argument("--seed", type=int, default=12346)
+    ap.add_argument("--workload", default="wgs", choices=["wgs", "panel"],
+                    help="wgs = configs[1] (the headline line); panel = configs[3] targeted-panel shape (500 loci x 2000x, single GPU, side measurement)")
     ap.add_argument("--sharded", type=int, default=-1, help="1: one sample sharded over the ranks (default when --gpus > 1), 0: plain single-table run")
     args = ap.parse_args()
 
@@ -64,6 +66,8 @@ def main():
     if use_shards:
         from breakid_amd import sharded
         contigs, cols = synth_gpu.make_wgs_shard(n_rec, args.seed, dev, rank, world)
+    elif args.workload == "panel":
+        contigs, cols = synth_gpu.make_panel(args.seed + rank, dev)
     else:
         contigs, cols = synth_gpu.make_wgs(n_rec, args.seed + rank, dev)
     torch.cuda.synchronize(dev)
@@ -139,7 +143,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u8 (+f64 sd replay)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" % args.mode,
+            "config": {"workload": ("configs[1]: 30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" if args.workload == "wgs" else
+                                    "configs[3]: targeted-panel shape, 500 fusion loci x 2000x, 20%% split reads, 10%% discordant, -%s clustering") % args.mode,
                        "records_per_gpu": int(n), "bytes_per_record_algorithmic": round(ks[1] / max(1, ks[2]) / n, 2),
                        "valid_clusters": int(n_valid), "w": w, "generator_s": round(gen_s, 2),
                        "sharding": ("one sample of %d records, contiguous record range per rank; RCCL all-gather of candidates/tuples/cluster "
@@ -153,7 +158,10 @@ def main():
         if world == 1 and not use_shards and args.cpu_sample > 0:
             from oracle import pyoracle
             ns = min(args.cpu_sample, n)
-            c2, scols = synth_gpu.make_wgs(ns, args.seed + 1000, dev)
+            if args.workload == "panel":
+                c2, scols = synth_gpu.make_panel(args.seed + 1000, dev)
+            else:
+                c2, scols = synth_gpu.make_wgs(ns, args.seed + 1000, dev)
             host = synth_gpu.to_numpy_cols(scols)
             t1 = time.perf_counter()
             o = pyoracle.Oracle(c2, host)

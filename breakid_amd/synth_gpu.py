@@ -428,3 +428,97 @@ def _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len):
     out["n_cigar_words"] = nwords
     out["n_aux_bytes"] = nbytes
     return list(contigs), out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Targeted-panel shape (BASELINE.json configs[3]): all reads pile up over `n_loci` fusion loci at `depth`x, a large
+# share of them split reads (primary + supplementary partner with SA tags) whose clip points scatter +-2 bp around
+# the breakpoint (exercises the A15 vote), plus discordant pairs bridging the two sides of every fusion.
+def make_panel(seed: int, device, n_loci=500, depth=2000, window=600, split_frac=0.2, disc_frac=0.1, contigs=HG19,
+               read_len=150, ins_mean=350.0, ins_sd=40.0):
+    rng = np.random.default_rng(seed)
+    lens = np.asarray([l for _, l in contigs], dtype=np.int64)
+    names = np.asarray([n for n, _ in contigs])
+    nt = len(contigs)
+    per_locus = depth * window // read_len            # records piled on each side of a locus
+    n_split = int(per_locus * split_frac) // 3        # triplets
+    n_disc = int(per_locus * disc_frac) // 2          # pairs
+    n_proper = max(0, (per_locus - 3 * n_split - 2 * n_disc) // 2)
+    cols = {k: [] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "pairid", "c0", "c1", "sa")}
+
+    def add(tid, pos, mtid, mpos, isize, flag, mapq, pairid, c0, c1=None, sa=None):
+        n = len(tid)
+        b = lambda a: np.full(n, a) if np.isscalar(a) else np.asarray(a)
+        cols["tid"].append(b(tid).astype(np.int32)); cols["pos"].append(b(pos).astype(np.int32))
+        cols["mtid"].append(b(mtid).astype(np.int32)); cols["mpos"].append(b(mpos).astype(np.int32))
+        cols["isize"].append(b(isize).astype(np.int32)); cols["flag"].append(b(flag).astype(np.uint16))
+        cols["mapq"].append(b(mapq).astype(np.uint8)); cols["pairid"].append(b(pairid).astype(np.int64))
+        cols["c0"].append(b(c0).astype(np.uint32))
+        cols["c1"].append(np.zeros(n, np.uint32) if c1 is None else b(c1).astype(np.uint32))
+        cols["sa"].append(np.full(n, "", dtype="U48") if sa is None else np.asarray(sa).astype("U48"))
+
+    def sites(k, margin=20000):
+        t = rng.integers(0, nt, k)
+        p = (rng.random(k) * (lens[t] - 2 * margin)).astype(np.int64) + margin
+        return t, p
+
+    la_t, la_p = sites(n_loci)
+    lb_t, lb_p = sites(n_loci)
+    same = rng.random(n_loci) < 0.3
+    lb_t = np.where(same, la_t, lb_t)
+    lb_p = np.where(same, (la_p + 50000 + (rng.random(n_loci) * 1e6).astype(np.int64)) % (lens[lb_t] - 40000) + 20000, lb_p)
+    rev_a = rng.integers(0, 2, n_loci).astype(bool)
+    rev_b = rng.integers(0, 2, n_loci).astype(bool)
+    # discordant pairs bridging A and B
+    if n_disc:
+        li = np.repeat(np.arange(n_loci), n_disc)
+        k = len(li)
+        ta, tb = la_t[li], lb_t[li]
+        pa = la_p[li] - rng.integers(read_len, window // 2 + read_len, k)
+        pb = lb_p[li] + rng.integers(0, window // 2, k)
+        ra, rb = rev_a[li], rev_b[li]
+        mq = np.where(rng.random(k) < 0.03, rng.integers(0, 30, k), 60)
+        pid = np.arange(k, dtype=np.int64) + (1 << 40)
+        fa = 0x1 | 0x40 | np.where(ra, 0x10, 0) | np.where(rb, 0x20, 0) | np.where(rng.random(k) < 0.02, 0x400, 0)
+        fb = 0x1 | 0x80 | np.where(rb, 0x10, 0) | np.where(ra, 0x20, 0)
+        isz = np.where(ta == tb, pb - pa + read_len, 0)
+        add(ta, pa, tb, pb, isz, fa, mq, pid, (read_len << 4))
+        add(tb, pb, ta, pa, -isz, fb, mq, pid, (read_len << 4))
+    # split triplets: primary clipped at A, supplementary at B, mate upstream of A
+    if n_split:
+        li = np.repeat(np.arange(n_loci), n_split)
+        k = len(li)
+        ta, tb = la_t[li], lb_t[li]
+        m1 = rng.integers(35, read_len - 35, k)
+        m2 = read_len - m1
+        wob = rng.choice(np.asarray([0, 0, 0, 0, 0, 1, -1, 2, -2, 3]), k)
+        bpa = la_p[li] + wob
+        bpb = lb_p[li] + rng.choice(np.asarray([0, 0, 0, 0, 1, -1, 2]), k)
+        pos_a, pos_b = bpa - m1, bpb
+        mate = pos_a - rng.integers(60, 250, k)
+        pid = np.arange(k, dtype=np.int64) + (3 << 40)
+        cig = lambda a, ca, b, cb: np.char.add(np.char.add(a.astype("U4"), ca), np.char.add(b.astype("U4"), cb))
+        c1t, c2t = cig(m1, "M", m2, "S"), cig(m1, "S", m2, "M")
+        mqs = np.where(rng.random(k) < 0.05, rng.integers(0, 25, k), 60)
+        head = lambda nm, p: np.char.add(np.char.add(nm, ","), np.char.add((p + 1).astype("U12"), ",+,"))
+        sa1 = np.char.add(np.char.add(head(names[tb], pos_b), c2t), np.char.add(np.char.add(",", mqs.astype("U3")), ",0;"))
+        sa2 = np.char.add(np.char.add(head(names[ta], pos_a), c1t), ",60,0;")
+        add(ta, pos_a, ta, mate, -(pos_a + m1 - mate), 0x1 | 0x2 | 0x80 | 0x10, 60, pid, (m1 << 4), (m2 << 4) | 4, sa1)
+        part = np.where(rng.random(k) < 0.85, 0x100, 0x800)   # bwa mem -M marks the partner 0x100; 0x800 never votes
+        add(tb, pos_b, ta, mate, 0, 0x1 | 0x80 | 0x10 | part, mqs, pid, (m1 << 4) | 4, (m2 << 4), sa2)
+        add(ta, mate, ta, pos_a, pos_a + m1 - mate, 0x1 | 0x2 | 0x40 | 0x20, 60, pid, (read_len << 4))
+    sp = {k: (np.concatenate(v) if v else np.zeros(0, dtype=(np.int64 if k != "sa" else "U48"))) for k, v in cols.items()}
+    # proper pairs piled over both sides of each locus
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    P = 2 * n_loci * n_proper
+    side_t = torch.from_numpy(np.concatenate([la_t, lb_t])).to(device)
+    side_p = torch.from_numpy(np.concatenate([la_p, lb_p])).to(device)
+    si = torch.arange(P, device=device, dtype=torch.int64) // max(n_proper, 1)
+    tid = side_t[si] if P else torch.zeros(0, dtype=torch.int64, device=device)
+    ins = torch.clamp(torch.round(torch.randn(P, generator=g, device=device) * ins_sd + ins_mean).to(torch.int64), min=read_len + 1)
+    off = (torch.rand(P, generator=g, device=device) * (window + 400)).to(torch.int64) - (window + 400) // 2 - 175
+    pos = (side_p[si] + off) if P else torch.zeros(0, dtype=torch.int64, device=device)
+    mpos = pos + ins - read_len
+    pid = torch.arange(P, device=device, dtype=torch.int64)
+    return _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len)

@@ -118,6 +118,30 @@ def test_wgs_shape_device_resident_vs_oracle():
     o.close()
 
 
+@pytest.mark.parametrize("fast", [True, False])
+def test_panel_shape_vs_oracle(fast):
+    """BASELINE.json configs[3] at test size: reads piled over fusion loci, ~20 % split reads whose clip points
+    scatter around the breakpoint (the A15 vote), discordant pairs bridging both sides, supplementary (0x800)
+    partners that enter the mate join without a mate."""
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_panel(77, dev, n_loci=40, depth=600, window=600)
+    host = synth_gpu.to_numpy_cols(cols)
+    ctx = capi.Context(contigs)
+    ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w, n_valid = ctx.run(qual=20, fast=fast)
+    o = pyoracle.Oracle(contigs, host)
+    ow, rc = o.run(20, fast=fast)
+    assert rc == 0 and w == ow
+    _compare_stages(ctx, o)
+    assert n_valid > 0
+    splits, _ = ctx.fetch(abi.STAGE_SPLITS)
+    assert len(splits) > 1000
+    ctx.close()
+    o.close()
+
+
 def _triangular(rng, n):
     """x ~ U[0, y] with y increasing: the discovery-order shape of same-chromosome pairs that drives
     median-of-3 introsort into its depth limit (heapsort branch) on large segments."""
