@@ -177,6 +177,9 @@ template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint3
   return false;
 }
 
+constexpr uint32_t HEAP_PAD = 32;
+__device__ unsigned long long g_heap_iters[2];  // debug: loop iterations / pops of sort_heap (BK_DEBUG_SORT)
+
 // the routines below are executed by one full wavefront (64 lanes, all active)
 // make_heap, bottom level first (nodes of one depth own disjoint subtrees)
 template <class M> __device__ void make_heap_wave(const M &mem, const uint32_t m)
@@ -205,59 +208,111 @@ template <class M> __device__ void make_heap_wave(const M &mem, const uint32_t m
   }
 }
 
-// sort_heap with a slower memory (global): pops follow each other two steps apart (lag-2 pipeline) until the heap
-// has shrunk to `stop` elements; every pop has finished when this returns.
-template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m, const uint32_t stop)
+// sort_heap: pops follow each other two steps apart (lag-2 pipeline) until the heap has shrunk to `stop` elements;
+// every pop has finished when this returns.  One loop iteration = one sift step of every pop in flight (one lane
+// each) + at most one launch.  The wave is alone on its critical path, so the loop is written branch-free: the
+// values a launch needs (the root and the leaf about to be detached) are fetched together with the children of
+// the holes, idle lanes run the same instructions with len = 0.
+template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m, const uint32_t stop)
 {
   if (m < 2 || m <= stop) return;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t t_end = m - (stop < 1 ? 1 : stop) + 1;  // pops t = 1 .. t_end-1 detach leaves m-1 .. stop
-  bool active = false;
-  uint32_t hole = 0, len = 0;
-  hent v = 0;
-  uint32_t next_t = 1;
-  int since = 2;
-  const unsigned long long max_iter = 64ull * m + 4096ull;
-  for (unsigned long long iter = 0; iter < max_iter; ++iter)
+  if (V == 1)
   {
-    if (active) active = sift_step(mem, hole, len, v);
+    bool active = false;
+    uint32_t hole = 0, len = 0;
+    hent v = 0;
+    uint32_t next_t = 1;
+    int since = 2;
+    const unsigned long long max_iter = 64ull * m + 4096ull;
+    for (unsigned long long iter = 0; iter < max_iter; ++iter)
+    {
+      if (active) active = sift_step(mem, hole, len, v);
+      mem.step_sync();
+      ++since;
+      bool launched = false;
+      if (next_t < t_end)
+      {
+        const uint32_t L = m - next_t;
+        const bool blocks = active && anc_or_self(hole, L);
+        if (since >= 2 && __ballot(blocks) == 0ull)
+        {
+          if (lane == (next_t & 63u))
+          {
+            v = mem.ld(L);
+            mem.st(L, mem.ld(0));
+            hole = 0;
+            len = L;
+            active = true;
+          }
+          mem.launch_sync();
+          since = 0;
+          ++next_t;
+          launched = true;
+        }
+      }
+      if (!launched && next_t >= t_end && __ballot(active) == 0ull) break;
+    }
+    mem.step_sync();
+    return;
+  }
+  uint32_t hole = 0, len = 0;  // len == 0 <=> idle lane
+  uint32_t vk = 0, vx = 0;     // key / index halves of the value being sifted
+  uint32_t next_t = 1, since = 2;
+  uint32_t budget = m > 0x03000000u ? 0xFFFFFFFFu : 64u * m + 4096u;
+  while (true)
+  {
+    const bool more = next_t < t_end;
+    const uint32_t L = m - next_t;  // leaf the next launch detaches (still a valid slot when !more)
+    const hent pre_root = mem.ld(0);
+    const hent pre_leaf = mem.ld(L);
+    const uint32_t left = 2 * hole + 1;
+    const bool has_l = left < len;
+    const uint32_t a = has_l ? left : 0;
+    const hent el = mem.ld(a), er = mem.ld(a + 1);
+    const uint32_t kl = hkey(el), kr = hkey(er);
+    const bool pr = (left + 1 < len) & (kr >= kl);
+    const uint32_t kc = pr ? kr : kl, xc = pr ? (uint32_t) er : (uint32_t) el;
+    const bool desc = has_l & (kc >= vk);
+    const bool was_active = len != 0;
+    const bool wrote_leaf = was_active & (hole == L);  // pre_leaf is stale then
+    if (was_active) mem.st(hole, ((hent) (desc ? kc : vk) << 32) | (desc ? xc : vx));
+    hole = desc ? left + (pr ? 1u : 0u) : hole;
+    len = desc ? len : 0;
     mem.step_sync();
     ++since;
-    bool launched = false;
-    if (next_t < t_end)
-    {
-      const uint32_t L = m - next_t;
-      const bool blocks = active && anc_or_self(hole, L);
-      if (since >= 2 && __ballot(blocks) == 0ull)
-      {
-        if (lane == (next_t & 63u))
-        {
-          v = mem.ld(L);
-          mem.st(L, mem.ld(0));
-          hole = 0;
-          len = L;
-          active = true;
-        }
-        mem.launch_sync();
-        since = 0;
-        ++next_t;
-        launched = true;
-      }
-    }
-    if (!launched && next_t >= t_end && __ballot(active) == 0ull) break;
+    const bool blocks = wrote_leaf | ((len != 0) & anc_or_self(hole, L));
+    const bool go = more & (since >= 2) & (__ballot(blocks) == 0ull);
+    const bool idle = __ballot(len != 0) == 0ull;
+    const bool mine = go & (lane == (next_t & 63u));
+    if (mine) mem.st(L, pre_root);
+    vk = mine ? hkey(pre_leaf) : vk;
+    vx = mine ? (uint32_t) pre_leaf : vx;
+    hole = mine ? 0u : hole;
+    len = mine ? L : len;
+    since = go ? 0u : since;
+    next_t += go ? 1u : 0u;
+    --budget;
+    if ((!more & idle) | (budget == 0)) break;
   }
   mem.step_sync();
+  if (lane == 0)
+  {
+    atomicAdd(&g_heap_iters[0], (unsigned long long) ((m > 0x03000000u ? 0xFFFFFFFFu : 64u * m + 4096u) - budget));
+    atomicAdd(&g_heap_iters[1], (unsigned long long) (t_end - 1));
+  }
 }
 
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
-template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                                        hent *__restrict__ scratch)
 {
   extern __shared__ __attribute__((aligned(16))) hent dyn[];
-  __shared__ hent stat[CLS == 0 ? HEAP_SMALL : 1];
+  __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
   const uint32_t s = blockIdx.x;
   if (s >= nh) return;
   const HeapSeg sg = hs[s];
@@ -274,12 +329,12 @@ template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const Hea
     GlbMem gmem{buf};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     make_heap_wave(gmem, m);
-    sort_heap_lag2(gmem, m, HEAP_LARGE);
+    sort_heap_lag2<V>(gmem, m, HEAP_LARGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) dyn[i] = buf[i];
     __syncthreads();
     LdsMem lmem{dyn};
-    sort_heap_lag2(lmem, HEAP_LARGE, 1);
+    sort_heap_lag2<V>(lmem, HEAP_LARGE, 1);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) buf[i] = dyn[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -288,7 +343,7 @@ template <int CLS> __global__ __launch_bounds__(64) void k_se_heapsort(const Hea
   {
     LdsMem mem{buf};
     make_heap_wave(mem, m);
-    sort_heap_lag2(mem, m, 1);
+    sort_heap_lag2<V>(mem, m, 1);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += 64)
@@ -498,31 +553,69 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     if (nh)
     {
       const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
-      hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + 1);
-      hipLaunchKernelGGL(k_se_heapsort<0>, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch);
-      if (e[1] > HEAP_SMALL)
+      hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
+      static const int sift_k = getenv("BK_SIFT_K") ? atoi(getenv("BK_SIFT_K")) : 2;
+      static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
+      hipEvent_t ev0 = nullptr, ev1 = nullptr;
+      if (dbg)
       {
-        static bool attr_set = false;
-        if (!attr_set)
-        {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_LARGE * 8));
-          attr_set = true;
-        }
-        hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh), dim3(64), HEAP_LARGE * 8, st, hl, nh, key, idx, hscratch);
+        HIP_CHECK(hipEventCreate(&ev0));
+        HIP_CHECK(hipEventCreate(&ev1));
+        HIP_CHECK(hipEventRecord(ev0, st));
       }
-      if (e[1] > HEAP_LARGE)
+      const size_t dyn = (HEAP_LARGE + HEAP_PAD) * 8;
+      if (!b.fork)
       {
-        static bool attr2_set = false;
-        if (!attr2_set)
+        HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i)
         {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_LARGE * 8));
-          attr2_set = true;
+          HIP_CHECK(hipStreamCreateWithFlags(&b.aux[i], hipStreamNonBlocking));
+          HIP_CHECK(hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming));
         }
-        hipLaunchKernelGGL(k_se_heapsort<2>, dim3(nh), dim3(64), HEAP_LARGE * 8, st, hl, nh, key, idx, hscratch);
+      }
+      auto launch = [&](auto k0, auto k1, auto k2) {
+        // largest class first: its longest segment is the critical path of the whole sort
+        HIP_CHECK(hipEventRecord(b.fork, st));
+        int used = 0;
+        if (e[1] > HEAP_LARGE)
+        {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+          HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
+          hipLaunchKernelGGL(k2, dim3(nh), dim3(64), dyn, b.aux[used], hl, nh, key, idx, hscratch);
+          HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
+          ++used;
+        }
+        if (e[1] > HEAP_SMALL)
+        {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+          HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
+          hipLaunchKernelGGL(k1, dim3(nh), dim3(64), dyn, b.aux[used], hl, nh, key, idx, hscratch);
+          HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
+          ++used;
+        }
+        hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch);
+        for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
+      };
+      switch (sift_k)
+      {
+      case 2: launch(k_se_heapsort<0, 2>, k_se_heapsort<1, 2>, k_se_heapsort<2, 2>); break;
+      default: launch(k_se_heapsort<0, 1>, k_se_heapsort<1, 1>, k_se_heapsort<2, 1>); break;
+      }
+      if (dbg)
+      {
+        float ms = 0;
+        HIP_CHECK(hipEventRecord(ev1, st));
+        HIP_CHECK(hipEventSynchronize(ev1));
+        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        unsigned long long it[2] = {0, 0}, zero[2] = {0, 0};
+        HIP_CHECK(hipMemcpyFromSymbol(it, HIP_SYMBOL(g_heap_iters), 16));
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_iters), zero, 16));
+        fprintf(stderr, "[sortemu] heapsort kernels %.3f ms (%.3f us per element of the largest segment); %llu iterations for %llu pops\n", ms, ms * 1e3 / e[1], it[0], it[1]);
+        (void) hipEventDestroy(ev0);
+        (void) hipEventDestroy(ev1);
       }
     }
-    if (getenv("BK_DEBUG_SORT"))
-    fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
+    if (getenv("BK_DEBUG_SORT")) fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
   }
   // __final_insertion_sort == stable sort by key of what the introsort loop left
   uint64_t *ck = b.ck.as<uint64_t>(n);
