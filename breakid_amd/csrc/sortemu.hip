@@ -257,16 +257,22 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
     mem.step_sync();
     return;
   }
-  uint32_t hole = 0, len = 0;  // len == 0 <=> idle lane
-  uint32_t vk = 0, vx = 0;     // key / index halves of the value being sifted
+  uint32_t hole = 0, len = 0, lvl = 0;  // len == 0 <=> idle lane; lvl = depth of the hole
+  uint32_t vk = 0, vx = 0;              // key / index halves of the value being sifted
   uint32_t next_t = 1, since = 2;
   uint32_t budget = m > 0x03000000u ? 0xFFFFFFFFu : 64u * m + 4096u;
+  uint32_t L = m - 1;                   // leaf the next launch detaches
+  int dL = 31 - __clz((int) (L + 1));   // its depth
+  bool more = next_t < t_end;
   while (true)
   {
-    const bool more = next_t < t_end;
-    const uint32_t L = m - next_t;  // leaf the next launch detaches (still a valid slot when !more)
-    const hent pre_root = mem.ld(0);
-    const hent pre_leaf = mem.ld(L);
+    const bool may_launch = more & (since >= 1);  // uniform
+    hent pre_root = 0, pre_leaf = 0;
+    if (may_launch)
+    {
+      pre_root = mem.ld(0);
+      pre_leaf = mem.ld(L);
+    }
     const uint32_t left = 2 * hole + 1;
     const bool has_l = left < len;
     const uint32_t a = has_l ? left : 0;
@@ -275,31 +281,168 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
     const bool pr = (left + 1 < len) & (kr >= kl);
     const uint32_t kc = pr ? kr : kl, xc = pr ? (uint32_t) er : (uint32_t) el;
     const bool desc = has_l & (kc >= vk);
+    const uint32_t hole0 = hole;
+    if (len != 0) mem.st(hole, ((hent) (desc ? kc : vk) << 32) | (desc ? xc : vx));
     const bool was_active = len != 0;
-    const bool wrote_leaf = was_active & (hole == L);  // pre_leaf is stale then
-    if (was_active) mem.st(hole, ((hent) (desc ? kc : vk) << 32) | (desc ? xc : vx));
     hole = desc ? left + (pr ? 1u : 0u) : hole;
+    lvl += desc ? 1u : 0u;
     len = desc ? len : 0;
     mem.step_sync();
     ++since;
-    const bool blocks = wrote_leaf | ((len != 0) & anc_or_self(hole, L));
-    const bool go = more & (since >= 2) & (__ballot(blocks) == 0ull);
-    const bool idle = __ballot(len != 0) == 0ull;
-    const bool mine = go & (lane == (next_t & 63u));
-    if (mine) mem.st(L, pre_root);
-    vk = mine ? hkey(pre_leaf) : vk;
-    vx = mine ? (uint32_t) pre_leaf : vx;
-    hole = mine ? 0u : hole;
-    len = mine ? L : len;
-    since = go ? 0u : since;
-    next_t += go ? 1u : 0u;
-    --budget;
-    if ((!more & idle) | (budget == 0)) break;
+    if (may_launch & (since >= 2))
+    {
+      // a pop in flight that can still reach L (its hole is L or an ancestor of L), or that wrote L in this step
+      // (pre_leaf is stale then), holds the launch back
+      const bool anc = ((int) lvl <= dL) & (((L + 1) >> (dL - (int) lvl)) == hole + 1);
+      const bool blocks = (was_active & (hole0 == L)) | ((len != 0) & anc);
+      if (__ballot(blocks) == 0ull)
+      {
+        if (lane == (next_t & 63u))
+        {
+          mem.st(L, pre_root);
+          vk = hkey(pre_leaf);
+          vx = (uint32_t) pre_leaf;
+          hole = 0;
+          lvl = 0;
+          len = L;
+        }
+        since = 0;
+        ++next_t;
+        more = next_t < t_end;
+        L = m - next_t;
+        dL = 31 - __clz((int) (L + 1));
+      }
+    }
+    else if (!more)
+    {
+      if (__ballot(len != 0) == 0ull) break;
+    }
+    if (--budget == 0) break;
   }
   mem.step_sync();
   if (lane == 0)
   {
     atomicAdd(&g_heap_iters[0], (unsigned long long) ((m > 0x03000000u ? 0xFFFFFFFFu : 64u * m + 4096u) - budget));
+    atomicAdd(&g_heap_iters[1], (unsigned long long) (t_end - 1));
+  }
+}
+
+// The same pop pipeline as sort_heap_lag2, written in GCN assembly.  A lone wavefront issues at most one instruction
+// every 4 cycles, so the segment's critical path is the instruction count of one loop iteration; the compiler's
+// version spends ~80 instructions per iteration on mask bookkeeping, this one ~25 (+~25 in an iteration that
+// launches).  Per-lane state: h1 = hole + 1 (v40), len (v41; 0 = idle lane), value (idx v42, key v43).
+// Uniform state: next_t (s41), since (s42), L+1 (s43), clz(L+1) (s44), budget (s45), t_end (s46).
+// GLB = false: heap in LDS at byte offset `base`; GLB = true: heap in global memory at `gptr` (base = 0).
+#define BK_HEAP_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, ST_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL)                                      \
+  "v_mov_b32 v62, %[lane]\n"                                                                                               \
+  "s_mov_b32 s62, %[plo]\n s_mov_b32 s63, %[phi]\n"                                                                          \
+  "s_sub_u32 s40, %[base], 8\n"                                                                                            \
+  "v_mov_b32 v60, %[base]\n"                                                                                               \
+  "s_mov_b32 s46, %[tend]\n s_mov_b32 s41, 1\n s_mov_b32 s42, 2\n s_mov_b32 s43, %[m]\n"                                      \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "s_lshl_b32 s47, s43, 3\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
+  "s_mov_b32 s45, %[budget]\n"                                                                                             \
+  "v_mov_b32 v40, 1\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
+  "BK_LOOP_%=:\n"                                                                                                         \
+  WAIT_ALL LD1_ROOT LD1_LEAF                                                                                              \
+  "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
+  "v_cmp_le_u32_e64 s[48:49], v44, v41\n"                                                                                  \
+  "v_cmp_lt_u32_e64 s[50:51], v44, v41\n"                                                                                  \
+  "v_lshl_add_u32 v45, v44, 3, s40\n"                                                                                      \
+  "v_cndmask_b32_e64 v45, v60, v45, s[48:49]\n"                                                                            \
+  LD2_KIDS                                                                                                                \
+  "v_lshl_add_u32 v52, v40, 3, s40\n"                                                                                      \
+  "v_cmp_ne_u32_e64 s[58:59], 0, v41\n"                                                                                    \
+  "v_mov_b32 v54, v40\n"                                                                                                   \
+  WAIT_LOADS                                                                                                              \
+  "v_cmp_ge_u32_e32 vcc, v49, v47\n"                                                                                       \
+  "s_and_b64 s[52:53], vcc, s[50:51]\n"                                                                                    \
+  "v_cndmask_b32_e64 v51, v47, v49, s[52:53]\n"                                                                            \
+  "v_cndmask_b32_e64 v50, v46, v48, s[52:53]\n"                                                                            \
+  "v_cmp_ge_u32_e32 vcc, v51, v43\n"                                                                                       \
+  "s_and_b64 s[54:55], vcc, s[48:49]\n"                                                                                    \
+  "v_cndmask_b32_e64 v51, v43, v51, s[54:55]\n"                                                                            \
+  "v_cndmask_b32_e64 v50, v42, v50, s[54:55]\n"                                                                            \
+  "s_and_saveexec_b64 s[56:57], s[58:59]\n"                                                                                \
+  ST_HOLE                                                                                                                 \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "v_addc_co_u32_e64 v53, vcc, v44, 0, s[52:53]\n"                                                                         \
+  "v_cndmask_b32_e64 v40, v40, v53, s[54:55]\n"                                                                            \
+  "v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"                                                                              \
+  "s_add_u32 s42, s42, 1\n"                                                                                                \
+  "s_cmp_ge_u32 s41, s46\n"                                                                                                \
+  "s_cbranch_scc1 BK_NOMORE_%=\n"                                                                                          \
+  "s_cmp_lt_u32 s42, 2\n"                                                                                                  \
+  "s_cbranch_scc1 BK_NEXT_%=\n"                                                                                            \
+  "v_ffbh_u32_e32 v63, v40\n"                                                                                              \
+  "v_subrev_u32_e32 v63, s44, v63\n"                                                                                       \
+  "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
+  "v_cmp_eq_u32_e32 vcc, v64, v40\n"                                                                                       \
+  "v_cmp_gt_u32_e64 s[60:61], 32, v63\n"                                                                                   \
+  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
+  "v_cmp_ne_u32_e64 s[60:61], 0, v41\n"                                                                                    \
+  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
+  "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
+  "s_and_b64 s[60:61], s[60:61], s[58:59]\n"                                                                               \
+  "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
+  "s_cbranch_vccnz BK_NEXT_%=\n"                                                                                           \
+  "s_and_b32 s47, s41, 63\n"                                                                                               \
+  "v_cmp_eq_u32_e32 vcc, s47, v62\n"                                                                                       \
+  "s_sub_u32 s47, s43, 1\n"                                                                                                \
+  "s_and_saveexec_b64 s[56:57], vcc\n"                                                                                     \
+  ST_LEAF                                                                                                                 \
+  "v_mov_b32 v42, v58\n v_mov_b32 v43, v59\n v_mov_b32 v40, 1\n v_mov_b32 v41, s47\n"                                         \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "s_add_u32 s41, s41, 1\n"                                                                                                \
+  "s_mov_b32 s43, s47\n"                                                                                                   \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "v_add_u32_e32 v61, -8, v61\n"                                                                                           \
+  "s_mov_b32 s42, 0\n"                                                                                                     \
+  "s_branch BK_NEXT_%=\n"                                                                                                  \
+  "BK_NOMORE_%=:\n"                                                                                                       \
+  "v_cmp_ne_u32_e32 vcc, 0, v41\n"                                                                                         \
+  "s_cbranch_vccz BK_DONE_%=\n"                                                                                            \
+  "BK_NEXT_%=:\n"                                                                                                         \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cmp_lg_u32 s45, 0\n"                                                                                                  \
+  "s_cbranch_scc1 BK_LOOP_%=\n"                                                                                            \
+  "BK_DONE_%=:\n"                                                                                                         \
+  WAIT_ALL                                                                                                                \
+  "s_mov_b32 %[left], s45\n"
+
+#define BK_HEAP_CLOBBERS                                                                                                     \
+  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v56", "v57", "v58", \
+      "v59", "v60", "v61", "v62", "v63", "v64", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",    \
+      "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory"
+
+template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, const uint32_t m, const uint32_t stop)
+{
+  if (m < 2 || m <= stop) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t_end = __builtin_amdgcn_readfirstlane(m - (stop < 1 ? 1 : stop) + 1);
+  const uint32_t budget = __builtin_amdgcn_readfirstlane(m > 0x03000000u ? 0xFFFFFFFFu : 64u * m + 4096u);
+  const uint32_t mm = __builtin_amdgcn_readfirstlane(m);
+  const unsigned long long p = (unsigned long long) buf;
+  const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t) p), phi = __builtin_amdgcn_readfirstlane((uint32_t) (p >> 32));
+  const uint32_t base = GLB ? 0u : plo;  // low half of a flat LDS address = byte offset inside LDS
+  uint32_t left;
+  if (GLB)
+    asm volatile(BK_HEAP_ASM("global_load_dwordx2 v[56:57], v60, s[62:63]\n", "global_load_dwordx2 v[58:59], v61, s[62:63]\n",
+                             "global_load_dwordx4 v[46:49], v45, s[62:63]\n", "global_store_dwordx2 v52, v[50:51], s[62:63]\n",
+                             "global_store_dwordx2 v61, v[56:57], s[62:63]\n", "s_waitcnt vmcnt(0)\n", "s_waitcnt vmcnt(0)\n")
+                 : [left] "=s"(left)
+                 : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
+                 : BK_HEAP_CLOBBERS);
+  else
+    asm volatile(BK_HEAP_ASM("ds_read_b64 v[56:57], v60\n", "ds_read_b64 v[58:59], v61\n", "ds_read2_b64 v[46:49], v45 offset1:1\n",
+                             "ds_write_b64 v52, v[50:51]\n", "ds_write_b64 v61, v[56:57]\n", "s_waitcnt lgkmcnt(0)\n", "")
+                 : [left] "=s"(left)
+                 : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
+                 : BK_HEAP_CLOBBERS);
+  if (!GLB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0)
+  {
+    atomicAdd(&g_heap_iters[0], (unsigned long long) (budget - left));
     atomicAdd(&g_heap_iters[1], (unsigned long long) (t_end - 1));
   }
 }
@@ -329,12 +472,12 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
     GlbMem gmem{buf};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     make_heap_wave(gmem, m);
-    sort_heap_lag2<V>(gmem, m, HEAP_LARGE);
+    if (V == 3) sort_heap_asm<true>(buf, m, HEAP_LARGE); else sort_heap_lag2<V>(gmem, m, HEAP_LARGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) dyn[i] = buf[i];
     __syncthreads();
     LdsMem lmem{dyn};
-    sort_heap_lag2<V>(lmem, HEAP_LARGE, 1);
+    if (V == 3) sort_heap_asm<false>(dyn, HEAP_LARGE, 1); else sort_heap_lag2<V>(lmem, HEAP_LARGE, 1);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) buf[i] = dyn[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -343,7 +486,7 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
   {
     LdsMem mem{buf};
     make_heap_wave(mem, m);
-    sort_heap_lag2<V>(mem, m, 1);
+    if (V == 3) sort_heap_asm<false>(buf, m, 1); else sort_heap_lag2<V>(mem, m, 1);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += 64)
@@ -554,7 +697,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     {
       const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
       hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
-      static const int sift_k = getenv("BK_SIFT_K") ? atoi(getenv("BK_SIFT_K")) : 2;
+      static const int sift_k = getenv("BK_SIFT_K") ? atoi(getenv("BK_SIFT_K")) : 3;
       static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
       hipEvent_t ev0 = nullptr, ev1 = nullptr;
       if (dbg)
@@ -599,6 +742,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       switch (sift_k)
       {
       case 2: launch(k_se_heapsort<0, 2>, k_se_heapsort<1, 2>, k_se_heapsort<2, 2>); break;
+      case 3: launch(k_se_heapsort<0, 3>, k_se_heapsort<1, 3>, k_se_heapsort<2, 3>); break;
       default: launch(k_se_heapsort<0, 1>, k_se_heapsort<1, 1>, k_se_heapsort<2, 1>); break;
       }
       if (dbg)
