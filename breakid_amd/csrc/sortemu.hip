@@ -17,9 +17,16 @@
 #include "sortemu.h"
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 
 namespace
 {
+inline double now_ms()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 struct Seg
 {
   uint32_t first, last;
@@ -666,6 +673,13 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     uint32_t *posL = b.posL.as<uint32_t>((uint64_t) n + 2), *posR = b.posR.as<uint32_t>((uint64_t) n + 2);
     const unsigned nbk = cdiv(n, 256);
     int level = 0;
+    static const bool dbg_levels = getenv("BK_DEBUG_SORT") != nullptr;
+    double t_loop0 = 0;
+    if (dbg_levels)
+    {
+      HIP_CHECK(hipStreamSynchronize(st));
+      t_loop0 = now_ms();
+    }
     while (ns)
     {
       if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
@@ -683,6 +697,11 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (ns2) hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2);
       std::swap(segs, segs2);
       ns = ns2;
+      if (dbg_levels && (level % 4 == 0 || ns2 == 0))
+      {
+        HIP_CHECK(hipStreamSynchronize(st));
+        fprintf(stderr, "[sortemu]   level %d: %u segments -> %u, %.3f ms so far\n", level, ns, ns2, now_ms() - t_loop0);
+      }
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
