@@ -149,6 +149,11 @@ class Context:
         self._keep = (cols, soa)
         self._check(self.L.bk_upload_records(self.h, C.byref(soa), abi.BK_MEM_HOST))
 
+    def upload_soa(self, handle):
+        """handle: BamTable from decode_bam(keep=True); the decoder's (pinned) columns go straight to bk_upload_records."""
+        self._keep = handle
+        self._check(self.L.bk_upload_records(self.h, C.byref(handle.soa), abi.BK_MEM_HOST))
+
     def attach_device(self, ptrs, n, n_cigar_words, n_aux_bytes):
         """ptrs: dict name -> device pointer (int) of columns already resident in HBM."""
         s = abi.Soa()
@@ -233,8 +238,22 @@ class Context:
         return [(names[i].decode(), float(ms[i]), int(by[i])) for i in range(n.value)]
 
 
-def decode_bam(path):
-    """C++ BGZF/BAM decoder -> (contigs, SoA dict of numpy copies)."""
+class BamTable:
+    """Decoded record table still owned by the C++ reader (pinned host columns); close() releases it."""
+
+    def __init__(self, L, h, soa):
+        self.L, self.h, self.soa = L, h, soa
+        n = soa.n
+        self.nbytes = n * (4 * 5 + 2 + 1 + 8) + (n + 1) * 8 + soa.n_cigar_words * 4 + soa.n_aux_bytes
+
+    def close(self):
+        if self.h:
+            self.L.bk_bam_close(self.h)
+            self.h = None
+
+
+def decode_bam(path, keep=False):
+    """C++ BGZF/BAM decoder -> (contigs, SoA dict of numpy copies); keep=True also returns the live BamTable."""
     L = lib()
     h = C.c_void_p()
     err = C.create_string_buffer(512)
@@ -264,6 +283,11 @@ def decode_bam(path):
             cols[name] = np.frombuffer(buf, dtype=dt, count=cnt).copy()
         cols["cigar"] = cols["cigar"][: s.n_cigar_words]
         cols["aux"] = cols["aux"][: s.n_aux_bytes]
+        if keep:
+            t = BamTable(L, h, s)
+            h = None
+            return contigs, cols, t
         return contigs, cols
     finally:
-        L.bk_bam_close(h)
+        if h:
+            L.bk_bam_close(h)

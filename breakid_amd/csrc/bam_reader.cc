@@ -1,16 +1,106 @@
-// Host feed: BGZF/BAM decoder -> columnar record table (include/breakid_hip.h: bk_soa).
+// Host feed: BGZF/BAM decoder -> pinned columnar record table (include/breakid_hip.h: bk_soa).
 // Own implementation (zlib inflate only); replaces the htslib reader the reference uses for its two
 // sequential passes (BreakID.cc:1414 samread, :1929 sam_read1).  Record layout: SAM spec §4.2 /
 // htslib/sam.h:148-181; aux walk as sam.c:1267-1279 (bam_aux_get).
+//
+// BGZF blocks are independent deflate streams and BAM records are self-delimiting, so both stages run on all host
+// cores: (1) block headers are hopped sequentially (18 bytes each), the blocks are inflated in parallel into one
+// buffer; (2) record starts are hopped sequentially (4 bytes each) into checkpoints every CHUNK records, the
+// chunks are decoded in parallel straight into the fixed-width columns, CIGAR words / aux blobs go through
+// chunk-local buffers and are placed by a prefix sum.  Columns live in pinned host memory (hipHostMalloc) when a
+// GPU is present, so bk_upload_records(BK_MEM_HOST) runs at PCIe speed.  BREAKID_THREADS overrides the thread count.
+#include <hip/hip_runtime_api.h>
 #include <zlib.h>
 
+#include <atomic>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/breakid_hip.h"
+
+namespace
+{
+struct HostBuf
+{
+  void *p = nullptr;
+  bool pinned = false;
+  size_t bytes = 0;
+  HostBuf() = default;
+  HostBuf(const HostBuf &) = delete;
+  HostBuf &operator=(const HostBuf &) = delete;
+  ~HostBuf() { release(); }
+  void release()
+  {
+    if (!p) return;
+    if (pinned)
+      (void) hipHostFree(p);
+    else
+      free(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  // pinned when the HIP runtime has a device; plain memory otherwise (the decoder itself is host code)
+  bool alloc(size_t n, bool want_pinned)
+  {
+    release();
+    if (n == 0) n = 16;
+    if (want_pinned && hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess && p)
+    {
+      pinned = true;
+      bytes = n;
+      return true;
+    }
+    (void) hipGetLastError();
+    p = malloc(n);
+    pinned = false;
+    bytes = p ? n : 0;
+    return p != nullptr;
+  }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+unsigned n_threads()
+{
+  if (const char *e = getenv("BREAKID_THREADS"))
+  {
+    int v = atoi(e);
+    if (v > 0) return (unsigned) v;
+  }
+  unsigned h = std::thread::hardware_concurrency();
+  if (h == 0) h = 4;
+  return h > 64 ? 64 : h;
+}
+
+// dynamic scheduling over [0, njobs): fn(job) on up to nt threads
+template <class F> void parallel_for(size_t njobs, unsigned nt, F fn)
+{
+  if (njobs == 0) return;
+  if (nt > njobs) nt = (unsigned) njobs;
+  if (nt <= 1)
+  {
+    for (size_t j = 0; j < njobs; ++j) fn(j);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&]() {
+      for (;;)
+      {
+        size_t j = next.fetch_add(1);
+        if (j >= njobs) break;
+        fn(j);
+      }
+    });
+  for (auto &t : th) t.join();
+}
+}  // namespace
 
 struct bk_bam
 {
@@ -21,12 +111,8 @@ struct bk_bam
   std::vector<const char *> name_ptrs;
   std::vector<uint32_t> lens;
   // decoded columns
-  std::vector<int32_t> tid, pos, mtid, mpos, isize;
-  std::vector<uint16_t> flag;
-  std::vector<uint8_t> mapq;
-  std::vector<uint64_t> qhash;
-  std::vector<uint32_t> cigar_off, cigar, aux_off;
-  std::vector<uint8_t> aux;
+  HostBuf tid, pos, mtid, mpos, isize, flag, mapq, qhash, cigar_off, cigar, aux_off, aux;
+  double t_inflate_s = 0, t_decode_s = 0;
 };
 
 extern "C" uint64_t bk_qname_hash(const char *name, size_t len)
@@ -54,11 +140,17 @@ void set_err(char *err, size_t errlen, const std::string &m)
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24); }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t) (p[0] | (p[1] << 8)); }
 
+struct Block
+{
+  size_t in_off, clen, out_off;
+  uint32_t isize;
+};
+
 bool inflate_all(const std::vector<uint8_t> &file, std::vector<uint8_t> &out, std::string &why)
 {
-  size_t off = 0;
-  out.clear();
-  out.reserve(file.size() * 4);
+  // pass 1: hop over the block headers
+  std::vector<Block> blocks;
+  size_t off = 0, total = 0;
   while (off < file.size())
   {
     if (off + 18 > file.size())
@@ -73,47 +165,67 @@ bool inflate_all(const std::vector<uint8_t> &file, std::vector<uint8_t> &out, st
       return false;
     }
     uint16_t xlen = rd16(h + 10);
+    if (off + 12 + (size_t) xlen > file.size())
+    {
+      why = "truncated BGZF header";
+      return false;
+    }
     const uint8_t *x = h + 12;
     int bsize = -1;
     for (size_t k = 0; k + 4 <= xlen;)
     {
       uint16_t slen = rd16(x + k + 2);
-      if (x[k] == 66 && x[k + 1] == 67 && slen == 2) bsize = rd16(x + k + 4);
-      k += 4 + slen;
+      if (x[k] == 66 && x[k + 1] == 67 && slen == 2 && k + 6 <= xlen) bsize = rd16(x + k + 4);
+      k += 4 + (size_t) slen;
     }
-    if (bsize < 0 || off + (size_t) bsize + 1 > file.size())
+    if (bsize < 0 || off + (size_t) bsize + 1 > file.size() || (size_t) bsize + 1 < 12 + (size_t) xlen + 8)
     {
       why = "bad BGZF block size";
       return false;
     }
-    size_t cdata = 12 + xlen, clen = (size_t) bsize + 1 - cdata - 8;
-    uint32_t isize = rd32(h + bsize + 1 - 4);
-    size_t base = out.size();
-    out.resize(base + isize);
-    if (isize)
-    {
-      z_stream zs;
-      memset(&zs, 0, sizeof zs);
-      if (inflateInit2(&zs, -15) != Z_OK)
-      {
-        why = "inflateInit2 failed";
-        return false;
-      }
-      zs.next_in = const_cast<Bytef *>(h + cdata);
-      zs.avail_in = (uInt) clen;
-      zs.next_out = out.data() + base;
-      zs.avail_out = isize;
-      int rc = inflate(&zs, Z_FINISH);
-      inflateEnd(&zs);
-      if (rc != Z_STREAM_END)
-      {
-        why = "inflate failed";
-        return false;
-      }
-    }
+    Block b;
+    b.in_off = off + 12 + xlen;
+    b.clen = (size_t) bsize + 1 - (12 + (size_t) xlen) - 8;
+    b.isize = rd32(h + bsize + 1 - 4);
+    b.out_off = total;
+    total += b.isize;
+    blocks.push_back(b);
     off += (size_t) bsize + 1;
   }
+  out.assign(total, 0);
+  // pass 2: independent deflate streams
+  std::atomic<int> bad{0};
+  parallel_for(blocks.size(), n_threads(), [&](size_t j) {
+    const Block &b = blocks[j];
+    if (!b.isize) return;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK)
+    {
+      bad = 1;
+      return;
+    }
+    zs.next_in = const_cast<Bytef *>(file.data() + b.in_off);
+    zs.avail_in = (uInt) b.clen;
+    zs.next_out = out.data() + b.out_off;
+    zs.avail_out = b.isize;
+    int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) bad = 2;
+  });
+  if (bad)
+  {
+    why = bad == 1 ? "inflateInit2 failed" : "inflate failed";
+    return false;
+  }
   return true;
+}
+
+double now_s()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 }  // namespace
 
@@ -142,12 +254,15 @@ extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t err
   bk_bam *b = new bk_bam();
   b->path = path;
   std::string why;
+  const double t0 = now_s();
   if (!inflate_all(file, b->data, why))
   {
     set_err(err, errlen, why);
     delete b;
     return BK_ERR_IO;
   }
+  b->t_inflate_s = now_s() - t0;
+  std::vector<uint8_t>().swap(file);
   const std::vector<uint8_t> &d = b->data;
   if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0)
   {
@@ -157,7 +272,7 @@ extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t err
   }
   size_t p = 4;
   uint32_t l_text = rd32(d.data() + p);
-  p += 4 + l_text;
+  p += 4 + (size_t) l_text;
   if (p + 4 > d.size())
   {
     set_err(err, errlen, "truncated BAM header");
@@ -192,48 +307,66 @@ extern "C" int bk_bam_header(const bk_bam *b, int *n_targets, const char *const 
   return BK_OK;
 }
 
-extern "C" int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen)
+namespace
 {
-  if (!b || !out) return BK_ERR_ARG;
-  const std::vector<uint8_t> &d = b->data;
-  size_t p = b->rec_begin;
-  b->cigar_off.assign(1, 0);
-  b->aux_off.assign(1, 0);
-  while (p + 4 <= d.size())
+constexpr size_t CHUNK = 1 << 16;  // records per decode job
+
+struct ChunkOut
+{
+  std::vector<uint32_t> cigar;
+  std::vector<uint8_t> aux;
+  uint64_t cigar_base = 0, aux_base = 0;
+  int bad = 0;
+};
+
+struct Cols
+{
+  int32_t *tid, *pos, *mtid, *mpos, *isize;
+  uint16_t *flag;
+  uint8_t *mapq;
+  uint64_t *qhash;
+  uint32_t *cigar_off, *aux_off;  // chunk-local offsets first, rebased in the placement pass
+};
+
+// decode records [r0, r1) starting at byte offset p of the inflated stream
+void decode_chunk(const uint8_t *d, size_t dsize, size_t p, size_t r0, size_t r1, const Cols &c, ChunkOut &o)
+{
+  for (size_t i = r0; i < r1; ++i)
   {
-    uint32_t bs = rd32(d.data() + p);
+    uint32_t bs = rd32(d + p);
     p += 4;
-    if (bs < 32 || p + bs > d.size())
-    {
-      set_err(err, errlen, "truncated BAM record");
-      return BK_ERR_IO;
-    }
-    const uint8_t *r = d.data() + p;
-    int32_t tid = (int32_t) rd32(r), pos = (int32_t) rd32(r + 4);
-    uint8_t l_name = r[8], mq = r[9];
-    uint16_t n_cig = rd16(r + 12), fl = rd16(r + 14);
+    const uint8_t *r = d + p;
+    uint8_t l_name = r[8];
+    uint16_t n_cig = rd16(r + 12);
     uint32_t l_seq = rd32(r + 16);
-    int32_t mtid = (int32_t) rd32(r + 20), mpos = (int32_t) rd32(r + 24), isz = (int32_t) rd32(r + 28);
-    size_t o = 32;
-    size_t need = o + l_name + (size_t) n_cig * 4 + (l_seq + 1) / 2 + l_seq;
-    if (need > bs)
+    size_t q = 32;
+    size_t need = q + l_name + (size_t) n_cig * 4 + ((size_t) l_seq + 1) / 2 + l_seq;
+    if (need > bs || p + bs > dsize)
     {
-      set_err(err, errlen, "corrupt BAM record");
-      return BK_ERR_IO;
+      o.bad = 1;
+      return;
     }
-    size_t qn = l_name ? strnlen((const char *) r + o, l_name) : 0;  // bam_get_qname is a C string
-    b->qhash.push_back(bk_qname_hash((const char *) r + o, qn));
-    o += l_name;
-    for (uint16_t k = 0; k < n_cig; ++k) b->cigar.push_back(rd32(r + o + 4 * k));
-    o += (size_t) n_cig * 4 + (l_seq + 1) / 2 + l_seq;
+    c.tid[i] = (int32_t) rd32(r);
+    c.pos[i] = (int32_t) rd32(r + 4);
+    c.mapq[i] = r[9];
+    c.flag[i] = rd16(r + 14);
+    c.mtid[i] = (int32_t) rd32(r + 20);
+    c.mpos[i] = (int32_t) rd32(r + 24);
+    c.isize[i] = (int32_t) rd32(r + 28);
+    size_t qn = l_name ? strnlen((const char *) r + q, l_name) : 0;  // bam_get_qname is a C string
+    c.qhash[i] = bk_qname_hash((const char *) r + q, qn);
+    q += l_name;
+    c.cigar_off[i] = (uint32_t) o.cigar.size();
+    for (uint16_t k = 0; k < n_cig; ++k) o.cigar.push_back(rd32(r + q + 4 * (size_t) k));
+    q += (size_t) n_cig * 4 + ((size_t) l_seq + 1) / 2 + l_seq;
     // aux walk: first SA:Z and OC:Z (bam_aux_get returns the first match)
     const uint8_t *sa = nullptr, *oc = nullptr;
     size_t sa_len = 0, oc_len = 0;
-    while (o + 3 <= bs)
+    while (q + 3 <= bs)
     {
-      const uint8_t *tag = r + o;
-      uint8_t type = r[o + 2];
-      o += 3;
+      const uint8_t *tag = r + q;
+      uint8_t type = r[q + 2];
+      q += 3;
       size_t len = 0;
       switch (type)
       {
@@ -243,60 +376,148 @@ extern "C" int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen)
       case 'd': len = 8; break;
       case 'Z': case 'H':
       {
-        size_t e = o;
+        size_t e = q;
         while (e < bs && r[e]) ++e;
         if (type == 'Z')
         {
-          if (!sa && tag[0] == 'S' && tag[1] == 'A') { sa = r + o; sa_len = e - o; }
-          if (!oc && tag[0] == 'O' && tag[1] == 'C') { oc = r + o; oc_len = e - o; }
+          if (!sa && tag[0] == 'S' && tag[1] == 'A') { sa = r + q; sa_len = e - q; }
+          if (!oc && tag[0] == 'O' && tag[1] == 'C') { oc = r + q; oc_len = e - q; }
         }
-        len = e - o + 1;
+        len = e - q + 1;
         break;
       }
       case 'B':
       {
-        if (o + 5 > bs) { o = bs; continue; }
-        uint8_t sub = r[o];
-        uint32_t cnt = rd32(r + o + 1);
+        if (q + 5 > bs) { q = bs; continue; }
+        uint8_t sub = r[q];
+        uint32_t cnt = rd32(r + q + 1);
         size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
         len = 5 + (size_t) cnt * es;
         break;
       }
       default:
-        o = bs;
+        q = bs;
         continue;
       }
-      o += len;
+      q += len;
     }
+    c.aux_off[i] = (uint32_t) o.aux.size();
     if (sa && sa_len)
     {
       if (oc && oc_len)
       {
-        b->aux.insert(b->aux.end(), oc, oc + oc_len);
-        b->aux.push_back('\t');
+        o.aux.insert(o.aux.end(), oc, oc + oc_len);
+        o.aux.push_back('\t');
       }
-      b->aux.insert(b->aux.end(), sa, sa + sa_len);
+      o.aux.insert(o.aux.end(), sa, sa + sa_len);
     }
-    b->tid.push_back(tid);
-    b->pos.push_back(pos);
-    b->mtid.push_back(mtid);
-    b->mpos.push_back(mpos);
-    b->isize.push_back(isz);
-    b->flag.push_back(fl);
-    b->mapq.push_back(mq);
-    b->cigar_off.push_back((uint32_t) b->cigar.size());
-    b->aux_off.push_back((uint32_t) b->aux.size());
     p += bs;
   }
-  if (b->cigar.empty()) b->cigar.push_back(0);
-  if (b->aux.empty()) b->aux.push_back(0);
+}
+}  // namespace
+
+extern "C" int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen)
+{
+  if (!b || !out) return BK_ERR_ARG;
+  const double t0 = now_s();
+  const std::vector<uint8_t> &dv = b->data;
+  const uint8_t *d = dv.data();
+  const size_t dsize = dv.size();
+  // pass 1: record starts, one checkpoint per CHUNK records
+  std::vector<size_t> ckpt;
+  size_t n = 0, p = b->rec_begin;
+  while (p + 4 <= dsize)
+  {
+    uint32_t bs = rd32(d + p);
+    if (bs < 32 || p + 4 + (size_t) bs > dsize)
+    {
+      set_err(err, errlen, "truncated BAM record");
+      return BK_ERR_IO;
+    }
+    if (n % CHUNK == 0) ckpt.push_back(p);
+    ++n;
+    p += 4 + (size_t) bs;
+  }
+  if (n >= 0xFFFFFFF0ull)
+  {
+    set_err(err, errlen, "more than 2^32 records in one BAM");
+    return BK_ERR_LIMIT;
+  }
+  int ndev = 0;
+  const bool pin = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+  (void) hipGetLastError();
+  bool ok = b->tid.alloc(n * 4, pin) && b->pos.alloc(n * 4, pin) && b->mtid.alloc(n * 4, pin) && b->mpos.alloc(n * 4, pin) && b->isize.alloc(n * 4, pin) &&
+            b->flag.alloc(n * 2, pin) && b->mapq.alloc(n, pin) && b->qhash.alloc(n * 8, pin) && b->cigar_off.alloc((n + 1) * 4, pin) && b->aux_off.alloc((n + 1) * 4, pin);
+  if (!ok)
+  {
+    set_err(err, errlen, "out of host memory for the record table");
+    return BK_ERR_IO;
+  }
+  Cols c{b->tid.as<int32_t>(), b->pos.as<int32_t>(), b->mtid.as<int32_t>(), b->mpos.as<int32_t>(), b->isize.as<int32_t>(), b->flag.as<uint16_t>(),
+         b->mapq.as<uint8_t>(), b->qhash.as<uint64_t>(), b->cigar_off.as<uint32_t>(), b->aux_off.as<uint32_t>()};
+  // pass 2: chunks in parallel
+  const size_t nchunks = ckpt.size();
+  std::vector<ChunkOut> co(nchunks);
+  const unsigned nt = n_threads();
+  parallel_for(nchunks, nt, [&](size_t j) {
+    const size_t r0 = j * CHUNK, r1 = (r0 + CHUNK < n) ? r0 + CHUNK : n;
+    decode_chunk(d, dsize, ckpt[j], r0, r1, c, co[j]);
+  });
+  uint64_t ncig = 0, naux = 0;
+  for (size_t j = 0; j < nchunks; ++j)
+  {
+    if (co[j].bad)
+    {
+      set_err(err, errlen, "corrupt BAM record");
+      return BK_ERR_IO;
+    }
+    co[j].cigar_base = ncig;
+    co[j].aux_base = naux;
+    ncig += co[j].cigar.size();
+    naux += co[j].aux.size();
+  }
+  if (ncig >= 0xFFFFFFF0ull || naux >= 0xFFFFFFF0ull)
+  {
+    set_err(err, errlen, "CIGAR / SA columns exceed 32-bit offsets");
+    return BK_ERR_LIMIT;
+  }
+  if (!b->cigar.alloc((ncig ? ncig : 1) * 4, pin) || !b->aux.alloc(naux ? naux : 1, pin))
+  {
+    set_err(err, errlen, "out of host memory for the record table");
+    return BK_ERR_IO;
+  }
+  uint32_t *cig = b->cigar.as<uint32_t>();
+  uint8_t *aux = b->aux.as<uint8_t>();
+  if (!ncig) cig[0] = 0;
+  if (!naux) aux[0] = 0;
+  // pass 3: place the variable-length columns, rebase the offsets
+  parallel_for(nchunks, nt, [&](size_t j) {
+    const size_t r0 = j * CHUNK, r1 = (r0 + CHUNK < n) ? r0 + CHUNK : n;
+    ChunkOut &o = co[j];
+    if (!o.cigar.empty()) memcpy(cig + o.cigar_base, o.cigar.data(), o.cigar.size() * 4);
+    if (!o.aux.empty()) memcpy(aux + o.aux_base, o.aux.data(), o.aux.size());
+    const uint32_t cb = (uint32_t) o.cigar_base, ab = (uint32_t) o.aux_base;
+    for (size_t i = r0; i < r1; ++i)
+    {
+      c.cigar_off[i] += cb;
+      c.aux_off[i] += ab;
+    }
+    std::vector<uint32_t>().swap(o.cigar);
+    std::vector<uint8_t>().swap(o.aux);
+  });
+  c.cigar_off[n] = (uint32_t) ncig;
+  c.aux_off[n] = (uint32_t) naux;
   memset(out, 0, sizeof *out);
-  out->n = b->tid.size();
-  out->tid = b->tid.data(); out->pos = b->pos.data(); out->mtid = b->mtid.data(); out->mpos = b->mpos.data(); out->isize = b->isize.data();
-  out->flag = b->flag.data(); out->mapq = b->mapq.data(); out->qhash = b->qhash.data();
-  out->cigar_off = b->cigar_off.data(); out->cigar = b->cigar.data(); out->aux_off = b->aux_off.data(); out->aux = b->aux.data();
-  out->n_cigar_words = b->cigar_off.back();
-  out->n_aux_bytes = b->aux_off.back();
+  out->n = n;
+  out->tid = c.tid; out->pos = c.pos; out->mtid = c.mtid; out->mpos = c.mpos; out->isize = c.isize;
+  out->flag = c.flag; out->mapq = c.mapq; out->qhash = c.qhash;
+  out->cigar_off = c.cigar_off; out->cigar = cig; out->aux_off = c.aux_off; out->aux = aux;
+  out->n_cigar_words = (uint32_t) ncig;
+  out->n_aux_bytes = (uint32_t) naux;
+  b->t_decode_s = now_s() - t0;
+  if (getenv("BREAKID_FEED_STATS"))
+    fprintf(stderr, "[feed] %zu records, %.1f MB inflated: inflate %.3f s, decode %.3f s, %u threads, %s host columns\n", n, dsize / 1e6, b->t_inflate_s,
+            b->t_decode_s, nt, b->tid.pinned ? "pinned" : "pageable");
   return BK_OK;
 }
 

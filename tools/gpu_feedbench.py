@@ -1,0 +1,85 @@
+"""Feed-path measurement (run on the GPU box): synthetic coordinate-sorted BAM -> bk_bam_open/decode (BGZF inflate +
+record decode on the host cores, pinned columns) -> bk_upload_records(BK_MEM_HOST) -> bk_run.  Prints the rate of
+every stage so DESIGN.md can quote the PCIe-inclusive number next to the HBM-resident one."""
+import os, struct, sys, time, zlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def write_bam(path, n_pairs, seed=7, read_len=150):
+    rng = np.random.default_rng(seed)
+    contigs = [("chr1", 249250621), ("chr2", 243199373), ("chr3", 198022430)]
+    lens = np.asarray([l for _, l in contigs])
+    n = 2 * n_pairs
+    tid = rng.integers(0, 3, n_pairs)
+    pos = (rng.random(n_pairs) * (lens[tid] - 2000)).astype(np.int64)
+    ins = np.clip(np.round(rng.normal(350, 40, n_pairs)), read_len + 1, None).astype(np.int64)
+    disc = rng.random(n_pairs) < 0.05
+    mt = np.where(disc, rng.integers(0, 3, n_pairs), tid)
+    mp = np.where(disc, (rng.random(n_pairs) * (lens[mt] - 2000)).astype(np.int64), pos + ins - read_len)
+    l_name = 20
+    rec_len = 32 + l_name + 4 + (read_len + 1) // 2 + read_len
+    dt = np.dtype([("bs", "<u4"), ("tid", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"), ("bin", "<u2"), ("ncig", "<u2"), ("flag", "<u2"), ("lseq", "<u4"),
+                   ("mtid", "<i4"), ("mpos", "<i4"), ("isize", "<i4"), ("name", "S%d" % l_name), ("cigar", "<u4"), ("seq", "u1", ((read_len + 1) // 2,)), ("qual", "u1", (read_len,))])
+    assert dt.itemsize == rec_len + 4
+    a = np.zeros(n, dt)
+    names = np.char.add("read_", np.char.zfill(np.arange(n_pairs).astype("U14"), 14)).astype("S%d" % l_name)
+    for half, (t, p, t2, p2, fl, sgn) in enumerate([(tid, pos, mt, mp, 0x63, 1), (mt, mp, tid, pos, 0x93, -1)]):
+        v = a[half::2]
+        v["tid"], v["pos"], v["mtid"], v["mpos"] = t, p, t2, p2
+        v["flag"] = np.where(disc, (fl & ~0x2), fl)
+        v["isize"] = np.where(disc, 0, sgn * ins)
+        v["name"] = names
+    a["bs"] = rec_len; a["l_name"] = l_name; a["mapq"] = 60; a["ncig"] = 1; a["lseq"] = read_len; a["cigar"] = read_len << 4
+    a["seq"] = rng.integers(0, 256, (n, (read_len + 1) // 2), dtype=np.uint8) & 0x77 | 0x11
+    a["qual"] = rng.choice(np.asarray([2, 11, 25, 37, 37, 37, 37], np.uint8), (n, read_len))
+    order = np.lexsort((a["pos"], a["tid"]))
+    a = a[order]
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (nm.encode(), ln) for nm, ln in contigs)
+    hdr = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(contigs))
+    for nm, ln in contigs:
+        hdr += struct.pack("<I", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<I", ln)
+    raw = hdr + a.tobytes()
+    with open(path, "wb") as f:
+        for off in range(0, len(raw), 0xFF00):
+            blk = raw[off:off + 0xFF00]
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            comp = c.compress(blk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(blk), len(blk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return n, len(raw), os.path.getsize(path)
+
+
+if __name__ == "__main__":
+    n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    path = "/tmp/feed_%d.bam" % n_pairs
+    t = time.time()
+    n, raw, comp = write_bam(path, n_pairs)
+    print("wrote %s: %d records, %.1f MB inflated, %.1f MB file (%.1f s)" % (path, n, raw / 1e6, comp / 1e6, time.time() - t), flush=True)
+    import torch
+    from breakid_amd import abi, capi
+    for threads in ("1", ""):
+        if threads:
+            os.environ["BREAKID_THREADS"] = threads
+        else:
+            os.environ.pop("BREAKID_THREADS", None)
+        os.environ["BREAKID_FEED_STATS"] = "1"
+        t0 = time.perf_counter()
+        contigs, cols, handle = capi.decode_bam(path, keep=True)
+        t1 = time.perf_counter()
+        print("threads=%s: open+decode %.3f s -> %.2f M records/s, %.1f MB/s of BAM" % (threads or "all", t1 - t0, n / (t1 - t0) / 1e6, comp / (t1 - t0) / 1e6), flush=True)
+        if not threads:
+            ctx = capi.Context(contigs)
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                ctx.upload_soa(handle)
+                ctx.sync()
+                t3 = time.perf_counter()
+                w, nv = ctx.run(qual=20, fast=True)
+                ctx.sync()
+                t4 = time.perf_counter()
+                print("  upload (pinned H2D) %.1f ms = %.1f GB/s, %.1f M records/s; run %.1f ms; upload+run %.1f M records/s" % (
+                    (t3 - t2) * 1e3, handle.nbytes / (t3 - t2) / 1e9, n / (t3 - t2) / 1e6, (t4 - t3) * 1e3, n / (t4 - t2) / 1e6), flush=True)
+            ctx.close()
+        handle.close()
