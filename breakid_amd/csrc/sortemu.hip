@@ -27,23 +27,27 @@ inline double now_ms()
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
+// Live segments of one level are laid out back to back in a compact index space (cbase = first compact index of
+// the segment): the per-level passes touch only elements that are still being partitioned, not all n positions.
 struct Seg
 {
   uint32_t first, last;
   uint32_t pivot;
   int32_t depth;
   uint32_t cut;
+  uint32_t cbase;
 };
 
 // depth_limit = 2 * floor(log2(n))  (std::__lg(n) * 2)
-__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, uint32_t *__restrict__ cnt)
+// cnt entries: (#segments) | (#elements in them) << 32, scanned together
+__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsigned long long *__restrict__ cnt)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   uint64_t sz = goff[g + 1] - goff[g];
-  cnt[g] = sz > 16 ? 1u : 0u;
+  cnt[g] = sz > 16 ? (1ull | (sz << 32)) : 0ull;
 }
-__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const uint32_t *__restrict__ off, Seg *__restrict__ segs)
+__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
@@ -56,7 +60,8 @@ __global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, 
     s.pivot = 0;
     s.depth = 2 * (63 - __clzll((long long) sz));
     s.cut = 0;
-    segs[off[g]] = s;
+    s.cbase = (uint32_t) (off[g] >> 32);
+    segs[(uint32_t) off[g]] = s;
   }
 }
 
@@ -504,79 +509,78 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
   }
 }
 
-__device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t p)
+__device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t c)
 {
-  // largest s with segs[s].first <= p, or ~0u
+  // segment that owns compact index c: largest s with segs[s].cbase <= c (segs[0].cbase == 0)
   uint32_t lo = 0, hi = ns;
   while (lo < hi)
   {
     uint32_t m = (lo + hi) >> 1;
-    if (segs[m].first <= p) lo = m + 1; else hi = m;
+    if (segs[m].cbase <= c) lo = m + 1; else hi = m;
   }
-  if (lo == 0) return 0xFFFFFFFFu;
-  uint32_t s = lo - 1;
-  return (p < segs[s].last && segs[s].depth >= 0) ? s : 0xFFFFFFFFu;
+  return lo - 1;
 }
 
-// lr[p] = (#L-stopper at p) | (#R-stopper at p) << 32 ; segof[p] = segment index or ~0
-__global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t n,
+// lr[c] = (#L-stopper at c) | (#R-stopper at c) << 32 ; segof[c] = segment index
+__global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
                                                   unsigned long long *__restrict__ lr, uint32_t *__restrict__ segof)
 {
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  uint32_t s = find_seg(segs, ns, p);
-  segof[p] = s;
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= na) return;
+  const uint32_t s = find_seg(segs, ns, c);
+  segof[c] = s;
+  const Seg sg = segs[s];
   unsigned long long v = 0;
-  if (s != 0xFFFFFFFFu && p > segs[s].first)
+  if (sg.depth >= 0 && c > sg.cbase)
   {
-    uint32_t k = key[p], pv = segs[s].pivot;
+    uint32_t k = key[sg.first + (c - sg.cbase)], pv = sg.pivot;
     if (k >= pv) v |= 1ull;          // !(key < pivot): the left scan stops here
     if (k <= pv) v |= 1ull << 32;    // !(pivot < key): the right scan stops here
   }
-  lr[p] = v;
+  lr[c] = v;
 }
 
-__global__ __launch_bounds__(256) void k_se_lists(const Seg *__restrict__ segs, const uint32_t *__restrict__ segof, const uint32_t *__restrict__ key, uint32_t n,
+__global__ __launch_bounds__(256) void k_se_lists(const Seg *__restrict__ segs, const uint32_t *__restrict__ segof, const uint32_t *__restrict__ key, uint32_t na,
                                                   const unsigned long long *__restrict__ LR, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR)
 {
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  uint32_t s = segof[p];
-  if (s == 0xFFFFFFFFu) return;
-  Seg sg = segs[s];
-  if (p <= sg.first) return;
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= na) return;
+  const Seg sg = segs[segof[c]];
+  if (sg.depth < 0 || c <= sg.cbase) return;
+  const uint32_t p = sg.first + (c - sg.cbase);
   uint32_t k = key[p];
-  unsigned long long here = LR[p], base = LR[sg.first], end = LR[sg.last];
+  unsigned long long here = LR[c], base = LR[sg.cbase], end = LR[sg.cbase + (sg.last - sg.first)];
   if (k >= sg.pivot)
   {
     uint32_t j = (uint32_t) here - (uint32_t) base;
-    posL[sg.first + 1 + j] = p;
+    posL[sg.cbase + 1 + j] = p;
   }
   if (k <= sg.pivot)
   {
     uint32_t nR = (uint32_t) (end >> 32) - (uint32_t) (base >> 32);
     uint32_t jl = (uint32_t) (here >> 32) - (uint32_t) (base >> 32);
-    posR[sg.first + 1 + (nR - 1 - jl)] = p;
+    posR[sg.cbase + 1 + (nR - 1 - jl)] = p;
   }
 }
 
-__global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const uint32_t *__restrict__ segof, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t n,
+__global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const uint32_t *__restrict__ segof, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
                                                  const unsigned long long *__restrict__ LR, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR)
 {
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  uint32_t s = segof[p];
-  if (s == 0xFFFFFFFFu) return;
-  const uint32_t first = segs[s].first, last = segs[s].last;
-  unsigned long long base = LR[first], end = LR[last];
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= na) return;
+  const uint32_t s = segof[c];
+  const Seg sg = segs[s];
+  if (sg.depth < 0) return;
+  const uint32_t first = sg.first, cb = sg.cbase;
+  unsigned long long base = LR[cb], end = LR[cb + (sg.last - first)];
   uint32_t nL = (uint32_t) end - (uint32_t) base;
   uint32_t nR = (uint32_t) (end >> 32) - (uint32_t) (base >> 32);
   uint32_t m = nL < nR ? nL : nR;
-  uint32_t j = p - first;
+  uint32_t j = c - cb;
   if (j > m) return;
   const uint32_t INF = 0xFFFFFFFFu;
-  uint32_t lj = j < nL ? posL[first + 1 + j] : INF;
-  uint32_t rj = j < nR ? posR[first + 1 + j] : first;
+  uint32_t lj = j < nL ? posL[cb + 1 + j] : INF;
+  uint32_t rj = j < nR ? posR[cb + 1 + j] : first;
   bool cont = (j < nL) && (j < nR) && (lj < rj);
   if (cont)
   {
@@ -592,8 +596,8 @@ __global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const u
     uint32_t rprev = 0;
     if (j > 0)
     {
-      uint32_t lp = posL[first + j];   // j-1 < m <= nL, nR
-      rprev = posR[first + j];
+      uint32_t lp = posL[cb + j];   // j-1 < m <= nL, nR
+      rprev = posR[cb + j];
       prev_cont = lp < rprev;
     }
     if (j == 0)
@@ -603,30 +607,40 @@ __global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const u
   }
 }
 
-__global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ cnt)
+__global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, unsigned long long *__restrict__ cnt)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   Seg sg = segs[s];
-  cnt[s] = sg.depth < 0 ? 0u : ((sg.cut - sg.first) > 16 ? 1u : 0u) + ((sg.last - sg.cut) > 16 ? 1u : 0u);
+  unsigned long long v = 0;
+  if (sg.depth >= 0)
+  {
+    const uint32_t a = sg.cut - sg.first, b = sg.last - sg.cut;
+    if (a > 16) v += 1ull | ((unsigned long long) a << 32);
+    if (b > 16) v += 1ull | ((unsigned long long) b << 32);
+  }
+  cnt[s] = v;
 }
-__global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ off, Seg *__restrict__ out)
+__global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const unsigned long long *__restrict__ off, Seg *__restrict__ out)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   Seg sg = segs[s];
   if (sg.depth < 0) return;
-  uint32_t o = off[s];
+  uint32_t o = (uint32_t) off[s], cb = (uint32_t) (off[s] >> 32);
   if ((sg.cut - sg.first) > 16)
   {
     Seg c = sg;
     c.last = sg.cut;
+    c.cbase = cb;
+    cb += sg.cut - sg.first;
     out[o++] = c;
   }
   if ((sg.last - sg.cut) > 16)
   {
     Seg c = sg;
     c.first = sg.cut;
+    c.cbase = cb;
     out[o++] = c;
   }
 }
@@ -652,15 +666,16 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   if (n64 == 0 || ng == 0) return;
   if (n64 > 0x7FFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: more than 2^31 pairs");
   const uint32_t n = (uint32_t) n64;
-  uint32_t *cnt = b.cnt.as<uint32_t>((uint64_t) (n / 8 + ng) + 32);
+  unsigned long long *cnt = b.cnt.as<unsigned long long>((uint64_t) (n / 8 + ng) + 32);
   uint32_t *err = b.err.as<uint32_t>(4);
   HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
   // level 0 segments = groups larger than 16
   hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt);
-  prims::exclusive_scan<uint32_t>(cnt, cnt, ng, b.scan_tmp, st);
-  uint32_t ns = 0;
-  HIP_CHECK(hipMemcpyAsync(&ns, cnt + ng, 4, hipMemcpyDeviceToHost, st));
+  prims::exclusive_scan<unsigned long long>(cnt, cnt, ng, b.scan_tmp, st);
+  unsigned long long tot = 0;
+  HIP_CHECK(hipMemcpyAsync(&tot, cnt + ng, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  uint32_t ns = (uint32_t) tot, na = (uint32_t) (tot >> 32);  // live segments, elements in them
   size_t max_segs = (size_t) n / 8 + ng + 16;
   Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
   uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
@@ -671,7 +686,6 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     unsigned long long *lr = b.lr.as<unsigned long long>((uint64_t) n + 1);
     uint32_t *segof = b.segof.as<uint32_t>(n);
     uint32_t *posL = b.posL.as<uint32_t>((uint64_t) n + 2), *posR = b.posR.as<uint32_t>((uint64_t) n + 2);
-    const unsigned nbk = cdiv(n, 256);
     int level = 0;
     static const bool dbg_levels = getenv("BK_DEBUG_SORT") != nullptr;
     double t_loop0 = 0;
@@ -684,23 +698,25 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     {
       if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
       hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-      hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, n, lr, segof);
-      prims::exclusive_scan<unsigned long long>(lr, lr, n, b.scan_tmp, st);
-      hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, n, lr, posL, posR);
-      hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, n, lr, posL, posR);
+      const unsigned nbk = cdiv(na, 256);
+      hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, na, lr, segof);
+      prims::exclusive_scan<unsigned long long>(lr, lr, na, b.scan_tmp, st);
+      hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR);
+      hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR);
       hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
-      prims::exclusive_scan<uint32_t>(cnt, cnt, ns, b.scan_tmp, st);
-      uint32_t ns2 = 0;
-      HIP_CHECK(hipMemcpyAsync(&ns2, cnt + ns, 4, hipMemcpyDeviceToHost, st));
+      prims::exclusive_scan<unsigned long long>(cnt, cnt, ns, b.scan_tmp, st);
+      HIP_CHECK(hipMemcpyAsync(&tot, cnt + ns, 8, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
+      const uint32_t ns2 = (uint32_t) tot;
       if (ns2 > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
       if (ns2) hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2);
       std::swap(segs, segs2);
       ns = ns2;
+      na = (uint32_t) (tot >> 32);
       if (dbg_levels && (level % 4 == 0 || ns2 == 0))
       {
         HIP_CHECK(hipStreamSynchronize(st));
-        fprintf(stderr, "[sortemu]   level %d: %u segments -> %u, %.3f ms so far\n", level, ns, ns2, now_ms() - t_loop0);
+        fprintf(stderr, "[sortemu]   level %d: %u segments -> %u (%u live elements), %.3f ms so far\n", level, ns, ns2, (uint32_t) (tot >> 32), now_ms() - t_loop0);
       }
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
