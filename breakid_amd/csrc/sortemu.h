@@ -8,14 +8,15 @@ struct SortEmuBufs
   DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch;
   prims::RadixBufs radix;
   // the three size classes of the heapsort branch run side by side (fork/join around the caller's stream)
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+  static constexpr int N_AUX = 5;
+  hipStream_t aux[N_AUX] = {};
+  hipEvent_t fork = nullptr, join[N_AUX] = {};
   SortEmuBufs() = default;
   SortEmuBufs(const SortEmuBufs &) = delete;
   SortEmuBufs &operator=(const SortEmuBufs &) = delete;
   ~SortEmuBufs()
   {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < N_AUX; ++i)
     {
       if (aux[i]) (void) hipStreamDestroy(aux[i]);
       if (join[i]) (void) hipEventDestroy(join[i]);

@@ -463,8 +463,9 @@ constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
+// (lo, hi]: the sizes this launch takes (CLS 1 is launched once per LDS footprint so that small heaps share a CU)
 template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
-                                                                       hent *__restrict__ scratch)
+                                                                       hent *__restrict__ scratch, uint32_t lo, uint32_t hi)
 {
   extern __shared__ __attribute__((aligned(16))) hent dyn[];
   __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
@@ -472,8 +473,7 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
   if (s >= nh) return;
   const HeapSeg sg = hs[s];
   const uint32_t m = sg.last - sg.first;
-  const int cls = m <= HEAP_SMALL ? 0 : (m <= HEAP_LARGE ? 1 : 2);
-  if (cls != CLS) return;
+  if (m <= lo || m > hi) return;
   uint32_t *gk = key + sg.first, *gx = idx + sg.first;
   hent *buf = CLS == 0 ? stat : (CLS == 1 ? dyn : scratch + sg.first);
   for (uint32_t i = threadIdx.x; i < m; i += 64) buf[i] = ((hent) gk[i] << 32) | gx[i];
@@ -745,7 +745,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (!b.fork)
       {
         HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < SortEmuBufs::N_AUX; ++i)
         {
           HIP_CHECK(hipStreamCreateWithFlags(&b.aux[i], hipStreamNonBlocking));
           HIP_CHECK(hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming));
@@ -755,23 +755,31 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         // largest class first: its longest segment is the critical path of the whole sort
         HIP_CHECK(hipEventRecord(b.fork, st));
         int used = 0;
+        auto side = [&](auto k, size_t lds, uint32_t lo, uint32_t hi) {
+          HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
+          hipLaunchKernelGGL(k, dim3(nh), dim3(64), lds, b.aux[used], hl, nh, key, idx, hscratch, lo, hi);
+          HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
+          ++used;
+        };
         if (e[1] > HEAP_LARGE)
         {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-          hipLaunchKernelGGL(k2, dim3(nh), dim3(64), dyn, b.aux[used], hl, nh, key, idx, hscratch);
-          HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
-          ++used;
+          side(k2, dyn, HEAP_LARGE, 0xFFFFFFFFu);
         }
         if (e[1] > HEAP_SMALL)
         {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-          hipLaunchKernelGGL(k1, dim3(nh), dim3(64), dyn, b.aux[used], hl, nh, key, idx, hscratch);
-          HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
-          ++used;
+          const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
+          // one launch per LDS footprint (BK_HEAP_CLASSES=1) packs more mid-size heaps per CU but measured slower
+          // end to end (197 vs 187 ms per step): the extra activity slows the lone wave on the critical path
+          static const bool split = getenv("BK_HEAP_CLASSES") != nullptr;
+          if (!split)
+            side(k1, dyn, HEAP_SMALL, HEAP_LARGE);
+          else
+            for (int c = 0; c < 4; ++c)
+              if (e[1] > bounds[c + 1]) side(k1, ((size_t) bounds[c] + HEAP_PAD) * 8, bounds[c + 1], bounds[c]);
         }
-        hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch);
+        hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch, 0u, HEAP_SMALL);
         for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
       };
       switch (sift_k)
