@@ -343,20 +343,10 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
 // every 4 cycles, so the segment's critical path is the instruction count of one loop iteration; the compiler's
 // version spends ~80 instructions per iteration on mask bookkeeping, this one ~25 (+~25 in an iteration that
 // launches).  Per-lane state: h1 = hole + 1 (v40), len (v41; 0 = idle lane), value (idx v42, key v43).
-// Uniform state: next_t (s41), since (s42), L+1 (s43), clz(L+1) (s44), budget (s45), t_end (s46).
+// Uniform state: next_t (s41), L+1 (s43), clz(L+1) (s44), budget (s45), t_end (s46).
 // GLB = false: heap in LDS at byte offset `base`; GLB = true: heap in global memory at `gptr` (base = 0).
-#define BK_HEAP_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, ST_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL)                                      \
-  "v_mov_b32 v62, %[lane]\n"                                                                                               \
-  "s_mov_b32 s62, %[plo]\n s_mov_b32 s63, %[phi]\n"                                                                          \
-  "s_sub_u32 s40, %[base], 8\n"                                                                                            \
-  "v_mov_b32 v60, %[base]\n"                                                                                               \
-  "s_mov_b32 s46, %[tend]\n s_mov_b32 s41, 1\n s_mov_b32 s42, 2\n s_mov_b32 s43, %[m]\n"                                      \
-  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
-  "s_lshl_b32 s47, s43, 3\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
-  "s_mov_b32 s45, %[budget]\n"                                                                                             \
-  "v_mov_b32 v40, 1\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
-  "BK_LOOP_%=:\n"                                                                                                         \
-  WAIT_ALL LD1_ROOT LD1_LEAF                                                                                              \
+// one sift step of every pop in flight (idle lanes: len = 0 -> no store, state unchanged)
+#define BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                         \
   "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
   "v_cmp_le_u32_e64 s[48:49], v44, v41\n"                                                                                  \
   "v_cmp_lt_u32_e64 s[50:51], v44, v41\n"                                                                                  \
@@ -380,12 +370,31 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
   "s_mov_b64 exec, s[56:57]\n"                                                                                             \
   "v_addc_co_u32_e64 v53, vcc, v44, 0, s[52:53]\n"                                                                         \
   "v_cndmask_b32_e64 v40, v40, v53, s[54:55]\n"                                                                            \
-  "v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"                                                                              \
-  "s_add_u32 s42, s42, 1\n"                                                                                                \
+  "v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"
+
+// Loop A = the iteration right after a launch (the next pop may not start yet: lag 2), loop B = iterations that may
+// launch: they prefetch the root and the leaf to detach together with the children of the holes.
+#define BK_HEAP_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, ST_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL)                                      \
+  "v_mov_b32 v62, %[lane]\n"                                                                                               \
+  "s_mov_b32 s62, %[plo]\n s_mov_b32 s63, %[phi]\n"                                                                          \
+  "s_sub_u32 s40, %[base], 8\n"                                                                                            \
+  "v_mov_b32 v60, %[base]\n"                                                                                               \
+  "s_mov_b32 s46, %[tend]\n s_mov_b32 s41, 1\n s_mov_b32 s43, %[m]\n"                                                       \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "s_lshl_b32 s47, s43, 3\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
+  "s_mov_b32 s45, %[budget]\n"                                                                                             \
+  "v_mov_b32 v40, 1\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
+  "s_branch BK_B_%=\n"                                                                                                     \
+  "BK_A_%=:\n"                                                                                                            \
+  WAIT_ALL                                                                                                                \
+  BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                             \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc1 BK_DONE_%=\n"                                                                                            \
+  "BK_B_%=:\n"                                                                                                            \
+  WAIT_ALL LD1_ROOT LD1_LEAF                                                                                              \
+  BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                             \
   "s_cmp_ge_u32 s41, s46\n"                                                                                                \
   "s_cbranch_scc1 BK_NOMORE_%=\n"                                                                                          \
-  "s_cmp_lt_u32 s42, 2\n"                                                                                                  \
-  "s_cbranch_scc1 BK_NEXT_%=\n"                                                                                            \
   "v_ffbh_u32_e32 v63, v40\n"                                                                                              \
   "v_subrev_u32_e32 v63, s44, v63\n"                                                                                       \
   "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
@@ -397,7 +406,7 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
   "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
   "s_and_b64 s[60:61], s[60:61], s[58:59]\n"                                                                               \
   "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
-  "s_cbranch_vccnz BK_NEXT_%=\n"                                                                                           \
+  "s_cbranch_vccnz BK_BNEXT_%=\n"                                                                                          \
   "s_and_b32 s47, s41, 63\n"                                                                                               \
   "v_cmp_eq_u32_e32 vcc, s47, v62\n"                                                                                       \
   "s_sub_u32 s47, s43, 1\n"                                                                                                \
@@ -409,15 +418,15 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
   "s_mov_b32 s43, s47\n"                                                                                                   \
   "s_flbit_i32_b32 s44, s43\n"                                                                                             \
   "v_add_u32_e32 v61, -8, v61\n"                                                                                           \
-  "s_mov_b32 s42, 0\n"                                                                                                     \
-  "s_branch BK_NEXT_%=\n"                                                                                                  \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_A_%=\n"                                                                                               \
+  "s_branch BK_DONE_%=\n"                                                                                                  \
   "BK_NOMORE_%=:\n"                                                                                                       \
   "v_cmp_ne_u32_e32 vcc, 0, v41\n"                                                                                         \
   "s_cbranch_vccz BK_DONE_%=\n"                                                                                            \
-  "BK_NEXT_%=:\n"                                                                                                         \
+  "BK_BNEXT_%=:\n"                                                                                                        \
   "s_sub_u32 s45, s45, 1\n"                                                                                                \
-  "s_cmp_lg_u32 s45, 0\n"                                                                                                  \
-  "s_cbranch_scc1 BK_LOOP_%=\n"                                                                                            \
+  "s_cbranch_scc0 BK_B_%=\n"                                                                                               \
   "BK_DONE_%=:\n"                                                                                                         \
   WAIT_ALL                                                                                                                \
   "s_mov_b32 %[left], s45\n"
