@@ -123,26 +123,45 @@ struct HeapSeg
 typedef unsigned long long hent;
 __device__ __forceinline__ uint32_t hkey(hent e) { return (uint32_t) (e >> 32); }
 
-struct LdsMem
+// A second entry format serves heaps of 20 001 .. 65 536 elements: (rank of the key inside the segment) << 16 | local
+// index, 4 bytes, so that twice as much of the heap fits LDS (the keys are ranked by one radix sort before the launch).
+struct E64
 {
-  hent *e;
-  __device__ __forceinline__ hent ld(uint32_t i) const { return e[i]; }
-  __device__ __forceinline__ void st(uint32_t i, hent v) const { e[i] = v; }
+  typedef hent T;
+  static __device__ __forceinline__ uint32_t key(T e) { return (uint32_t) (e >> 32); }
+};
+struct E32
+{
+  typedef uint32_t T;
+  static __device__ __forceinline__ uint32_t key(T e) { return e >> 16; }
+};
+
+template <class E> struct LdsMemT
+{
+  typedef typename E::T T;
+  T *e;
+  static __device__ __forceinline__ uint32_t key(T v) { return E::key(v); }
+  __device__ __forceinline__ T ld(uint32_t i) const { return e[i]; }
+  __device__ __forceinline__ void st(uint32_t i, T v) const { e[i] = v; }
   __device__ __forceinline__ void step_sync() const { __builtin_amdgcn_wave_barrier(); }
   __device__ __forceinline__ void launch_sync() const { __builtin_amdgcn_wave_barrier(); }
 };
 // global-memory variant for segments that do not fit LDS.  All lanes belong to one wavefront on one CU, so
 // plain accesses are coherent through that CU's write-through L1 (the same guarantee __syncthreads() gives a
 // block); every step drains its stores before the next step's loads.
-struct GlbMem
+template <class E> struct GlbMemT
 {
-  hent *e;  // plain accesses; the "memory" clobber of step_sync makes the compiler reload after every step
-  __device__ __forceinline__ hent ld(uint32_t i) const { return e[i]; }
-  __device__ __forceinline__ void st(uint32_t i, hent v) const { e[i] = v; }
+  typedef typename E::T T;
+  T *e;  // plain accesses; the "memory" clobber of step_sync makes the compiler reload after every step
+  static __device__ __forceinline__ uint32_t key(T v) { return E::key(v); }
+  __device__ __forceinline__ T ld(uint32_t i) const { return e[i]; }
+  __device__ __forceinline__ void st(uint32_t i, T v) const { e[i] = v; }
   __device__ __forceinline__ void step_sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   // the detached leaf L is out of reach of every in-flight pop (ancestor stall), so its store needs no drain of its own
   __device__ __forceinline__ void launch_sync() const {}
 };
+typedef LdsMemT<E64> LdsMem;
+typedef GlbMemT<E64> GlbMem;
 
 __device__ __forceinline__ bool anc_or_self(uint32_t a, uint32_t b)  // is node a an ancestor of (or equal to) node b
 {
@@ -152,16 +171,17 @@ __device__ __forceinline__ bool anc_or_self(uint32_t a, uint32_t b)  // is node 
 }
 
 // one top-down sift step of the value v sitting in `hole`; returns true while the hole keeps descending
-template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint32_t &hole, uint32_t len, hent v)
+template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint32_t &hole, uint32_t len, typename M::T v)
 {
+  typedef typename M::T T;
   const uint32_t right = 2 * (hole + 1), left = right - 1;
-  hent ec = 0;
+  T ec = 0;
   uint32_t c = 0;
   bool has = true;
   if (right < len)
   {
-    const hent el = mem.ld(left), er = mem.ld(right);
-    if (hkey(er) < hkey(el))
+    const T el = mem.ld(left), er = mem.ld(right);
+    if (M::key(er) < M::key(el))
     {
       c = left;
       ec = el;
@@ -179,7 +199,7 @@ template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint3
   }
   else
     has = false;
-  if (has && !(hkey(ec) < hkey(v)))
+  if (has && !(M::key(ec) < M::key(v)))
   {
     mem.st(hole, ec);
     hole = c;
@@ -210,7 +230,7 @@ template <class M> __device__ void make_heap_wave(const M &mem, const uint32_t m
       if (p <= hi)
       {
         uint32_t hole = p;
-        const hent v = mem.ld(p);
+        const typename M::T v = mem.ld(p);
         while (sift_step(mem, hole, m, v))
         {
         }
@@ -468,13 +488,133 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   }
 }
 
+// ---- the same pipeline for 4-byte entries (rank << 16 | local index): value v42, its key v43, children v46/v47 ----
+#define BK_HEAP32_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                       \
+  "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
+  "v_cmp_le_u32_e64 s[48:49], v44, v41\n"                                                                                  \
+  "v_cmp_lt_u32_e64 s[50:51], v44, v41\n"                                                                                  \
+  "v_lshl_add_u32 v45, v44, 2, s40\n"                                                                                      \
+  "v_cndmask_b32_e64 v45, v60, v45, s[48:49]\n"                                                                            \
+  LD2_KIDS                                                                                                                \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "v_cmp_ne_u32_e64 s[58:59], 0, v41\n"                                                                                    \
+  "v_mov_b32 v54, v40\n"                                                                                                   \
+  WAIT_LOADS                                                                                                              \
+  "v_lshrrev_b32 v48, 16, v46\n"                                                                                           \
+  "v_lshrrev_b32 v49, 16, v47\n"                                                                                           \
+  "v_cmp_ge_u32_e32 vcc, v49, v48\n"                                                                                       \
+  "s_and_b64 s[52:53], vcc, s[50:51]\n"                                                                                    \
+  "v_cndmask_b32_e64 v50, v46, v47, s[52:53]\n"                                                                            \
+  "v_cndmask_b32_e64 v51, v48, v49, s[52:53]\n"                                                                            \
+  "v_cmp_ge_u32_e32 vcc, v51, v43\n"                                                                                       \
+  "s_and_b64 s[54:55], vcc, s[48:49]\n"                                                                                    \
+  "v_cndmask_b32_e64 v50, v42, v50, s[54:55]\n"                                                                            \
+  "s_and_saveexec_b64 s[56:57], s[58:59]\n"                                                                                \
+  ST_HOLE                                                                                                                 \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "v_addc_co_u32_e64 v53, vcc, v44, 0, s[52:53]\n"                                                                         \
+  "v_cndmask_b32_e64 v40, v40, v53, s[54:55]\n"                                                                            \
+  "v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"
+
+#define BK_HEAP32_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, ST_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL)                                    \
+  "v_mov_b32 v62, %[lane]\n"                                                                                               \
+  "s_mov_b32 s62, %[plo]\n s_mov_b32 s63, %[phi]\n"                                                                          \
+  "s_sub_u32 s40, %[base], 4\n"                                                                                            \
+  "v_mov_b32 v60, %[base]\n"                                                                                               \
+  "s_mov_b32 s46, %[tend]\n s_mov_b32 s41, 1\n s_mov_b32 s43, %[m]\n"                                                       \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "s_lshl_b32 s47, s43, 2\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
+  "s_mov_b32 s45, %[budget]\n"                                                                                             \
+  "v_mov_b32 v40, 1\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
+  "s_branch BK_B_%=\n"                                                                                                     \
+  "BK_A_%=:\n"                                                                                                            \
+  WAIT_ALL                                                                                                                \
+  BK_HEAP32_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                           \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc1 BK_DONE_%=\n"                                                                                            \
+  "BK_B_%=:\n"                                                                                                            \
+  WAIT_ALL LD1_ROOT LD1_LEAF                                                                                              \
+  BK_HEAP32_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                           \
+  "s_cmp_ge_u32 s41, s46\n"                                                                                                \
+  "s_cbranch_scc1 BK_NOMORE_%=\n"                                                                                          \
+  "v_ffbh_u32_e32 v63, v40\n"                                                                                              \
+  "v_subrev_u32_e32 v63, s44, v63\n"                                                                                       \
+  "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
+  "v_cmp_eq_u32_e32 vcc, v64, v40\n"                                                                                       \
+  "v_cmp_gt_u32_e64 s[60:61], 32, v63\n"                                                                                   \
+  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
+  "v_cmp_ne_u32_e64 s[60:61], 0, v41\n"                                                                                    \
+  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
+  "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
+  "s_and_b64 s[60:61], s[60:61], s[58:59]\n"                                                                               \
+  "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
+  "s_cbranch_vccnz BK_BNEXT_%=\n"                                                                                          \
+  "s_and_b32 s47, s41, 63\n"                                                                                               \
+  "v_cmp_eq_u32_e32 vcc, s47, v62\n"                                                                                       \
+  "s_sub_u32 s47, s43, 1\n"                                                                                                \
+  "s_and_saveexec_b64 s[56:57], vcc\n"                                                                                     \
+  ST_LEAF                                                                                                                 \
+  "v_mov_b32 v42, v58\n v_lshrrev_b32 v43, 16, v58\n v_mov_b32 v40, 1\n v_mov_b32 v41, s47\n"                                 \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "s_add_u32 s41, s41, 1\n"                                                                                                \
+  "s_mov_b32 s43, s47\n"                                                                                                   \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "v_add_u32_e32 v61, -4, v61\n"                                                                                           \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_A_%=\n"                                                                                               \
+  "s_branch BK_DONE_%=\n"                                                                                                  \
+  "BK_NOMORE_%=:\n"                                                                                                       \
+  "v_cmp_ne_u32_e32 vcc, 0, v41\n"                                                                                         \
+  "s_cbranch_vccz BK_DONE_%=\n"                                                                                            \
+  "BK_BNEXT_%=:\n"                                                                                                        \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_B_%=\n"                                                                                               \
+  "BK_DONE_%=:\n"                                                                                                         \
+  WAIT_ALL                                                                                                                \
+  "s_mov_b32 %[left], s45\n"
+
+template <bool GLB> __device__ __forceinline__ void sort_heap_asm32(uint32_t *buf, const uint32_t m, const uint32_t stop)
+{
+  if (m < 2 || m <= stop) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t_end = __builtin_amdgcn_readfirstlane(m - (stop < 1 ? 1 : stop) + 1);
+  const uint32_t budget = __builtin_amdgcn_readfirstlane(m > 0x03000000u ? 0xFFFFFFFFu : 64u * m + 4096u);
+  const uint32_t mm = __builtin_amdgcn_readfirstlane(m);
+  const unsigned long long p = (unsigned long long) buf;
+  const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t) p), phi = __builtin_amdgcn_readfirstlane((uint32_t) (p >> 32));
+  const uint32_t base = GLB ? 0u : plo;
+  uint32_t left;
+  if (GLB)
+    asm volatile(BK_HEAP32_ASM("global_load_dword v56, v60, s[62:63]\n", "global_load_dword v58, v61, s[62:63]\n",
+                               "global_load_dwordx2 v[46:47], v45, s[62:63]\n", "global_store_dword v52, v50, s[62:63]\n",
+                               "global_store_dword v61, v56, s[62:63]\n", "s_waitcnt vmcnt(0)\n", "s_waitcnt vmcnt(0)\n")
+                 : [left] "=s"(left)
+                 : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
+                 : BK_HEAP_CLOBBERS);
+  else
+    asm volatile(BK_HEAP32_ASM("ds_read_b32 v56, v60\n", "ds_read_b32 v58, v61\n", "ds_read2_b32 v[46:47], v45 offset1:1\n",
+                               "ds_write_b32 v52, v50\n", "ds_write_b32 v61, v56\n", "s_waitcnt lgkmcnt(0)\n", "")
+                 : [left] "=s"(left)
+                 : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
+                 : BK_HEAP_CLOBBERS);
+  if (!GLB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0)
+  {
+    atomicAdd(&g_heap_iters[0], (unsigned long long) (budget - left));
+    atomicAdd(&g_heap_iters[1], (unsigned long long) (t_end - 1));
+  }
+}
+
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
+constexpr uint32_t HEAP_LARGE32 = 40000; // the same LDS in 4-byte ranked entries
+constexpr uint32_t HEAP_RANKED_MAX = 65536;
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
 // (lo, hi]: the sizes this launch takes (CLS 1 is launched once per LDS footprint so that small heaps share a CU)
 template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
-                                                                       hent *__restrict__ scratch, uint32_t lo, uint32_t hi)
+                                                                       hent *__restrict__ scratch, uint32_t lo, uint32_t hi,
+                                                                       const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32)
 {
   extern __shared__ __attribute__((aligned(16))) hent dyn[];
   __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
@@ -487,6 +627,44 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
   hent *buf = CLS == 0 ? stat : (CLS == 1 ? dyn : scratch + sg.first);
   for (uint32_t i = threadIdx.x; i < m; i += 64) buf[i] = ((hent) gk[i] << 32) | gx[i];
   __syncthreads();
+  if (CLS == 2 && V == 3 && rank32 != nullptr && m <= HEAP_RANKED_MAX)
+  {
+    // ranked 4-byte entries (see E32): up to HEAP_LARGE32 of them fit LDS.  buf keeps the packed originals.
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(dyn);
+    uint32_t *g32 = scratch32 + sg.first;
+    const bool fits = m <= HEAP_LARGE32;
+    uint32_t *e32 = fits ? l32 : g32;
+    for (uint32_t i = threadIdx.x; i < m; i += 64) e32[i] = (rank32[sg.first + i] << 16) | i;
+    __syncthreads();
+    if (fits)
+    {
+      LdsMemT<E32> mem{l32};
+      make_heap_wave(mem, m);
+      sort_heap_asm32<false>(l32, m, 1);
+    }
+    else
+    {
+      GlbMemT<E32> gmem{g32};
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      make_heap_wave(gmem, m);
+      sort_heap_asm32<true>(g32, m, HEAP_LARGE32);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) l32[i] = g32[i];
+      __syncthreads();
+      sort_heap_asm32<false>(l32, HEAP_LARGE32, 1);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) g32[i] = l32[i];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += 64)
+    {
+      const hent e = buf[e32[i] & 0xFFFFu];
+      gk[i] = hkey(e);
+      gx[i] = (uint32_t) e;
+    }
+    return;
+  }
   if (CLS == 2)
   {
     // too large for LDS: heapify and pop in global memory until the heap fits, then finish in LDS
@@ -516,6 +694,44 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
     gk[i] = hkey(e);
     gx[i] = (uint32_t) e;
   }
+}
+
+// ---- dense key ranks inside the heap segments of the ranked class (HEAP_LARGE < m <= HEAP_RANKED_MAX) ----------------
+__global__ void k_hr_count(const HeapSeg *__restrict__ hs, uint32_t nh, unsigned long long *__restrict__ cnt)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nh) return;
+  const uint32_t m = hs[s].last - hs[s].first;
+  cnt[s] = (m > HEAP_LARGE && m <= HEAP_RANKED_MAX) ? (1ull | ((unsigned long long) m << 32)) : 0ull;
+}
+// one block per heap segment: (ordinal << 32 | key, position) of every element of a ranked-class segment
+__global__ __launch_bounds__(256) void k_hr_gather(const HeapSeg *__restrict__ hs, uint32_t nh, const unsigned long long *__restrict__ off, const uint32_t *__restrict__ key,
+                                                   uint64_t *__restrict__ ck, uint32_t *__restrict__ val, uint32_t *__restrict__ ordbase)
+{
+  const uint32_t s = blockIdx.x;
+  const uint32_t first = hs[s].first, m = hs[s].last - first;
+  if (!(m > HEAP_LARGE && m <= HEAP_RANKED_MAX)) return;
+  const uint32_t ord = (uint32_t) off[s], base = (uint32_t) (off[s] >> 32);
+  if (threadIdx.x == 0) ordbase[ord] = base;
+  for (uint32_t i = threadIdx.x; i < m; i += 256)
+  {
+    ck[base + i] = ((uint64_t) ord << 32) | key[first + i];
+    val[base + i] = first + i;
+  }
+}
+__global__ __launch_bounds__(256) void k_hr_flags(const uint64_t *__restrict__ ck, uint32_t n, uint32_t *__restrict__ f)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f[i] = (i > 0 && ck[i] != ck[i - 1] && (ck[i] >> 32) == (ck[i - 1] >> 32)) ? 1u : 0u;
+}
+// ex = exclusive scan of the flags (n + 1 entries): rank = number of key changes since the segment's first element
+__global__ __launch_bounds__(256) void k_hr_scatter(const uint64_t *__restrict__ ck, const uint32_t *__restrict__ val, const uint32_t *__restrict__ ex,
+                                                    const uint32_t *__restrict__ ordbase, uint32_t n, uint32_t *__restrict__ rank32)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rank32[val[i]] = ex[i + 1] - ex[ordbase[(uint32_t) (ck[i] >> 32)]];
 }
 
 __device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t c)
@@ -760,13 +976,44 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
           HIP_CHECK(hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming));
         }
       }
+      // heaps of HEAP_LARGE+1 .. HEAP_RANKED_MAX elements run on ranked 4-byte entries: rank their keys first
+      const uint32_t *rank32 = nullptr;
+      uint32_t *scratch32 = nullptr;
+      static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
+      if (e[1] > HEAP_LARGE && sift_k == 3 && !no_ranked)
+      {
+        unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
+        hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
+        prims::exclusive_scan<unsigned long long>(hc, hc, nh, b.scan_tmp, st);
+        unsigned long long tot2 = 0;
+        HIP_CHECK(hipMemcpyAsync(&tot2, hc + nh, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint32_t n_ord = (uint32_t) tot2, e2 = (uint32_t) (tot2 >> 32);
+        if (e2)
+        {
+          uint64_t *hck = b.hr_ck.as<uint64_t>(e2);
+          uint32_t *hval = b.hr_val.as<uint32_t>(e2), *hf = b.hr_f.as<uint32_t>((uint64_t) e2 + 1), *hord = b.hr_ord.as<uint32_t>(n_ord);
+          uint32_t *r32 = b.rank32.as<uint32_t>(n);
+          scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
+          hipLaunchKernelGGL(k_hr_gather, dim3(nh), dim3(256), 0, st, hl, nh, hc, key, hck, hval, hord);
+          int obits = 1;
+          while ((1u << obits) < n_ord && obits < 31) ++obits;
+          uint64_t *sk;
+          uint32_t *sv;
+          prims::radix_sort_pairs(hck, hval, e2, 0, 32 + obits, b.radix, st, &sk, &sv);
+          hipLaunchKernelGGL(k_hr_flags, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, e2, hf);
+          prims::exclusive_scan<uint32_t>(hf, hf, e2, b.scan_tmp, st);
+          hipLaunchKernelGGL(k_hr_scatter, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, sv, hf, hord, e2, r32);
+          rank32 = r32;
+        }
+      }
       auto launch = [&](auto k0, auto k1, auto k2) {
         // largest class first: its longest segment is the critical path of the whole sort
         HIP_CHECK(hipEventRecord(b.fork, st));
         int used = 0;
         auto side = [&](auto k, size_t lds, uint32_t lo, uint32_t hi) {
           HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-          hipLaunchKernelGGL(k, dim3(nh), dim3(64), lds, b.aux[used], hl, nh, key, idx, hscratch, lo, hi);
+          hipLaunchKernelGGL(k, dim3(nh), dim3(64), lds, b.aux[used], hl, nh, key, idx, hscratch, lo, hi, rank32, scratch32);
           HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
           ++used;
         };
@@ -788,7 +1035,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
             for (int c = 0; c < 4; ++c)
               if (e[1] > bounds[c + 1]) side(k1, ((size_t) bounds[c] + HEAP_PAD) * 8, bounds[c + 1], bounds[c]);
         }
-        hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch, 0u, HEAP_SMALL);
+        hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32);
         for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
       };
       switch (sift_k)

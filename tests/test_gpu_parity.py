@@ -161,7 +161,8 @@ def _median3_killer(n, div):
 
 
 @pytest.mark.parametrize("case", ["random_ties", "triangular_big", "many_groups", "sorted_and_reversed", "all_equal",
-                                  "killer_lds_small", "killer_lds_large", "killer_global", "killer_global_ties", "killer_mixed_ties"])
+                                  "killer_lds_small", "killer_lds_large", "killer_global", "killer_global_ties", "killer_mixed_ties",
+                                  "killer_ranked_lds", "killer_ranked_global", "killer_ranked_edge"])
 def test_std_sort_emulation_matches_libstdcxx(case):
     rng = np.random.default_rng(99)
     if case.startswith("killer"):
@@ -169,7 +170,11 @@ def test_std_sort_emulation_matches_libstdcxx(case):
                  "killer_lds_large": [_median3_killer(12000, 2), _median3_killer(20000, 3)],
                  "killer_global": [_median3_killer(100000, 1)],
                  "killer_global_ties": [_median3_killer(100000, 2), _median3_killer(20000, 2)],
-                 "killer_mixed_ties": [_median3_killer(100000, 3), _median3_killer(100000, 7), _median3_killer(300000, 2)]}[case]
+                 "killer_mixed_ties": [_median3_killer(100000, 3), _median3_killer(100000, 7), _median3_killer(300000, 2)],
+                 # heaps of 20 001 .. 65 536 elements run on ranked 4-byte entries (all in LDS up to 40 000)
+                 "killer_ranked_lds": [_median3_killer(30000, 1), _median3_killer(39000, 3), _median3_killer(24000, 40)],
+                 "killer_ranked_global": [_median3_killer(50000, 1), _median3_killer(64000, 5), _median3_killer(44000, 2) * 60000],
+                 "killer_ranked_edge": [_median3_killer(65536 + 60, 1), _median3_killer(65536 + 80, 2), _median3_killer(40060, 1)]}[case]
         key = np.concatenate(parts)
         off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
     elif case == "random_ties":
