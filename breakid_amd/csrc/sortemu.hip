@@ -365,6 +365,10 @@ template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uin
 // launches).  Per-lane state: h1 = hole + 1 (v40), len (v41; 0 = idle lane), value (idx v42, key v43).
 // Uniform state: next_t (s41), L+1 (s43), clz(L+1) (s44), budget (s45), t_end (s46).
 // GLB = false: heap in LDS at byte offset `base`; GLB = true: heap in global memory at `gptr` (base = 0).
+// Global variant: the loads of a step follow the stores of the step before in program order through the same L1,
+// which keeps them ordered per address for one wavefront; the loop therefore only waits for its loads
+// (`s_waitcnt vmcnt(0)` before their use also covers the older stores) and does not drain the store acknowledgements
+// at the top of every step (0.34 -> 0.26 us per step).  The caller drains before it reads the result.
 // one sift step of every pop in flight (idle lanes: len = 0 -> no store, state unchanged)
 #define BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                         \
   "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
@@ -470,7 +474,7 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   if (GLB)
     asm volatile(BK_HEAP_ASM("global_load_dwordx2 v[56:57], v60, s[62:63]\n", "global_load_dwordx2 v[58:59], v61, s[62:63]\n",
                              "global_load_dwordx4 v[46:49], v45, s[62:63]\n", "global_store_dwordx2 v52, v[50:51], s[62:63]\n",
-                             "global_store_dwordx2 v61, v[56:57], s[62:63]\n", "s_waitcnt vmcnt(0)\n", "s_waitcnt vmcnt(0)\n")
+                             "global_store_dwordx2 v61, v[56:57], s[62:63]\n", "s_waitcnt vmcnt(0)\n", "")
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
@@ -587,7 +591,7 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm32(uint32_t *bu
   if (GLB)
     asm volatile(BK_HEAP32_ASM("global_load_dword v56, v60, s[62:63]\n", "global_load_dword v58, v61, s[62:63]\n",
                                "global_load_dwordx2 v[46:47], v45, s[62:63]\n", "global_store_dword v52, v50, s[62:63]\n",
-                               "global_store_dword v61, v56, s[62:63]\n", "s_waitcnt vmcnt(0)\n", "s_waitcnt vmcnt(0)\n")
+                               "global_store_dword v61, v56, s[62:63]\n", "s_waitcnt vmcnt(0)\n", "")
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
