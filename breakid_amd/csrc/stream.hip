@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
   const uint64_t nq = a.n / ST_V;  // full quads
   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
   const uint64_t q_round = ((nq + stride - 1) / stride) * stride;  // whole blocks stay in the loop (barriers inside)
+  unsigned int iter_no = 0;
   for (uint64_t q = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; q < q_round; q += stride)
   {
     const bool live = q < nq;
@@ -512,9 +513,11 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
         }
       }
     }
-    __syncthreads();
-    // ---- flush bins that are at least half full (or on the last iteration) ----
+    // ---- flush bins that are at least half full (or on the last iteration); looked at every other iteration ----
     const bool last_iter = q + stride >= q_round;  // uniform per block: all lanes share the iteration index
+    ++iter_no;
+    if (!(last_iter || (iter_no & 1u) == 0)) continue;
+    __syncthreads();
     const unsigned int nc = min(s_ncand, (unsigned int) ST_CAND_CAP), ns = min(s_nsa, (unsigned int) ST_SA_CAP);
     const bool flush_c = nc && (nc >= ST_CAND_CAP / 2 || last_iter), flush_s = ns && (ns >= ST_SA_CAP / 2 || last_iter);
     if (flush_c || flush_s)
