@@ -147,8 +147,9 @@ def main():
                                     "configs[3]: targeted-panel shape, 500 fusion loci x 2000x, 20%% split reads, 10%% discordant, -%s clustering") % args.mode,
                        "records_per_gpu": int(n), "bytes_per_record_algorithmic": round(ks[1] / max(1, ks[2]) / n, 2),
                        "valid_clusters": int(n_valid), "w": w, "generator_s": round(gen_s, 2),
-                       "sharding": ("one sample of %d records, contiguous record range per rank; RCCL all-gather of candidates/tuples/cluster "
-                                    "summaries, all-reduce of coverage/depth counts; chr-pair groups owned by LPT" % n_total) if use_shards else "single GPU"},
+                       "sharding": ("one sample of %d records, contiguous record range per rank; RCCL all-to-all of candidates (to the owner of "
+                                    "the read-name hash) and of pairs (to the owner of the chr-pair group, LPT), all-gather of tuples/cluster "
+                                    "summaries, all-reduce of coverage/depth counts" % n_total) if use_shards else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_stream", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "avg_launch_ms": round(ks[0] / max(1, ks[2]), 4), "algorithmic_bytes_per_launch": int(ks[1] / max(1, ks[2]))},

@@ -38,7 +38,7 @@ EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "b
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
            "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort", "bk_debug_ahc", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
-           "bk_shard_own_groups", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_depth", "bk_shard_bp_finish"]
+           "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
 
 def lib():
@@ -84,6 +84,10 @@ def lib():
         L.bk_shard_set_buffer.argtypes = [vp, C.c_int, vp, C.c_uint64]
         L.bk_shard_group_sizes.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32)]
         L.bk_shard_own_groups.argtypes = [vp, vp, C.c_uint32]
+        L.bk_shard_route_candidates.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64))]
+        L.bk_shard_group_keys.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
+        L.bk_shard_route_pairs.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64))]
+        L.bk_shard_group_pairs.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
         L.bk_shard_bp_cov.argtypes = [vp, C.c_double, C.POINTER(vp), u64p]
         L.bk_shard_bp_vote.argtypes = [vp, C.c_double, vp]
         L.bk_shard_bp_depth.argtypes = [vp, C.POINTER(vp), u64p]

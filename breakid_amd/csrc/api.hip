@@ -69,6 +69,8 @@ struct bk_ctx
   uint64_t cand_cap = 0, split_cap = 0, sa_cap = 0;
   // sharded sample: this table is records [rec_base, rec_base + n) of the sample; gathered tables replace the local ones
   uint64_t rec_base = 0;
+  std::vector<uint64_t> route_counts;
+  JoinBufs jb2;  // grouping of the pairs received from the other ranks (jb still backs the routed send buffer)
   const Cand *ext_cand = nullptr;
   const bk_split *ext_split = nullptr;
   bk_cluster *ext_clusters = nullptr;
@@ -439,6 +441,51 @@ int bk_isize_stats(bk_ctx *ctx, double *mean, double *sd)
   });
 }
 
+// host-side group tables of ctx->jr and the reference's group order; `all_keys` (sharded sample: the chr-pair keys of
+// every rank) makes the cluster/pair `group` ordinals global
+static void finish_groups(bk_ctx *ctx, const std::vector<uint32_t> *all_keys)
+{
+  const uint32_t ng = ctx->jr.n_groups;
+  ctx->gkey_host.assign(ng, 0);
+  ctx->gstart_host.assign(ng + 1, 0);
+  if (ng)
+  {
+    HIP_CHECK(hipMemcpyAsync(ctx->gkey_host.data(), ctx->jr.gkey, ng * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipMemcpyAsync(ctx->gstart_host.data(), ctx->jr.gstart, (ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+  }
+  // the reference iterates groups in std::map<string> order of "chrA_chrB" (BreakID.cc:93,119)
+  auto key_name = [&](uint32_t k) {
+    int t1 = (int) (k / (uint32_t) (ctx->nt + 1)) - 1, t2 = (int) (k % (uint32_t) (ctx->nt + 1)) - 1;
+    return rname(ctx, t1) + "_" + rname(ctx, t2);
+  };
+  std::vector<std::string> keys(ng);
+  for (uint32_t g = 0; g < ng; ++g) keys[g] = key_name(ctx->gkey_host[g]);
+  ctx->lex_to_num.resize(ng);
+  std::iota(ctx->lex_to_num.begin(), ctx->lex_to_num.end(), 0u);
+  std::sort(ctx->lex_to_num.begin(), ctx->lex_to_num.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+  ctx->glex_host.assign(ng, 0);
+  if (!all_keys)
+    for (uint32_t l = 0; l < ng; ++l) ctx->glex_host[ctx->lex_to_num[l]] = l;
+  else
+  {
+    std::vector<std::string> names;
+    names.reserve(all_keys->size());
+    for (uint32_t k : *all_keys) names.push_back(key_name(k));
+    std::sort(names.begin(), names.end());
+    names.erase(std::unique(names.begin(), names.end()), names.end());
+    for (uint32_t g = 0; g < ng; ++g)
+    {
+      auto it = std::lower_bound(names.begin(), names.end(), keys[g]);
+      if (it == names.end() || *it != keys[g]) throw bk_error(BK_ERR_ARG, "bk_shard_group_pairs: a local group is missing from the global key list");
+      ctx->glex_host[g] = (uint32_t) (it - names.begin());
+    }
+  }
+  uint32_t *dg = ctx->d_glex.as<uint32_t>((uint64_t) ng + 1);
+  if (ng) HIP_CHECK(hipMemcpyAsync(dg, ctx->glex_host.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
+  join_assign_ids(ctx->jr, dg, ctx->st);
+}
+
 int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, uint32_t *n_groups)
 {
   return guarded(ctx, [&] {
@@ -451,33 +498,10 @@ int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, 
       Scope s(ctx, "mate_join");
       join_candidates(ctx->cand_ptr(), ctx->hc.n_cand, w, ctx->d_tprefix.get<uint32_t>(), ctx->nt, ctx->jb, ctx->st, ctx->jr);
     }
-    const uint32_t ng = ctx->jr.n_groups;
-    ctx->gkey_host.assign(ng, 0);
-    ctx->gstart_host.assign(ng + 1, 0);
-    if (ng)
-    {
-      HIP_CHECK(hipMemcpyAsync(ctx->gkey_host.data(), ctx->jr.gkey, ng * 4, hipMemcpyDeviceToHost, ctx->st));
-      HIP_CHECK(hipMemcpyAsync(ctx->gstart_host.data(), ctx->jr.gstart, (ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
-      HIP_CHECK(hipStreamSynchronize(ctx->st));
-    }
-    // the reference iterates groups in std::map<string> order of "chrA_chrB" (BreakID.cc:93,119)
-    std::vector<std::string> keys(ng);
-    for (uint32_t g = 0; g < ng; ++g)
-    {
-      int t1 = (int) (ctx->gkey_host[g] / (uint32_t) (ctx->nt + 1)) - 1, t2 = (int) (ctx->gkey_host[g] % (uint32_t) (ctx->nt + 1)) - 1;
-      keys[g] = rname(ctx, t1) + "_" + rname(ctx, t2);
-    }
-    ctx->lex_to_num.resize(ng);
-    std::iota(ctx->lex_to_num.begin(), ctx->lex_to_num.end(), 0u);
-    std::sort(ctx->lex_to_num.begin(), ctx->lex_to_num.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-    ctx->glex_host.assign(ng, 0);
-    for (uint32_t l = 0; l < ng; ++l) ctx->glex_host[ctx->lex_to_num[l]] = l;
-    uint32_t *dg = ctx->d_glex.as<uint32_t>((uint64_t) ng + 1);
-    if (ng) HIP_CHECK(hipMemcpyAsync(dg, ctx->glex_host.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
-    join_assign_ids(ctx->jr, dg, ctx->st);
+    finish_groups(ctx, nullptr);
     ctx->clustered = false;
     if (n_pairs) *n_pairs = ctx->jr.n_pairs;
-    if (n_groups) *n_groups = ng;
+    if (n_groups) *n_groups = ctx->jr.n_groups;
   });
 }
 
@@ -788,6 +812,61 @@ int bk_shard_own_groups(bk_ctx *ctx, const uint8_t *own, uint32_t n_groups)
   return guarded(ctx, [&] {
     if (n_groups != ctx->jr.n_groups) throw bk_error(BK_ERR_ARG, "bk_shard_own_groups: wrong group count");
     ctx->own_groups.assign(own, own + n_groups);
+  });
+}
+
+int bk_shard_route_candidates(bk_ctx *ctx, uint32_t world, void **dev, const uint64_t **counts)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done || ctx->ext_cand) throw bk_error(BK_ERR_ARG, "bk_shard_route_candidates: needs this shard's own candidates (after bk_shard_begin)");
+    if (!world || world > 4096 || !dev || !counts) throw bk_error(BK_ERR_ARG, "bk_shard_route_candidates: bad arguments");
+    *dev = route_candidates(ctx->d_cand.get<Cand>(), ctx->hc.n_cand, world, ctx->jb, ctx->st, ctx->route_counts);
+    *counts = ctx->route_counts.data();
+  });
+}
+
+int bk_shard_group_keys(bk_ctx *ctx, const uint32_t **keys, uint32_t *n_groups)
+{
+  return guarded(ctx, [&] {
+    if (keys) *keys = ctx->gkey_host.data();
+    if (n_groups) *n_groups = ctx->jr.n_groups;
+  });
+}
+
+int bk_shard_route_pairs(bk_ctx *ctx, const uint32_t *dest_of_group, uint32_t n_groups, uint32_t world, void **dev, const uint64_t **counts)
+{
+  return guarded(ctx, [&] {
+    if (n_groups != ctx->jr.n_groups || !world || !dev || !counts || (n_groups && !dest_of_group)) throw bk_error(BK_ERR_ARG, "bk_shard_route_pairs: bad arguments");
+    ctx->route_counts.assign(world, 0);
+    for (uint32_t g = 0; g < n_groups; ++g)
+    {
+      if (dest_of_group[g] >= world) throw bk_error(BK_ERR_ARG, "bk_shard_route_pairs: destination out of range");
+      ctx->route_counts[dest_of_group[g]] += ctx->gstart_host[g + 1] - ctx->gstart_host[g];
+    }
+    std::vector<uint64_t> base(world, 0), off(n_groups, 0);
+    for (uint32_t d = 1; d < world; ++d) base[d] = base[d - 1] + ctx->route_counts[d - 1];
+    for (uint32_t g = 0; g < n_groups; ++g)
+    {
+      off[g] = base[dest_of_group[g]];
+      base[dest_of_group[g]] += ctx->gstart_host[g + 1] - ctx->gstart_host[g];
+    }
+    *dev = route_pairs(ctx->jr, off, ctx->jb, ctx->st);
+    *counts = ctx->route_counts.data();
+  });
+}
+
+int bk_shard_group_pairs(bk_ctx *ctx, const void *pairs_dev, uint64_t n, const uint32_t *all_keys, uint32_t n_all_keys)
+{
+  return guarded(ctx, [&] {
+    if ((n && !pairs_dev) || (n_all_keys && !all_keys)) throw bk_error(BK_ERR_ARG, "bk_shard_group_pairs: null input");
+    {
+      Scope s(ctx, "group_pairs");
+      group_pairs((const bk_pair *) pairs_dev, n, ctx->nt, ctx->jb2, ctx->st, ctx->jr);
+    }
+    std::vector<uint32_t> keys(all_keys, all_keys + n_all_keys);
+    finish_groups(ctx, &keys);
+    ctx->own_groups.clear();  // the table holds exactly the groups this rank owns
+    ctx->clustered = false;
   });
 }
 

@@ -141,11 +141,48 @@ __global__ __launch_bounds__(256) void k_assign_ids(bk_pair *__restrict__ pairs,
   pairs[i].group = glex[g];
   pairs[i].id = (uint32_t) (i - gstart[g]);
 }
+// sort key of a pair: (numeric chr-pair key, discovery index)
+__global__ __launch_bounds__(256) void k_pair_keys(const bk_pair *__restrict__ p, uint64_t n, int32_t nt, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t gk = (uint64_t) (uint32_t) (p[i].p1_tid + 1) * (uint64_t) (nt + 1) + (uint64_t) (uint32_t) (p[i].p2_tid + 1);
+  okey[i] = (gk << 32) | p[i].rec;
+  oval[i] = (uint32_t) i;
+}
+// dst[off[g] + rank inside group g] = src: groups leave for their destination rank as contiguous blocks
+__global__ __launch_bounds__(256) void k_route_pairs(const bk_pair *__restrict__ src, const uint32_t *__restrict__ gof, const uint64_t *__restrict__ gstart,
+                                                     const uint64_t *__restrict__ off, uint64_t n, bk_pair *__restrict__ dst)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = gof[i];
+  dst[off[g] + (i - gstart[g])] = src[i];
+}
+__global__ __launch_bounds__(256) void k_cand_dest(const Cand *__restrict__ c, uint64_t n, uint32_t world, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  key[i] = (uint32_t) ((c[i].qhash >> 17) % world);
+  val[i] = (uint32_t) i;
+}
+// first position of every destination in the sorted key array (destinations that receive nothing stay unset)
+__global__ __launch_bounds__(256) void k_dest_starts(const uint64_t *__restrict__ key, uint64_t n, unsigned long long *__restrict__ starts)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0 || key[i] != key[i - 1]) starts[key[i]] = i;
+}
+__global__ __launch_bounds__(256) void k_gather_cand(const Cand *__restrict__ in, const uint32_t *__restrict__ perm, uint64_t n, Cand *__restrict__ out)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[perm[i]];
+}
 }  // namespace
 
-void join_candidates(const Cand *cand, uint64_t n_cand, double w, const uint32_t *tprefix, int32_t nt, JoinBufs &b, hipStream_t st, JoinResult &res)
+// mate join proper: candidates -> pairs in no particular order (b.unsorted, keys in b.okey / b.oval)
+static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, const uint32_t *tprefix, int32_t nt, JoinBufs &b, hipStream_t st)
 {
-  res = JoinResult();
   if (n_cand > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 discordant candidates");
   unsigned long long *counter = b.counter.as<unsigned long long>(2);
   uint32_t *err = (uint32_t *) (counter + 1);
@@ -169,8 +206,14 @@ void join_candidates(const Cand *cand, uint64_t n_cand, double w, const uint32_t
   HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   if ((uint32_t) host[1]) throw bk_error(BK_ERR_LIMIT, "more than 4096 candidate records share one read-name hash");
-  uint64_t np = host[0];
-  if (np > cap) throw bk_error(BK_ERR_LIMIT, "pair capacity exceeded");  // cannot happen: one pair per two candidates
+  if (host[0] > cap) throw bk_error(BK_ERR_LIMIT, "pair capacity exceeded");  // cannot happen: one pair per two candidates
+  return host[0];
+}
+
+// pairs in any order (keys already in okey / oval) -> table sorted by (chr-pair key, discovery index) + group index
+static void group_sorted(const bk_pair *unsorted, uint64_t *okey, uint32_t *oval, uint64_t np, int32_t nt, JoinBufs &b, hipStream_t st, JoinResult &res)
+{
+  res = JoinResult();
   res.n_pairs = np;
   bk_pair *pairs = b.pairs.as<bk_pair>(np + 1);
   uint32_t *gof = b.gof.as<uint32_t>(np + 1);
@@ -195,6 +238,59 @@ void join_candidates(const Cand *cand, uint64_t n_cand, double w, const uint32_t
   hipLaunchKernelGGL(k_group_starts, dim3(cdiv(np, 256)), dim3(256), 0, st, gflag, gscan, ks, np, gstart, gkey, gof);
   res.gstart = gstart;
   res.gkey = gkey;
+}
+
+void join_candidates(const Cand *cand, uint64_t n_cand, double w, const uint32_t *tprefix, int32_t nt, JoinBufs &b, hipStream_t st, JoinResult &res)
+{
+  const uint64_t np = join_raw_pairs(cand, n_cand, w, tprefix, nt, b, st);
+  group_sorted(b.unsorted.get<bk_pair>(), b.okey.get<uint64_t>(), b.oval.get<uint32_t>(), np, nt, b, st, res);
+}
+
+void group_pairs(const bk_pair *raw, uint64_t np, int32_t nt, JoinBufs &b, hipStream_t st, JoinResult &res)
+{
+  if (np > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 pairs");
+  uint64_t *okey = b.okey.as<uint64_t>(np + 1);
+  uint32_t *oval = b.oval.as<uint32_t>(np + 1);
+  if (np) hipLaunchKernelGGL(k_pair_keys, dim3(cdiv(np, 256)), dim3(256), 0, st, raw, np, nt, okey, oval);
+  group_sorted(raw, okey, oval, np, nt, b, st, res);
+}
+
+Cand *route_candidates(const Cand *cand, uint64_t n, uint32_t world, JoinBufs &b, hipStream_t st, std::vector<uint64_t> &counts)
+{
+  counts.assign(world, 0);
+  Cand *out = b.route_cand.as<Cand>(n + 1);
+  if (n == 0) return out;
+  if (n > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 discordant candidates");
+  unsigned long long *dc = b.route_cnt.as<unsigned long long>(world);
+  HIP_CHECK(hipMemsetAsync(dc, 0xFF, (size_t) world * 8, st));
+  uint64_t *key = b.key.as<uint64_t>(n);
+  uint32_t *val = b.val.as<uint32_t>(n);
+  hipLaunchKernelGGL(k_cand_dest, dim3(cdiv(n, 256)), dim3(256), 0, st, cand, n, world, key, val);
+  int bits = 1;
+  while ((1u << bits) < world && bits < 31) ++bits;
+  uint64_t *ks;
+  uint32_t *vs;
+  prims::radix_sort_pairs(key, val, n, 0, bits, b.radix, st, &ks, &vs);
+  hipLaunchKernelGGL(k_gather_cand, dim3(cdiv(n, 256)), dim3(256), 0, st, cand, vs, n, out);
+  hipLaunchKernelGGL(k_dest_starts, dim3(cdiv(n, 256)), dim3(256), 0, st, ks, n, dc);
+  std::vector<uint64_t> starts(world + 1, n);
+  HIP_CHECK(hipMemcpyAsync(starts.data(), dc, (size_t) world * 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (uint32_t d = world; d-- > 0;)
+    if (starts[d] == ~0ull) starts[d] = starts[d + 1];  // nothing for rank d
+  for (uint32_t d = 0; d < world; ++d) counts[d] = starts[d + 1] - starts[d];
+  return out;
+}
+
+bk_pair *route_pairs(const JoinResult &jr, const std::vector<uint64_t> &off_of_group, JoinBufs &b, hipStream_t st)
+{
+  bk_pair *out = b.route_pairs.as<bk_pair>(jr.n_pairs + 1);
+  if (jr.n_pairs == 0) return out;
+  uint64_t *doff = b.route_off.as<uint64_t>((uint64_t) jr.n_groups + 1);
+  HIP_CHECK(hipMemcpyAsync(doff, off_of_group.data(), (size_t) jr.n_groups * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_route_pairs, dim3(cdiv(jr.n_pairs, 256)), dim3(256), 0, st, jr.pairs, jr.gof, jr.gstart, doff, jr.n_pairs, out);
+  HIP_CHECK(hipStreamSynchronize(st));
+  return out;
 }
 
 void join_assign_ids(JoinResult &res, const uint32_t *glex_dev, hipStream_t st)

@@ -81,6 +81,21 @@ class Comm:
         return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(t.device)
 
 
+    def all_to_all_var(self, t, send_bytes):
+        """uint8 tensor laid out as world contiguous blocks of send_bytes[d] bytes for rank d -> concatenation of the
+        blocks every rank sent here, in rank order (device tensor).  One all-to-all: each GPU talks to its 7 xGMI peers
+        directly, so the volume per rank stays O(total / world)."""
+        send_bytes = [int(x) for x in send_bytes]
+        if not self.on or self.world == 1:
+            return t[: send_bytes[0]]
+        per = self.all_gather_scalars(send_bytes)          # per[r][d] = bytes rank r sends to rank d
+        recv_bytes = [int(per[r][self.rank]) for r in range(self.world)]
+        x = self._to_comm(t[: sum(send_bytes)].contiguous())
+        out = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=x.device)
+        dist.all_to_all_single(out, x, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
+        return out.to(t.device)
+
+
 def lpt_owner(sizes, world):
     """Longest-processing-time assignment of chr-pair groups to ranks (deterministic on every rank)."""
     order = sorted(range(len(sizes)), key=lambda g: (-int(sizes[g]), g))
@@ -97,8 +112,9 @@ class ShardedRun:
     """Drives one rank's context through the sharded pipeline.  After run() every rank's context holds the whole
     cluster table (ctx.fetch(STAGE_CLUSTERS))."""
 
-    def __init__(self, ctx: capi.Context, comm: Comm):
+    def __init__(self, ctx: capi.Context, comm: Comm, routed=True):
         self.ctx, self.comm = ctx, comm
+        self.routed = routed  # False: the simpler replicated join (all-gather of every candidate to every rank)
         self._keep = []
 
     def _buffer(self, which):
@@ -114,6 +130,43 @@ class ShardedRun:
         self._keep.append(allt)
         self.ctx._check(L.bk_shard_set_buffer(h, which, C.c_void_p(allt.data_ptr() if allt.numel() else 0), allt.numel() // eb))
         return allt.numel() // eb
+
+    def _routed_join(self, qual, w):
+        """candidates -> owner of the read-name hash (all-to-all) -> local mate join -> pairs -> owner of the
+        chr-pair group (all-to-all) -> grouped table of exactly this rank's groups."""
+        ctx, comm = self.ctx, self.comm
+        L, h, dev = ctx.L, ctx.h, comm.device
+        W = comm.world
+        ptr, cnt = C.c_void_p(), C.POINTER(C.c_uint64)()
+        ctx._check(L.bk_shard_route_candidates(h, W, C.byref(ptr), C.byref(cnt)))
+        counts = [int(cnt[d]) for d in range(W)]
+        send = tensor_from_ptr(ptr.value, sum(counts) * 32, dev)
+        mine = comm.all_to_all_var(send, [c * 32 for c in counts])
+        self._keep.append(mine)
+        ctx._check(L.bk_shard_set_buffer(h, abi.BUF_CANDIDATES, C.c_void_p(mine.data_ptr() if mine.numel() else 0), mine.numel() // 32))
+        ctx.discordant_pairs(qual, w)  # joins the read names this rank owns
+        starts, ng, keys = C.POINTER(C.c_uint64)(), C.c_uint32(), C.POINTER(C.c_uint32)()
+        ctx._check(L.bk_shard_group_sizes(h, C.byref(starts), C.byref(ng)))
+        ctx._check(L.bk_shard_group_keys(h, C.byref(keys), C.byref(ng)))
+        local = np.zeros((ng.value, 2), np.int64)
+        for g in range(ng.value):
+            local[g, 0] = keys[g]
+            local[g, 1] = starts[g + 1] - starts[g]
+        allk = comm.all_gather_var(torch.from_numpy(local.reshape(-1)).view(torch.uint8).to(dev)).cpu().numpy().view(np.int64).reshape(-1, 2)
+        tot = {}
+        for k, sz in allk:
+            tot[int(k)] = tot.get(int(k), 0) + int(sz)
+        gkeys = sorted(tot)                                   # numeric key order, the same list on every rank
+        owner = dict(zip(gkeys, lpt_owner([tot[k] for k in gkeys], W)))
+        dest = np.asarray([owner[int(keys[g])] for g in range(ng.value)], dtype=np.uint32)
+        ctx._check(L.bk_shard_route_pairs(h, dest.ctypes.data if len(dest) else None, ng.value, W, C.byref(ptr), C.byref(cnt)))
+        counts = [int(cnt[d]) for d in range(W)]
+        send = tensor_from_ptr(ptr.value, sum(counts) * 48, dev)
+        pairs = comm.all_to_all_var(send, [c * 48 for c in counts])
+        self._keep.append(pairs)
+        ak = np.asarray(gkeys, dtype=np.uint32)
+        ctx._check(L.bk_shard_group_pairs(h, C.c_void_p(pairs.data_ptr() if pairs.numel() else 0), pairs.numel() // 48,
+                                          ak.ctypes.data if len(ak) else None, len(ak)))
 
     def run(self, rec_base, qual=20, fast=True):
         ctx, comm = self.ctx, self.comm
@@ -144,15 +197,18 @@ class ShardedRun:
         ctx._check(L.bk_shard_sd_finish(h, C.c_void_p(all_ex.data_ptr() if all_ex.numel() else 0), all_ex.numel() // 16, int(per[:, 0].sum()),
                                         C.byref(mean), C.byref(sd)))
         w = capi.w_from(mean.value, sd.value)
-        # candidates -> replicated mate join
-        self._gather_into(abi.BUF_CANDIDATES)
-        ctx.discordant_pairs(qual, w)
-        starts, ng = C.POINTER(C.c_uint64)(), C.c_uint32()
-        ctx._check(L.bk_shard_group_sizes(h, C.byref(starts), C.byref(ng)))
-        sizes = [int(starts[g + 1] - starts[g]) for g in range(ng.value)]
-        owner = lpt_owner(sizes, comm.world)
-        own = np.asarray([1 if o == comm.rank else 0 for o in owner], dtype=np.uint8)
-        ctx._check(L.bk_shard_own_groups(h, own.ctypes.data if len(own) else None, ng.value))
+        if self.routed:
+            self._routed_join(qual, w)
+        else:
+            # candidates -> replicated mate join, every rank then masks / clusters the groups it owns
+            self._gather_into(abi.BUF_CANDIDATES)
+            ctx.discordant_pairs(qual, w)
+            starts, ng = C.POINTER(C.c_uint64)(), C.c_uint32()
+            ctx._check(L.bk_shard_group_sizes(h, C.byref(starts), C.byref(ng)))
+            sizes = [int(starts[g + 1] - starts[g]) for g in range(ng.value)]
+            owner = lpt_owner(sizes, comm.world)
+            own = np.asarray([1 if o == comm.rank else 0 for o in owner], dtype=np.uint8)
+            ctx._check(L.bk_shard_own_groups(h, own.ctypes.data if len(own) else None, ng.value))
         ctx.mask_and_cluster(w, fast)
         ctx.cluster_summary(w)
         # tuples and cluster summaries to everybody

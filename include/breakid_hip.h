@@ -179,6 +179,17 @@ int bk_shard_buffer(bk_ctx *ctx, int which, void **dev, uint64_t *count, uint32_
 int bk_shard_set_buffer(bk_ctx *ctx, int which, const void *dev, uint64_t count); /* gathered table, device, caller keeps it alive */
 int bk_shard_group_sizes(bk_ctx *ctx, const uint64_t **starts, uint32_t *n_groups); /* n_groups+1 pair offsets, numeric key order */
 int bk_shard_own_groups(bk_ctx *ctx, const uint8_t *own, uint32_t n_groups);
+/* Routed exchange (scales with the number of GPUs: no rank joins or sorts more than its share).  Instead of the
+ * replicated join above:
+ *   bk_shard_route_candidates -> all-to-all -> bk_shard_set_buffer(BK_BUF_CANDIDATES); bk_discordant_pairs joins the
+ *     read names this rank owns ((qhash >> 17) % world)
+ *   bk_shard_group_keys + bk_shard_group_sizes -> all-gather of (key, size) -> owner per chr-pair key (LPT on the totals)
+ *   bk_shard_route_pairs -> all-to-all -> bk_shard_group_pairs: the table of exactly the groups this rank owns, `group`
+ *     ordinals global; then bk_mask_and_cluster, bk_cluster_summary and the gathers / reductions as above. */
+int bk_shard_route_candidates(bk_ctx *ctx, uint32_t world, void **dev, const uint64_t **counts); /* 32-byte candidates ordered by destination; counts[world] */
+int bk_shard_group_keys(bk_ctx *ctx, const uint32_t **keys, uint32_t *n_groups);                /* (p1_tid+1)*(n_targets+1)+(p2_tid+1) per group */
+int bk_shard_route_pairs(bk_ctx *ctx, const uint32_t *dest_of_group, uint32_t n_groups, uint32_t world, void **dev, const uint64_t **counts); /* bk_pair rows ordered by destination */
+int bk_shard_group_pairs(bk_ctx *ctx, const void *pairs_dev, uint64_t n, const uint32_t *all_keys, uint32_t n_all_keys);
 int bk_shard_bp_cov(bk_ctx *ctx, double w, void **cov_dev, uint64_t *n);   /* u32[2*n_clusters] partial coverage counts */
 int bk_shard_bp_vote(bk_ctx *ctx, double w, const void *cov_total_dev);
 int bk_shard_bp_depth(bk_ctx *ctx, void **depth_dev, uint64_t *n);         /* u32[2*n_clusters] partial depth counts */

@@ -31,6 +31,7 @@ def concat_shards(hosts):
 
 def main():
     n_per_rank, seed, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    routed = (sys.argv[4] if len(sys.argv) > 4 else "routed") == "routed"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", 0)
@@ -40,7 +41,7 @@ def main():
     rec_base = int(sum(counts[:rank]))
     ctx = capi.Context(contigs, device=0)
     ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
-    run = sharded.ShardedRun(ctx, comm)
+    run = sharded.ShardedRun(ctx, comm, routed=routed)
     w = run.run(rec_base, qual=20, fast=(mode == "fast"))
     got, _ = ctx.fetch(abi.STAGE_CLUSTERS)
     ok = True

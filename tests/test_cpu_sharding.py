@@ -42,6 +42,11 @@ def _worker(rank, world, port, q):
     ok &= m.tolist() == [7]
     sc = comm.all_gather_scalars([rank, 5 - rank])
     ok &= sc.tolist() == [[0, 5], [1, 4]]
+    # variable all-to-all: rank r sends (r + 1 + d) bytes valued 16*r + d to rank d (one of the blocks is empty)
+    blocks = [torch.full((0 if (rank == 1 and d == 0) else rank + 1 + d,), 16 * rank + d, dtype=torch.uint8) for d in range(world)]
+    got = comm.all_to_all_var(torch.cat(blocks), [b.numel() for b in blocks])
+    want = torch.cat([torch.full((0 if (r == 1 and rank == 0) else r + 1 + rank,), 16 * r + rank, dtype=torch.uint8) for r in range(world)])
+    ok &= torch.equal(got, want)
     owner = sharded.lpt_owner([9, 7, 7, 5, 1], world)
     q.put((rank, bool(ok), owner))
     dist.destroy_process_group()

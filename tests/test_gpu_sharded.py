@@ -33,11 +33,13 @@ def test_world1_sharded_equals_plain_run():
     b.close()
 
 
-@pytest.mark.parametrize("mode", ["fast", "ahc"])
-def test_two_rank_sharded_sample_matches_oracle(mode):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611" if mode == "fast" else "29612")
+@pytest.mark.parametrize("mode,exchange", [("fast", "routed"), ("ahc", "routed"), ("fast", "replicated")])
+def test_two_rank_sharded_sample_matches_oracle(mode, exchange):
+    """routed = candidates / pairs travel to their owner ranks by all-to-all; replicated = every rank joins everything"""
+    port = {"fastrouted": "29611", "ahcrouted": "29612", "fastreplicated": "29613"}[mode + exchange]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     n = "600000" if mode == "fast" else "150000"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "shard_worker.py"), n, "77", mode]
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "shard_worker.py"), n, "77", mode, exchange]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
