@@ -38,7 +38,7 @@ EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "b
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
            "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort", "bk_debug_ahc", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
-           "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_depth", "bk_shard_bp_finish"]
+           "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
 
 def lib():
@@ -90,6 +90,8 @@ def lib():
         L.bk_shard_group_pairs.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32]
         L.bk_shard_bp_cov.argtypes = [vp, C.c_double, C.POINTER(vp), u64p]
         L.bk_shard_bp_vote.argtypes = [vp, C.c_double, vp]
+        L.bk_shard_bp_vote_slice.argtypes = [vp, C.c_double, vp, C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
+        L.bk_shard_bp_set_voted.argtypes = [vp, vp]
         L.bk_shard_bp_depth.argtypes = [vp, C.POINTER(vp), u64p]
         L.bk_shard_bp_finish.argtypes = [vp, vp]
         L.bk_qname_hash.restype = C.c_uint64

@@ -899,6 +899,29 @@ int bk_shard_bp_vote(bk_ctx *ctx, double w, const void *cov_total_dev)
   });
 }
 
+int bk_shard_bp_vote_slice(bk_ctx *ctx, double w, const void *cov_total_dev, uint64_t lo, uint64_t hi, void **clusters_dev, void **voted_dev)
+{
+  return guarded(ctx, [&] {
+    if (lo > hi || hi > ctx->n_clusters || !clusters_dev || !voted_dev) throw bk_error(BK_ERR_ARG, "bk_shard_bp_vote_slice: bad range");
+    ensure_splits_sorted(ctx);
+    bp_vote(ctx->d_split.get<bk_split>(), ctx->hc.n_split, ctx->clusters_ptr() + lo, hi - lo, w, (int) ctx->hc.max_span,
+            cov_total_dev ? (const uint32_t *) cov_total_dev + 2 * lo : nullptr, ctx->d_hdr.get<int32_t>(), ctx->bb, ctx->st);
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    *clusters_dev = ctx->clusters_ptr() + lo;
+    *voted_dev = ctx->bb.voted.p;
+  });
+}
+
+int bk_shard_bp_set_voted(bk_ctx *ctx, const void *voted_all_dev)
+{
+  return guarded(ctx, [&] {
+    uint32_t *v = ctx->bb.voted.as<uint32_t>(ctx->n_clusters + 1);
+    if (ctx->n_clusters && voted_all_dev != v)
+      HIP_CHECK(hipMemcpyAsync(v, voted_all_dev, ctx->n_clusters * 4, hipMemcpyDeviceToDevice, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+  });
+}
+
 int bk_shard_bp_depth(bk_ctx *ctx, void **depth_dev, uint64_t *n)
 {
   return guarded(ctx, [&] {

@@ -219,7 +219,18 @@ class ShardedRun:
         ctx._check(L.bk_shard_bp_cov(h, w, C.byref(p), C.byref(n)))
         cov = comm.all_reduce(tensor_from_ptr(p.value, n.value * 4, dev).view(torch.int32).clone())
         self._keep.append(cov)
-        ctx._check(L.bk_shard_bp_vote(h, w, C.c_void_p(cov.data_ptr() if cov.numel() else 0)))
+        if self.routed and comm.world > 1:
+            # every rank votes for its slice of the cluster table; rows and flags of the slices are gathered in rank order
+            lo, hi = ncl * comm.rank // comm.world, ncl * (comm.rank + 1) // comm.world
+            cp, vp_ = C.c_void_p(), C.c_void_p()
+            ctx._check(L.bk_shard_bp_vote_slice(h, w, C.c_void_p(cov.data_ptr() if cov.numel() else 0), lo, hi, C.byref(cp), C.byref(vp_)))
+            rows = comm.all_gather_var(tensor_from_ptr(cp.value, (hi - lo) * 72, dev).clone())
+            flags = comm.all_gather_var(tensor_from_ptr(vp_.value, (hi - lo) * 4, dev).clone())
+            self._keep += [rows, flags]
+            ctx._check(L.bk_shard_set_buffer(h, abi.BUF_CLUSTERS, C.c_void_p(rows.data_ptr() if rows.numel() else 0), rows.numel() // 72))
+            ctx._check(L.bk_shard_bp_set_voted(h, C.c_void_p(flags.data_ptr() if flags.numel() else 0)))
+        else:
+            ctx._check(L.bk_shard_bp_vote(h, w, C.c_void_p(cov.data_ptr() if cov.numel() else 0)))
         ctx._check(L.bk_shard_bp_depth(h, C.byref(p), C.byref(n)))
         dep = comm.all_reduce(tensor_from_ptr(p.value, n.value * 4, dev).view(torch.int32).clone())
         self._keep.append(dep)

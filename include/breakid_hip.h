@@ -192,6 +192,10 @@ int bk_shard_route_pairs(bk_ctx *ctx, const uint32_t *dest_of_group, uint32_t n_
 int bk_shard_group_pairs(bk_ctx *ctx, const void *pairs_dev, uint64_t n, const uint32_t *all_keys, uint32_t n_all_keys);
 int bk_shard_bp_cov(bk_ctx *ctx, double w, void **cov_dev, uint64_t *n);   /* u32[2*n_clusters] partial coverage counts */
 int bk_shard_bp_vote(bk_ctx *ctx, double w, const void *cov_total_dev);
+/* the vote of clusters [lo, hi) only (every rank takes a slice); the voted rows (72 B) and flags (u32) of the slices are
+ * then all-gathered in rank order: BK_BUF_CLUSTERS via bk_shard_set_buffer, the flags via bk_shard_bp_set_voted */
+int bk_shard_bp_vote_slice(bk_ctx *ctx, double w, const void *cov_total_dev, uint64_t lo, uint64_t hi, void **clusters_dev, void **voted_dev);
+int bk_shard_bp_set_voted(bk_ctx *ctx, const void *voted_all_dev);
 int bk_shard_bp_depth(bk_ctx *ctx, void **depth_dev, uint64_t *n);         /* u32[2*n_clusters] partial depth counts */
 int bk_shard_bp_finish(bk_ctx *ctx, const void *depth_total_dev);
 
