@@ -27,30 +27,65 @@ __global__ __launch_bounds__(256) void k_group_kmax(const uint32_t *__restrict__
   else if (live)
     atomicMax(&kmax[g], v);
 }
+// Members of a cluster are mostly neighbours in the list (fast clustering: always), so every wave first reduces its
+// runs of equal slots with a segmented scan (head flags) and only the last lane of a run touches the accumulators:
+// ~2 instead of 64 atomics per field and wave.
 __global__ __launch_bounds__(256) void k_accumulate(const bk_pair *__restrict__ pairs, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ gof,
                                                     const uint32_t *__restrict__ cl, const uint32_t *__restrict__ slotbase, uint64_t n, ClusterAcc acc)
 {
-  uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const bk_pair pr = pairs[idx[p]];
-  uint32_t s = slotbase[gof[p]] + cl[p];
-  atomicAdd(&acc.n[s], 1u);
-  atomicAdd(&acc.sum1[s], (unsigned long long) pr.p1_pos);
-  atomicAdd(&acc.sum2[s], (unsigned long long) pr.p2_pos);
-  atomicMin(&acc.min1[s], pr.p1_pos);
-  atomicMax(&acc.max1[s], pr.p1_pos);
-  atomicMin(&acc.min2[s], pr.p2_pos);
-  atomicMax(&acc.max2[s], pr.p2_pos);
-  uint32_t type;
-  if (pr.p1_tid != pr.p2_tid)
-    type = BK_TYPE_DIFF_CHR;
-  else
+  const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = p < n;
+  uint32_t s = 0xFFFFFFFFu, cnt = 0, mn1 = 0xFFFFFFFFu, mx1 = 0, mn2 = 0xFFFFFFFFu, mx2 = 0, type = 0;
+  unsigned long long s1 = 0, s2 = 0;
+  if (live)
   {
-    type = 0;
-    if (pr.p1_rev && !pr.p2_rev) type |= BK_TYPE_ABS_REVERSE;
-    if (pr.p1_rev == pr.p2_rev) type |= BK_TYPE_SAME_ORIENT;
-    if (!pr.p1_rev && pr.p2_rev) type |= BK_TYPE_DEFAULT_ORIENT;
+    const bk_pair pr = pairs[idx[p]];
+    s = slotbase[gof[p]] + cl[p];
+    cnt = 1;
+    s1 = pr.p1_pos;
+    s2 = pr.p2_pos;
+    mn1 = mx1 = pr.p1_pos;
+    mn2 = mx2 = pr.p2_pos;
+    if (pr.p1_tid != pr.p2_tid)
+      type = BK_TYPE_DIFF_CHR;
+    else
+    {
+      if (pr.p1_rev && !pr.p2_rev) type |= BK_TYPE_ABS_REVERSE;
+      if (pr.p1_rev == pr.p2_rev) type |= BK_TYPE_SAME_ORIENT;
+      if (!pr.p1_rev && pr.p2_rev) type |= BK_TYPE_DEFAULT_ORIENT;
+    }
   }
+  const uint32_t s_prev = __shfl_up(s, 1, 64), s_next = __shfl_down(s, 1, 64);
+  bool head = lane == 0 || s_prev != s;
+  const bool tail = lane == 63 || s_next != s;
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint32_t o_cnt = __shfl_up(cnt, d, 64), o_mn1 = __shfl_up(mn1, d, 64), o_mx1 = __shfl_up(mx1, d, 64), o_mn2 = __shfl_up(mn2, d, 64),
+                   o_mx2 = __shfl_up(mx2, d, 64), o_type = __shfl_up(type, d, 64);
+    const unsigned long long o_s1 = __shfl_up(s1, d, 64), o_s2 = __shfl_up(s2, d, 64);
+    const int o_head = __shfl_up((int) head, d, 64);
+    if (lane >= d && !head)
+    {
+      cnt += o_cnt;
+      s1 += o_s1;
+      s2 += o_s2;
+      mn1 = min(mn1, o_mn1);
+      mx1 = max(mx1, o_mx1);
+      mn2 = min(mn2, o_mn2);
+      mx2 = max(mx2, o_mx2);
+      type |= o_type;
+      head = o_head != 0;
+    }
+  }
+  if (!live || !tail) return;
+  atomicAdd(&acc.n[s], cnt);
+  atomicAdd(&acc.sum1[s], s1);
+  atomicAdd(&acc.sum2[s], s2);
+  atomicMin(&acc.min1[s], mn1);
+  atomicMax(&acc.max1[s], mx1);
+  atomicMin(&acc.min2[s], mn2);
+  atomicMax(&acc.max2[s], mx2);
   atomicOr(&acc.type[s], type);
 }
 // slot -> (group, id): group found by binary search on slotbase

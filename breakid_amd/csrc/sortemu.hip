@@ -751,12 +751,23 @@ __device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint3
 }
 
 // lr[c] = (#L-stopper at c) | (#R-stopper at c) << 32 ; segof[c] = segment index
+// Live segments hold more than 16 elements, so the 256 consecutive compact indices of a block span at most 16
+// segments: one full binary search per block, then a 4-step search inside that window per lane.
 __global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
                                                   unsigned long long *__restrict__ lr, uint32_t *__restrict__ segof)
 {
+  __shared__ uint32_t s_first;
+  if (threadIdx.x == 0) s_first = find_seg(segs, ns, blockIdx.x * blockDim.x);
+  __syncthreads();
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= na) return;
-  const uint32_t s = find_seg(segs, ns, c);
+  uint32_t lo = s_first + 1, hi = s_first + 17 < ns ? s_first + 17 : ns;  // answer - 1 lies in [s_first, hi)
+  while (lo < hi)
+  {
+    uint32_t m = (lo + hi) >> 1;
+    if (segs[m].cbase <= c) lo = m + 1; else hi = m;
+  }
+  const uint32_t s = lo - 1;
   segof[c] = s;
   const Seg sg = segs[s];
   unsigned long long v = 0;
