@@ -245,50 +245,11 @@ template <class M> __device__ void make_heap_wave(const M &mem, const uint32_t m
 // each) + at most one launch.  The wave is alone on its critical path, so the loop is written branch-free: the
 // values a launch needs (the root and the leaf about to be detached) are fetched together with the children of
 // the holes, idle lanes run the same instructions with len = 0.
-template <int V, class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m, const uint32_t stop)
+template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m, const uint32_t stop)
 {
   if (m < 2 || m <= stop) return;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t t_end = m - (stop < 1 ? 1 : stop) + 1;  // pops t = 1 .. t_end-1 detach leaves m-1 .. stop
-  if (V == 1)
-  {
-    bool active = false;
-    uint32_t hole = 0, len = 0;
-    hent v = 0;
-    uint32_t next_t = 1;
-    int since = 2;
-    const unsigned long long max_iter = 64ull * m + 4096ull;
-    for (unsigned long long iter = 0; iter < max_iter; ++iter)
-    {
-      if (active) active = sift_step(mem, hole, len, v);
-      mem.step_sync();
-      ++since;
-      bool launched = false;
-      if (next_t < t_end)
-      {
-        const uint32_t L = m - next_t;
-        const bool blocks = active && anc_or_self(hole, L);
-        if (since >= 2 && __ballot(blocks) == 0ull)
-        {
-          if (lane == (next_t & 63u))
-          {
-            v = mem.ld(L);
-            mem.st(L, mem.ld(0));
-            hole = 0;
-            len = L;
-            active = true;
-          }
-          mem.launch_sync();
-          since = 0;
-          ++next_t;
-          launched = true;
-        }
-      }
-      if (!launched && next_t >= t_end && __ballot(active) == 0ull) break;
-    }
-    mem.step_sync();
-    return;
-  }
   uint32_t hole = 0, len = 0, lvl = 0;  // len == 0 <=> idle lane; lvl = depth of the hole
   uint32_t vk = 0, vx = 0;              // key / index halves of the value being sifted
   uint32_t next_t = 1, since = 2;
@@ -616,7 +577,7 @@ constexpr uint32_t HEAP_RANKED_MAX = 65536;
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
 // (lo, hi]: the sizes this launch takes (CLS 1 is launched once per LDS footprint so that small heaps share a CU)
-template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                                        hent *__restrict__ scratch, uint32_t lo, uint32_t hi,
                                                                        const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32)
 {
@@ -631,7 +592,7 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
   hent *buf = CLS == 0 ? stat : (CLS == 1 ? dyn : scratch + sg.first);
   for (uint32_t i = threadIdx.x; i < m; i += 64) buf[i] = ((hent) gk[i] << 32) | gx[i];
   __syncthreads();
-  if (CLS == 2 && V == 3 && rank32 != nullptr && m <= HEAP_RANKED_MAX)
+  if (CLS == 2 && ASM && rank32 != nullptr && m <= HEAP_RANKED_MAX)
   {
     // ranked 4-byte entries (see E32): up to HEAP_LARGE32 of them fit LDS.  buf keeps the packed originals.
     uint32_t *l32 = reinterpret_cast<uint32_t *>(dyn);
@@ -675,12 +636,12 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
     GlbMem gmem{buf};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     make_heap_wave(gmem, m);
-    if (V == 3) sort_heap_asm<true>(buf, m, HEAP_LARGE); else sort_heap_lag2<V>(gmem, m, HEAP_LARGE);
+    if (ASM) sort_heap_asm<true>(buf, m, HEAP_LARGE); else sort_heap_lag2(gmem, m, HEAP_LARGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) dyn[i] = buf[i];
     __syncthreads();
     LdsMem lmem{dyn};
-    if (V == 3) sort_heap_asm<false>(dyn, HEAP_LARGE, 1); else sort_heap_lag2<V>(lmem, HEAP_LARGE, 1);
+    if (ASM) sort_heap_asm<false>(dyn, HEAP_LARGE, 1); else sort_heap_lag2(lmem, HEAP_LARGE, 1);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) buf[i] = dyn[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -689,7 +650,7 @@ template <int CLS, int V> __global__ __launch_bounds__(64) void k_se_heapsort(co
   {
     LdsMem mem{buf};
     make_heap_wave(mem, m);
-    if (V == 3) sort_heap_asm<false>(buf, m, 1); else sort_heap_lag2<V>(mem, m, 1);
+    if (ASM) sort_heap_asm<false>(buf, m, 1); else sort_heap_lag2(mem, m, 1);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += 64)
@@ -972,7 +933,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     {
       const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
       hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
-      static const int sift_k = getenv("BK_SIFT_K") ? atoi(getenv("BK_SIFT_K")) : 3;
+      static const bool use_asm = getenv("BK_HEAP_CXX") == nullptr;  // BK_HEAP_CXX=1: the C++ statement of the pop loop (debugging)
       static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
       hipEvent_t ev0 = nullptr, ev1 = nullptr;
       if (dbg)
@@ -995,7 +956,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       const uint32_t *rank32 = nullptr;
       uint32_t *scratch32 = nullptr;
       static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
-      if (e[1] > HEAP_LARGE && sift_k == 3 && !no_ranked)
+      if (e[1] > HEAP_LARGE && use_asm && !no_ranked)
       {
         unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
         hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
@@ -1053,12 +1014,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32);
         for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
       };
-      switch (sift_k)
-      {
-      case 2: launch(k_se_heapsort<0, 2>, k_se_heapsort<1, 2>, k_se_heapsort<2, 2>); break;
-      case 3: launch(k_se_heapsort<0, 3>, k_se_heapsort<1, 3>, k_se_heapsort<2, 3>); break;
-      default: launch(k_se_heapsort<0, 1>, k_se_heapsort<1, 1>, k_se_heapsort<2, 1>); break;
-      }
+      if (use_asm)
+        launch(k_se_heapsort<0, true>, k_se_heapsort<1, true>, k_se_heapsort<2, true>);
+      else
+        launch(k_se_heapsort<0, false>, k_se_heapsort<1, false>, k_se_heapsort<2, false>);
       if (dbg)
       {
         float ms = 0;
