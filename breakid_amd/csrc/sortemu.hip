@@ -39,20 +39,38 @@ struct Seg
 };
 
 // depth_limit = 2 * floor(log2(n))  (std::__lg(n) * 2)
+// Segments of up to FIN_MAX elements leave the device-wide level loop: one workgroup finishes each of them in LDS
+// (k_se_finish).  fin[0] = number of entries of the finisher list.
+constexpr uint32_t FIN_MAX = 2048;
+struct FinSeg
+{
+  uint32_t first, last;
+  int32_t depth;
+};
+__device__ __forceinline__ void fin_append(FinSeg *__restrict__ fl, uint32_t *__restrict__ fin, uint32_t first, uint32_t last, int32_t depth)
+{
+  FinSeg f;
+  f.first = first;
+  f.last = last;
+  f.depth = depth;
+  fl[atomicAdd(fin, 1u)] = f;
+}
+
 // cnt entries: (#segments) | (#elements in them) << 32, scanned together
-__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsigned long long *__restrict__ cnt)
+__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsigned long long *__restrict__ cnt, FinSeg *__restrict__ fl, uint32_t *__restrict__ fin)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   uint64_t sz = goff[g + 1] - goff[g];
-  cnt[g] = sz > 16 ? (1ull | (sz << 32)) : 0ull;
+  cnt[g] = sz > FIN_MAX ? (1ull | (sz << 32)) : 0ull;
+  if (sz > 16 && sz <= FIN_MAX) fin_append(fl, fin, (uint32_t) goff[g], (uint32_t) goff[g + 1], 2 * (63 - __clzll((long long) sz)));
 }
 __global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   uint64_t sz = goff[g + 1] - goff[g];
-  if (sz > 16)
+  if (sz > FIN_MAX)
   {
     Seg s;
     s.first = (uint32_t) goff[g];
@@ -817,32 +835,292 @@ __global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, unsi
   if (sg.depth >= 0)
   {
     const uint32_t a = sg.cut - sg.first, b = sg.last - sg.cut;
-    if (a > 16) v += 1ull | ((unsigned long long) a << 32);
-    if (b > 16) v += 1ull | ((unsigned long long) b << 32);
+    if (a > FIN_MAX) v += 1ull | ((unsigned long long) a << 32);
+    if (b > FIN_MAX) v += 1ull | ((unsigned long long) b << 32);
   }
   cnt[s] = v;
 }
-__global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const unsigned long long *__restrict__ off, Seg *__restrict__ out)
+__global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const unsigned long long *__restrict__ off, Seg *__restrict__ out, FinSeg *__restrict__ fl,
+                                 uint32_t *__restrict__ fin)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   Seg sg = segs[s];
   if (sg.depth < 0) return;
   uint32_t o = (uint32_t) off[s], cb = (uint32_t) (off[s] >> 32);
-  if ((sg.cut - sg.first) > 16)
+  const uint32_t a = sg.cut - sg.first, b = sg.last - sg.cut;
+  if (a > FIN_MAX)
   {
     Seg c = sg;
     c.last = sg.cut;
     c.cbase = cb;
-    cb += sg.cut - sg.first;
+    cb += a;
     out[o++] = c;
   }
-  if ((sg.last - sg.cut) > 16)
+  else if (a > 16)
+    fin_append(fl, fin, sg.first, sg.cut, sg.depth);
+  if (b > FIN_MAX)
   {
     Seg c = sg;
     c.first = sg.cut;
     c.cbase = cb;
     out[o++] = c;
+  }
+  else if (b > 16)
+    fin_append(fl, fin, sg.cut, sg.last, sg.depth);
+}
+
+// ---- the same introsort loop for one segment of at most FIN_MAX elements, entirely in LDS ---------------------
+// Level-synchronous like the device-wide passes (pivot, stopper flags, prefix sums, position lists, swaps + cut,
+// children), with the sub-segment of every element tracked incrementally.  Sub-segments that exhaust the depth limit
+// are handed to the heapsort kernels through the global heap list, exactly as k_se_pivot does.
+struct LSeg
+{
+  uint16_t first, last, cut, base;  // base = index of the first child in the next table
+  uint32_t pivot;
+  int32_t depth;
+};
+constexpr uint32_t FIN_EPT = FIN_MAX / 256;
+constexpr uint32_t FIN_SEGS = 128;  // > FIN_MAX / 17 live sub-segments
+constexpr uint16_t FIN_DEAD = 0xFFFFu;
+
+__global__ __launch_bounds__(256) void k_se_finish(const FinSeg *__restrict__ fl, uint32_t nf, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
+                                                   uint2 *__restrict__ heap_list)
+{
+  __shared__ uint32_t s_key[FIN_MAX], s_idx[FIN_MAX];
+  __shared__ uint32_t s_lr[FIN_MAX + 1];  // exclusive prefix of (L-stopper | R-stopper << 16)
+  __shared__ uint16_t s_posL[FIN_MAX + 2], s_posR[FIN_MAX + 2];
+  __shared__ uint16_t s_segof[FIN_MAX];
+  __shared__ LSeg s_seg[2][FIN_SEGS];
+  __shared__ uint32_t s_scan[prims::WAVES];
+  __shared__ uint32_t s_ns;
+  if (blockIdx.x >= nf) return;
+  const FinSeg fs = fl[blockIdx.x];
+  const uint32_t m = fs.last - fs.first, g0 = fs.first, tid = threadIdx.x;
+  for (uint32_t e = tid; e < m; e += 256)
+  {
+    s_key[e] = key[g0 + e];
+    s_idx[e] = idx[g0 + e];
+    s_segof[e] = 0;
+  }
+  if (tid == 0)
+  {
+    LSeg r;
+    r.first = 0;
+    r.last = (uint16_t) m;
+    r.cut = r.base = 0;
+    r.pivot = 0;
+    r.depth = fs.depth;
+    s_seg[0][0] = r;
+    s_ns = 1;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int level = 0; level < 200; ++level)
+  {
+    const uint32_t ns = s_ns;
+    if (ns == 0) break;
+    LSeg *S = s_seg[cur], *N = s_seg[cur ^ 1];
+    // pivot step: __move_median_to_first(first, first+1, mid, last-1), or hand over to heapsort at the depth limit
+    if (tid < ns)
+    {
+      const LSeg sg = S[tid];
+      if (sg.depth == 0)
+      {
+        S[tid].depth = -1;
+        const uint32_t slot = atomicAdd(err + 3, 1u), sz = (uint32_t) sg.last - sg.first;
+        heap_list[slot] = make_uint2(g0 + sg.first, g0 + sg.last);
+        atomicAdd(err + 2, sz);
+        atomicMax(err + 1, sz);
+      }
+      else
+      {
+        const uint32_t first = sg.first, last = sg.last;
+        const uint32_t a = first + 1, b = first + (last - first) / 2, c = last - 1;
+        const uint32_t ka = s_key[a], kb = s_key[b], kc = s_key[c];
+        uint32_t pick;
+        if (ka < kb)
+        {
+          if (kb < kc) pick = b;
+          else if (ka < kc) pick = c;
+          else pick = a;
+        }
+        else if (ka < kc) pick = a;
+        else if (kb < kc) pick = c;
+        else pick = b;
+        const uint32_t kf = s_key[first], kp = s_key[pick], xf = s_idx[first], xp = s_idx[pick];
+        s_key[first] = kp;
+        s_key[pick] = kf;
+        s_idx[first] = xp;
+        s_idx[pick] = xf;
+        S[tid].pivot = kp;
+        S[tid].depth = sg.depth - 1;
+      }
+    }
+    __syncthreads();
+    // stopper flags and their prefix sums (FIN_EPT consecutive elements per thread)
+    {
+      uint32_t loc[FIN_EPT], sum = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < FIN_EPT; ++k)
+      {
+        const uint32_t e = tid * FIN_EPT + k;
+        uint32_t v = 0;
+        if (e < m)
+        {
+          const uint16_t s = s_segof[e];
+          if (s != FIN_DEAD)
+          {
+            const LSeg sg = S[s];
+            if (sg.depth >= 0 && e > sg.first)
+            {
+              const uint32_t kk = s_key[e];
+              if (kk >= sg.pivot) v |= 1u;
+              if (kk <= sg.pivot) v |= 1u << 16;
+            }
+          }
+        }
+        loc[k] = sum;
+        sum += v;
+      }
+      uint32_t total;
+      const uint32_t base = prims::block_exclusive_scan(sum, s_scan, total);
+#pragma unroll
+      for (uint32_t k = 0; k < FIN_EPT; ++k)
+      {
+        const uint32_t e = tid * FIN_EPT + k;
+        if (e <= m) s_lr[e] = base + loc[k];
+      }
+      if (m == FIN_MAX && tid == 0) s_lr[FIN_MAX] = total;
+    }
+    __syncthreads();
+    // position lists: l_j from the left, r_j from the right
+#pragma unroll
+    for (uint32_t k = 0; k < FIN_EPT; ++k)
+    {
+      const uint32_t e = tid * FIN_EPT + k;
+      if (e >= m) continue;
+      const uint16_t s = s_segof[e];
+      if (s == FIN_DEAD) continue;
+      const LSeg sg = S[s];
+      if (sg.depth < 0 || e <= sg.first) continue;
+      const uint32_t kk = s_key[e], here = s_lr[e], bs = s_lr[sg.first], en = s_lr[sg.last];
+      if (kk >= sg.pivot) s_posL[sg.first + 1 + ((here & 0xFFFFu) - (bs & 0xFFFFu))] = (uint16_t) e;
+      if (kk <= sg.pivot)
+      {
+        const uint32_t nR = (en >> 16) - (bs >> 16), jl = (here >> 16) - (bs >> 16);
+        s_posR[sg.first + 1 + (nR - 1 - jl)] = (uint16_t) e;
+      }
+    }
+    __syncthreads();
+    // swaps (l_j, r_j) for j < J and the cut
+#pragma unroll
+    for (uint32_t k = 0; k < FIN_EPT; ++k)
+    {
+      const uint32_t e = tid * FIN_EPT + k;
+      if (e >= m) continue;
+      const uint16_t s = s_segof[e];
+      if (s == FIN_DEAD) continue;
+      const LSeg sg = S[s];
+      if (sg.depth < 0) continue;
+      const uint32_t first = sg.first, bs = s_lr[first], en = s_lr[sg.last];
+      const uint32_t nL = (en & 0xFFFFu) - (bs & 0xFFFFu), nR = (en >> 16) - (bs >> 16);
+      const uint32_t mm = nL < nR ? nL : nR, j = e - first;
+      if (j > mm) continue;
+      const uint32_t lj = j < nL ? s_posL[first + 1 + j] : 0xFFFFFFFFu;
+      const uint32_t rj = j < nR ? s_posR[first + 1 + j] : first;
+      if ((j < nL) && (j < nR) && (lj < rj))
+      {
+        const uint32_t k1 = s_key[lj], k2 = s_key[rj], x1 = s_idx[lj], x2 = s_idx[rj];
+        s_key[lj] = k2;
+        s_key[rj] = k1;
+        s_idx[lj] = x2;
+        s_idx[rj] = x1;
+      }
+      else
+      {
+        bool prev_cont = false;
+        uint32_t rprev = 0;
+        if (j > 0)
+        {
+          const uint32_t lp = s_posL[first + j];
+          rprev = s_posR[first + j];
+          prev_cont = lp < rprev;
+        }
+        if (j == 0)
+          S[s].cut = (uint16_t) lj;
+        else if (prev_cont)
+          S[s].cut = (uint16_t) (lj < rprev ? lj : rprev);
+      }
+    }
+    __syncthreads();
+    // children (> 16 elements) form the next table
+    {
+      uint32_t cnt = 0, a = 0, b = 0;
+      LSeg sg;
+      sg.depth = -1;
+      if (tid < ns)
+      {
+        sg = S[tid];
+        if (sg.depth >= 0)
+        {
+          a = (uint32_t) sg.cut - sg.first;
+          b = (uint32_t) sg.last - sg.cut;
+          cnt = (a > 16 ? 1u : 0u) + (b > 16 ? 1u : 0u);
+        }
+      }
+      uint32_t total;
+      uint32_t o = prims::block_exclusive_scan(cnt, s_scan, total);
+      if (tid < ns && sg.depth >= 0)
+      {
+        S[tid].base = (uint16_t) o;
+        LSeg c = sg;
+        c.cut = c.base = 0;
+        if (a > 16)
+        {
+          c.first = sg.first;
+          c.last = sg.cut;
+          N[o++] = c;
+        }
+        if (b > 16)
+        {
+          c.first = sg.cut;
+          c.last = sg.last;
+          N[o] = c;
+        }
+      }
+      if (tid == 0) s_ns = total;
+    }
+    __syncthreads();
+    // every element moves to its child (or retires)
+#pragma unroll
+    for (uint32_t k = 0; k < FIN_EPT; ++k)
+    {
+      const uint32_t e = tid * FIN_EPT + k;
+      if (e >= m) continue;
+      const uint16_t s = s_segof[e];
+      if (s == FIN_DEAD) continue;
+      const LSeg sg = S[s];
+      uint16_t nx = FIN_DEAD;
+      if (sg.depth >= 0)
+      {
+        const uint32_t a = (uint32_t) sg.cut - sg.first, b = (uint32_t) sg.last - sg.cut;
+        if (e < sg.cut)
+        {
+          if (a > 16) nx = sg.base;
+        }
+        else if (b > 16)
+          nx = (uint16_t) (sg.base + (a > 16 ? 1 : 0));
+      }
+      s_segof[e] = nx;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (uint32_t e = tid; e < m; e += 256)
+  {
+    key[g0 + e] = s_key[e];
+    idx[g0 + e] = s_idx[e];
   }
 }
 
@@ -871,7 +1149,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   uint32_t *err = b.err.as<uint32_t>(4);
   HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
   // level 0 segments = groups larger than 16
-  hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt);
+  FinSeg *fin_list = b.fin_list.as<FinSeg>((uint64_t) n / 16 + ng + 16);  // every entry holds more than 16 elements
+  uint32_t *fin = b.fin_cnt.as<uint32_t>(1);
+  HIP_CHECK(hipMemsetAsync(fin, 0, 4, st));
+  hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, fin_list, fin);
   prims::exclusive_scan<unsigned long long>(cnt, cnt, ng, b.scan_tmp, st);
   unsigned long long tot = 0;
   HIP_CHECK(hipMemcpyAsync(&tot, cnt + ng, 8, hipMemcpyDeviceToHost, st));
@@ -910,7 +1191,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       HIP_CHECK(hipStreamSynchronize(st));
       const uint32_t ns2 = (uint32_t) tot;
       if (ns2 > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-      if (ns2) hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2);
+      hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin);
       std::swap(segs, segs2);
       ns = ns2;
       na = (uint32_t) (tot >> 32);
@@ -922,7 +1203,12 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
-  if (ns_initial)
+  // segments of at most FIN_MAX elements: the rest of their introsort loop in LDS, one workgroup each
+  uint32_t nfin = 0;
+  HIP_CHECK(hipMemcpyAsync(&nfin, fin, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (nfin) hipLaunchKernelGGL(k_se_finish, dim3(nfin), dim3(256), 0, st, fin_list, nfin, key, idx, err, heap_list);
+  if (ns_initial || nfin)
   {
     // segments that exhausted introsort's depth limit are heapsorted now (they are final: no children)
     uint32_t e[4] = {0, 0, 0, 0};
