@@ -50,6 +50,34 @@ def test_bam_decoder_matches_generator():
         assert np.array_equal(cols[k], ref[k]), k
 
 
+def test_bam_decoder_threads_and_chunks_agree(monkeypatch):
+    """parallel BGZF inflate / chunked record decode (bam_reader.cc): > 1 decode chunk (65536 records each), several BGZF
+    blocks, SA/OC blobs crossing chunk borders; 1 thread and 5 threads must give the same table; truncation is an error"""
+    contigs = [("chr1", 3_000_000), ("chr2", 2_000_000)]
+    ds = synth.make_cfg(5, contigs, 150_000, 40, 30, 200, jitter=200, read_len=100)
+    for i in range(0, len(ds.recs), 977):
+        ds.recs[i].sa = "chr2,%d,+,40S60M,60,0;" % (100 + i)
+        if i % 2:
+            ds.recs[i].oc = "60M40S"
+    ref = ds.to_soa()
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "a.bam")
+        ds.write_bam(p)
+        out = {}
+        for th in ("1", "5"):
+            monkeypatch.setenv("BREAKID_THREADS", th)
+            out[th] = capi.decode_bam(p)[1]
+        raw = open(p, "rb").read()
+        open(p, "wb").write(raw[: len(raw) // 2])
+        with pytest.raises(capi.BreakIDError) as e:
+            capi.decode_bam(p)
+        assert e.value.code == abi.BK_ERR_IO
+    assert len(ref["tid"]) > 2 * 65536
+    for k, _ in abi.SOA_COLS:
+        assert np.array_equal(out["1"][k], ref[k]), k
+        assert np.array_equal(out["5"][k], ref[k]), k
+
+
 def test_qname_hash_matches_python():
     L = capi.lib()
     for s in [b"", b"a", b"read/1", b"L12_3", b"x" * 200]:
