@@ -59,7 +59,7 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     n_rec = args.records
     if use_shards:
-        n_rec = min(n_rec, (0xFFFF0000 // max(world, 1)) // 1_000_000 * 1_000_000, 500_000_000)  # the whole sample stays below 2^32 records
+        n_rec = min(n_rec, (0xFFFF0000 // max(world, 1)) // 1_000_000 * 1_000_000)  # the whole sample stays below 2^32 records (536 M per rank at 8 ranks)
     while n_rec * 110 > free_b and n_rec > 1_000_000:
         n_rec //= 2
     t0 = time.time()
