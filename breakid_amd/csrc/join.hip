@@ -46,29 +46,47 @@ __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ can
     return;
   }
   // visit the run in record order: repeatedly take the smallest record index above the last one
+  // (a run of two, the usual case, is one comparison of the two records already in registers)
+  Cand r0 = {}, r1 = {};
+  if (len == 2)
+  {
+    r0 = cand[val[i]];
+    r1 = cand[val[i + 1]];
+    if (r1.rec < r0.rec)
+    {
+      const Cand t = r0;
+      r0 = r1;
+      r1 = t;
+    }
+  }
   long long last_rec = -1;
   uint32_t buffered = 0xFFFFFFFFu;  // candidate index of the buffered (first-arrived) mate
   for (uint32_t step = 0; step < len; ++step)
   {
     uint32_t best = 0xFFFFFFFFu;
-    long long best_rec = 0x7fffffffffffffffLL;
-    for (uint32_t k = 0; k < len; ++k)
+    if (len == 2)
+      best = step;  // marker only: r0 / r1 carry the data
+    else
     {
-      uint32_t ci = val[i + k];
-      long long r = cand[ci].rec;
-      if (r > last_rec && r < best_rec)
+      long long best_rec = 0x7fffffffffffffffLL;
+      for (uint32_t k = 0; k < len; ++k)
       {
-        best_rec = r;
-        best = ci;
+        uint32_t ci = val[i + k];
+        long long r = cand[ci].rec;
+        if (r > last_rec && r < best_rec)
+        {
+          best_rec = r;
+          best = ci;
+        }
       }
+      last_rec = best_rec;
     }
-    last_rec = best_rec;
     if (buffered == 0xFFFFFFFFu)
     {
       buffered = best;
       continue;
     }
-    const Cand b = cand[buffered], c = cand[best];
+    const Cand b = len == 2 ? r0 : cand[buffered], c = len == 2 ? r1 : cand[best];
     buffered = 0xFFFFFFFFu;  // readname_2_alignment.erase(it_mpr)
     // :1428  rname differs || abs(pos_cur - pos_buf) >= w   (positions are 1-based there; the difference is the same)
     int32_t bt = b.tid < 0 ? -1 : b.tid, ct = c.tid < 0 ? -1 : c.tid;
