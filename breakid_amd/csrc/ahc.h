@@ -6,7 +6,7 @@
 struct AhcBufs
 {
   DevBuf x, y, comp, csize, keys, vals, rank, cfs, need0, need1, need2, label, rootcomp, cand_t, npts, ent_cnt, pts_off, ent_off, cand_d, cand_o, cnodes_cnt,
-      cent_used, cpts_used, cbest_d, cbest_j, act, cnodes, entries, pts, out_cnt, out_idx, out_cl, err, newoff, scan_tmp;
+      cent_used, cpts_used, cbest_d, cbest_j, cmaxroot, act, cnodes, entries, pts, ptsxy, out_cnt, out_idx, out_cl, err, newoff, scan_tmp;
   prims::RadixBufs radix;
 };
 

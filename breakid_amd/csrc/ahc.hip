@@ -57,6 +57,7 @@ struct GroupMem
   uint64_t *cpts_used;
   double *cbest_d;
   int32_t *cbest_j;
+  int32_t *cmaxroot;    // per component: its root with the largest node index (the newest merged node, else the last leaf)
   uint32_t *act;         // active component ids (size >= 2)
 };
 
@@ -65,6 +66,14 @@ __device__ __forceinline__ double leaf_dist(const GroupMem &m, int a, int b)
   // euclidean_distance, util_cluster.cc:79-84, on doubles converted from uint32 (BreakID.cc:1800-1801)
   double dx = __dsub_rn((double) m.x[a], (double) m.x[b]);
   double dy = __dsub_rn((double) m.y[a], (double) m.y[b]);
+  return __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+}
+
+// the same distance from coordinates already in hand (first argument = the point of the merged node, as in leaf_dist(q_i, t_j))
+__device__ __forceinline__ double xy_dist(double xa, double ya, uint2 b)
+{
+  double dx = __dsub_rn(xa, (double) b.x);
+  double dy = __dsub_rn(ya, (double) b.y);
   return __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
 }
 
@@ -176,6 +185,50 @@ __device__ __forceinline__ bool best_less(double d1, int j1, double d2, int j2)
 }
 __device__ __forceinline__ bool cand_less(double d1, double o1, double d2, double o2) { return d1 < d2 || (d1 == d2 && o1 < o2); }
 
+// block-wide minimum under best_less: butterfly inside the waves, four partial results through LDS (two barriers)
+__device__ __forceinline__ void block_best(double &d, int &j, double *s_d, int32_t *s_j)
+{
+  for (int off = 32; off; off >>= 1)
+  {
+    const double od = __shfl_xor(d, off, 64);
+    const int oj = __shfl_xor(j, off, 64);
+    if (best_less(od, oj, d, j))
+    {
+      d = od;
+      j = oj;
+    }
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    s_d[threadIdx.x >> 6] = d;
+    s_j[threadIdx.x >> 6] = j;
+  }
+  __syncthreads();
+  d = s_d[0];
+  j = s_j[0];
+  for (int w = 1; w < AT / 64; ++w)
+    if (best_less(s_d[w], s_j[w], d, j))
+    {
+      d = s_d[w];
+      j = s_j[w];
+    }
+  __syncthreads();
+}
+__device__ __forceinline__ int block_max(int v, int32_t *s_j)
+{
+  for (int off = 32; off; off >>= 1)
+  {
+    const int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0) s_j[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = s_j[0];
+  for (int w = 1; w < AT / 64; ++w) v = s_j[w] > v ? s_j[w] : v;
+  __syncthreads();
+  return v;
+}
+
 struct AhcArgs
 {
   // per element (leaf position p in the clustered list)
@@ -195,9 +248,11 @@ struct AhcArgs
   unsigned long long *cent_used, *cpts_used;
   double *cbest_d;
   int32_t *cbest_j;
+  int32_t *cmaxroot;    // per component: its root with the largest node index (the newest merged node, else the last leaf)
   uint32_t *act, *cnodes;              // act: n, cnodes: 2n
   Entry *entries;
   uint32_t *pts;
+  uint2 *ptsxy;  // coordinates of the same points, same offsets: the linkage loops stream them without index chasing
   unsigned long long ent_leaf_total;
   double T;
   // outputs
@@ -251,6 +306,146 @@ __device__ void assign_ord_and_candidate(Entry *e, uint32_t cnt, int cross_top, 
   }
 }
 
+// The same for the list of a freshly merged node, by the whole workgroup: the right-to-left walk is a suffix scan
+// under the monoid (running maximum, how many entries equal it so far, target of the first of them), the candidate a
+// minimum under cand_less.  s_m / s_c / s_t hold one partial result per wave.
+struct RunState
+{
+  double m;
+  uint32_t c;
+  int32_t t;
+};
+__device__ __forceinline__ RunState run_join(const RunState &before, const RunState &cur)  // `before` was visited earlier (higher k)
+{
+  if (cur.m > before.m) return cur;
+  if (cur.m == before.m)
+  {
+    RunState r = before;
+    r.c += cur.c;
+    return r;
+  }
+  return before;
+}
+__device__ __forceinline__ RunState run_shfl_up(const RunState &v, int d)
+{
+  RunState o;
+  o.m = __shfl_up(v.m, d, 64);
+  o.c = __shfl_up(v.c, d, 64);
+  o.t = __shfl_up(v.t, d, 64);
+  return o;
+}
+__device__ void block_assign_ord_and_candidate(Entry *e, uint32_t cnt, int cross_top, const int32_t *rootcomp_base, int32_t &ct, double &cd, double &co, double *s_m,
+                                               uint32_t *s_c, int32_t *s_t)
+{
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  RunState carry;
+  carry.m = -1.0;
+  carry.c = 0;
+  carry.t = -1;
+  for (uint32_t done = 0; done < cnt; done += AT)
+  {
+    const bool live = done + tid < cnt;
+    const uint32_t k = live ? cnt - 1 - done - tid : 0;  // visiting order = descending k
+    RunState v;
+    v.m = -1.0;
+    v.c = 0;
+    v.t = -1;
+    double dk = 0;
+    int32_t tk = 0;
+    if (live)
+    {
+      dk = e[k].d;
+      tk = e[k].t;
+      v.m = dk;
+      v.c = 1;
+      v.t = tk;
+    }
+    RunState inc = v;
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const RunState o = run_shfl_up(inc, d);
+      if (lane >= d) inc = run_join(o, inc);
+    }
+    if (lane == 63)
+    {
+      s_m[w] = inc.m;
+      s_c[w] = inc.c;
+      s_t[w] = inc.t;
+    }
+    __syncthreads();
+    RunState ex = run_shfl_up(inc, 1);  // exclusive inside the wave
+    if (lane == 0)
+    {
+      ex.m = -1.0;
+      ex.c = 0;
+      ex.t = -1;
+    }
+    RunState pre = carry, tot = carry;
+    for (int i = 0; i < AT / 64; ++i)
+    {
+      RunState ws;
+      ws.m = s_m[i];
+      ws.c = s_c[i];
+      ws.t = s_t[i];
+      if (i < w) pre = run_join(pre, ws);
+      tot = run_join(tot, ws);
+    }
+    const RunState st = run_join(pre, ex);  // everything visited before entry k
+    if (live)
+    {
+      double ord = (double) tk;
+      if (dk == st.m && st.c == 1 && !(cross_top > tk)) ord = (double) st.t + 0.5;
+      e[k].ord = ord;
+    }
+    carry = tot;
+    __syncthreads();
+  }
+  // candidate = minimum (d, ord) over the entries whose target is still a root
+  int32_t bt = -1;
+  double bd = 0, bo = 0;
+  for (uint32_t k = tid; k < cnt; k += AT)
+  {
+    const Entry en = e[k];
+    if (rootcomp_base[en.t] < 0) continue;
+    if (bt < 0 || cand_less(en.d, en.ord, bd, bo))
+    {
+      bt = en.t;
+      bd = en.d;
+      bo = en.ord;
+    }
+  }
+  for (int off = 32; off; off >>= 1)
+  {
+    const int32_t ot = __shfl_xor(bt, off, 64);
+    const double od = __shfl_xor(bd, off, 64), oo = __shfl_xor(bo, off, 64);
+    if (ot >= 0 && (bt < 0 || cand_less(od, oo, bd, bo)))
+    {
+      bt = ot;
+      bd = od;
+      bo = oo;
+    }
+  }
+  __shared__ double s_o[AT / 64];
+  if (lane == 0)
+  {
+    s_m[w] = bd;
+    s_o[w] = bo;
+    s_t[w] = bt;
+  }
+  __syncthreads();
+  ct = s_t[0];
+  cd = s_m[0];
+  co = s_o[0];
+  for (int i = 1; i < AT / 64; ++i)
+    if (s_t[i] >= 0 && (ct < 0 || cand_less(s_m[i], s_o[i], cd, co)))
+    {
+      ct = s_t[i];
+      cd = s_m[i];
+      co = s_o[i];
+    }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
 {
   const uint32_t g = blockIdx.x;
@@ -260,6 +455,8 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
   __shared__ double s_d[AT];
   __shared__ int32_t s_j[AT];
   __shared__ uint32_t s_nact, s_nnodes, s_stop, s_cross;
+  __shared__ int32_t s_smax;  // largest leaf that is a component of its own (a root of 'another component' for ever)
+  __shared__ uint32_t s_scan4[AT / 64];
   __shared__ int32_t s_first, s_second;
   __shared__ uint32_t s_scan[AT];
   if (N < 2)
@@ -279,6 +476,7 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
   unsigned long long *cent_used = a.cent_used + gs, *cpts_used = a.cpts_used + gs;
   double *cbest_d = a.cbest_d + gs;
   int32_t *cbest_j = a.cbest_j + gs;
+  int32_t *cmaxroot = a.cmaxroot + gs;
   GroupMem gm{};
   gm.x = x;
   gm.y = y;
@@ -287,6 +485,7 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     s_nact = 0;
     s_nnodes = N;
     s_stop = 0;
+    s_smax = -1;
   }
   __syncthreads();
   // ---- leaves: add_leaf + update_neighbours for every point (util_cluster.cc:86-110) ----
@@ -312,7 +511,10 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       cpts_used[c] = 0;
       cbest_j[c] = -1;
       cbest_d[c] = 0;
-      if (csize[c] >= 2) act[atomicAdd(&s_nact, 1u)] = c;
+      if (csize[c] >= 2)
+        act[atomicAdd(&s_nact, 1u)] = c;
+      else
+        atomicMax(&s_smax, (int32_t) c);
     }
   }
   __syncthreads();
@@ -322,7 +524,11 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     const uint32_t c = comp[i];
     const uint64_t base = 2ull * (a.comp_first_sorted[gs + c]);  // capacity 2*csize per component, laid out by sorted start
     a.cnodes[base + rank[i]] = i;
-    if (rank[i] + 1 == csize[c]) cnodes_cnt[c] = csize[c];
+    if (rank[i] + 1 == csize[c])
+    {
+      cnodes_cnt[c] = csize[c];
+      cmaxroot[c] = (int32_t) i;
+    }
   }
   __syncthreads();
   // leaf neighbour lists + first candidates (one lane per leaf; lists hold the lower leaves of the component)
@@ -391,22 +597,11 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
         bj = cbest_j[c];
       }
     }
-    s_d[tid] = bd;
-    s_j[tid] = bj;
-    __syncthreads();
-    for (int st = AT / 2; st; st >>= 1)
-    {
-      if ((int) tid < st && best_less(s_d[tid + st], s_j[tid + st], s_d[tid], s_j[tid]))
-      {
-        s_d[tid] = s_d[tid + st];
-        s_j[tid] = s_j[tid + st];
-      }
-      __syncthreads();
-    }
+    block_best(bd, bj, s_d, s_j);
     if (tid == 0)
     {
-      const int j = s_j[0];
-      if (j < 0 || !(s_d[0] <= a.T))
+      const int j = bj;
+      if (j < 0 || !(bd <= a.T))
         s_stop = 1;
       else
       {
@@ -424,6 +619,7 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     const uint32_t ncn = cnodes_cnt[c];
     // merged point list = first's points then second's (:379-382)
     uint32_t *qpts = a.pts + a.cpts_off[gs + c] + cpts_used[c];
+    uint2 *qxy = a.ptsxy + a.cpts_off[gs + c] + cpts_used[c];
     __syncthreads();
     if (tid == 0)
     {
@@ -440,7 +636,9 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     {
       const int src = k < mf ? first : second;
       const uint32_t kk = k < mf ? k : k - mf;
-      qpts[k] = src < (int) N ? (uint32_t) src : (a.pts + pts_off[src])[kk];
+      const uint32_t leaf = src < (int) N ? (uint32_t) src : (a.pts + pts_off[src])[kk];
+      qpts[k] = leaf;
+      qxy[k] = make_uint2(x[leaf], y[leaf]);
     }
     Entry *qe = a.entries + a.ent_leaf_total + a.cent_off[gs + c] + cent_used[c];
     __syncthreads();
@@ -466,31 +664,31 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       const uint32_t k = base + tid;
       const int t = k < ncn ? (int) members[k] : -1;
       const uint32_t isr = (t >= 0 && rootcomp[t] >= 0) ? 1u : 0u;
-      // block exclusive scan of isr
-      s_scan[tid] = isr;
-      __syncthreads();
-      for (int off = 1; off < AT; off <<= 1)
-      {
-        uint32_t v = (int) tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-      }
-      const uint32_t pos = nent + s_scan[tid] - isr;
-      const uint32_t tot = s_scan[AT - 1];
+      uint32_t tot;
+      const uint32_t pos = nent + prims::block_exclusive_scan(isr, s_scan4, tot);
       if (isr)
       {
         const uint32_t mt = npts[t];
+        // sequential average_linkage sum (the order of the additions is part of the result); the coordinates stream
+        // from the two point lists, loaded four ahead of the dependent additions
         double total = 0.0;
-        if (t < (int) N)
+        const uint2 leaf_xy = t < (int) N ? make_uint2(x[t], y[t]) : make_uint2(0u, 0u);
+        const uint2 *txy = t < (int) N ? &leaf_xy : a.ptsxy + pts_off[t];
+        for (uint32_t i = 0; i < mq; ++i)
         {
-          for (uint32_t i = 0; i < mq; ++i) total = __dadd_rn(total, leaf_dist(gm, (int) qpts[i], t));
-        }
-        else
-        {
-          const uint32_t *tp = a.pts + pts_off[t];
-          for (uint32_t i = 0; i < mq; ++i)
-            for (uint32_t jj = 0; jj < mt; ++jj) total = __dadd_rn(total, leaf_dist(gm, (int) qpts[i], (int) tp[jj]));
+          const uint2 pi = qxy[i];
+          const double xi = (double) pi.x, yi = (double) pi.y;
+          uint32_t jj = 0;
+          for (; jj + 4 <= mt; jj += 4)
+          {
+            const uint2 p0 = txy[jj], p1 = txy[jj + 1], p2 = txy[jj + 2], p3 = txy[jj + 3];
+            const double d0 = xy_dist(xi, yi, p0), d1 = xy_dist(xi, yi, p1), d2 = xy_dist(xi, yi, p2), d3 = xy_dist(xi, yi, p3);
+            total = __dadd_rn(total, d0);
+            total = __dadd_rn(total, d1);
+            total = __dadd_rn(total, d2);
+            total = __dadd_rn(total, d3);
+          }
+          for (; jj < mt; ++jj) total = __dadd_rn(total, xy_dist(xi, yi, txy[jj]));
         }
         Entry en;
         en.t = t;
@@ -502,39 +700,35 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       __syncthreads();
       nent += tot;
     }
-    // largest root index below q that belongs to another component
+    // largest root index below q that belongs to another component: the newest root of every other component
+    // (its latest merged node, or its last leaf before the first merge), or a leaf that is a component of its own
     {
-      int found = -1;
-      for (int base = q - 1; base >= 0 && found < 0; base -= AT)
+      int mine = s_smax;
+      for (uint32_t k = tid; k < s_nact; k += AT)
       {
-        const int i = base - (int) tid;
-        int mine = (i >= 0 && rootcomp[i] >= 0 && (uint32_t) rootcomp[i] != c) ? i : -1;
-        s_j[tid] = mine;
-        __syncthreads();
-        for (int st = AT / 2; st; st >>= 1)
-        {
-          if ((int) tid < st && s_j[tid + st] > s_j[tid]) s_j[tid] = s_j[tid + st];
-          __syncthreads();
-        }
-        found = s_j[0];
-        __syncthreads();
+        const uint32_t c2 = act[k];
+        if (c2 != c && cmaxroot[c2] > mine) mine = cmaxroot[c2];
       }
+      const int found = block_max(mine, s_j);
       if (tid == 0) s_first = found;  // reuse as cross_top
     }
     __syncthreads();
-    if (tid == 0)
     {
       int32_t ct;
       double cd, co;
-      assign_ord_and_candidate(qe, nent, s_first, rootcomp, ct, cd, co);
-      ent_cnt[q] = nent;
-      cent_used[c] += nent;
-      cand_t[q] = ct;
-      cand_d[q] = cd;
-      cand_o[q] = co;
-      members[ncn] = (uint32_t) q;
-      cnodes_cnt[c] = ncn + 1;
-      s_nnodes = (uint32_t) q + 1;
+      block_assign_ord_and_candidate(qe, nent, s_first, rootcomp, ct, cd, co, s_d, s_scan, s_j);
+      if (tid == 0)
+      {
+        ent_cnt[q] = nent;
+        cent_used[c] += nent;
+        cand_t[q] = ct;
+        cand_d[q] = cd;
+        cand_o[q] = co;
+        members[ncn] = (uint32_t) q;
+        cnodes_cnt[c] = ncn + 1;
+        cmaxroot[c] = q;
+        s_nnodes = (uint32_t) q + 1;
+      }
     }
     __syncthreads();
     // roots whose candidate was one of the merged nodes look further down their list (:341-354)
@@ -576,22 +770,11 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
           j0 = r;
         }
       }
-      s_d[tid] = d0;
-      s_j[tid] = j0;
-      __syncthreads();
-      for (int st = AT / 2; st; st >>= 1)
-      {
-        if ((int) tid < st && best_less(s_d[tid + st], s_j[tid + st], s_d[tid], s_j[tid]))
-        {
-          s_d[tid] = s_d[tid + st];
-          s_j[tid] = s_j[tid + st];
-        }
-        __syncthreads();
-      }
+      block_best(d0, j0, s_d, s_j);
       if (tid == 0)
       {
-        cbest_d[c] = s_d[0];
-        cbest_j[c] = s_j[0];
+        cbest_d[c] = d0;
+        cbest_j[c] = j0;
       }
     }
     __syncthreads();
@@ -742,10 +925,12 @@ void ahc_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluste
   a.cpts_used = ab.cpts_used.as<unsigned long long>(n);
   a.cbest_d = ab.cbest_d.as<double>(n);
   a.cbest_j = ab.cbest_j.as<int32_t>(n);
+  a.cmaxroot = ab.cmaxroot.as<int32_t>(n);
   a.act = ab.act.as<uint32_t>(n);
   a.cnodes = ab.cnodes.as<uint32_t>(2 * n);
   a.entries = ab.entries.as<Entry>(n_entries + 1);
   a.pts = ab.pts.as<uint32_t>(tot[2] + 1);
+  a.ptsxy = ab.ptsxy.as<uint2>(tot[2] + 1);
   a.ent_leaf_total = tot[0];
   a.T = T;
   a.out_cnt = ab.out_cnt.as<uint32_t>((uint64_t) ng + 1);
