@@ -656,8 +656,9 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     }
     __syncthreads();
     // update_neighbours for the merged node: distance to every current root of the component (others are farther
-    // than T by construction).  Entries in ascending index; one lane per root, sequential average_linkage (:201-215)
-    // first pass: count roots -> compact positions via a block scan over the member list
+    // than T by construction).  Entries in ascending index.  The sequential average_linkage sum (:201-215) fixes the
+    // order of the additions, not of the distances: pairs with little work take one lane each, the others one wave
+    // each - 64 distances at a time in parallel, then added one after the other in list order.
     uint32_t nent = 0;
     for (uint32_t base = 0; base < ncn; base += AT)
     {
@@ -668,38 +669,61 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       const uint32_t pos = nent + prims::block_exclusive_scan(isr, s_scan4, tot);
       if (isr)
       {
-        const uint32_t mt = npts[t];
-        // sequential average_linkage sum (the order of the additions is part of the result); the coordinates stream
-        // from the two point lists, loaded four ahead of the dependent additions
-        double total = 0.0;
-        const uint2 leaf_xy = t < (int) N ? make_uint2(x[t], y[t]) : make_uint2(0u, 0u);
-        const uint2 *txy = t < (int) N ? &leaf_xy : a.ptsxy + pts_off[t];
-        for (uint32_t i = 0; i < mq; ++i)
-        {
-          const uint2 pi = qxy[i];
-          const double xi = (double) pi.x, yi = (double) pi.y;
-          uint32_t jj = 0;
-          for (; jj + 4 <= mt; jj += 4)
-          {
-            const uint2 p0 = txy[jj], p1 = txy[jj + 1], p2 = txy[jj + 2], p3 = txy[jj + 3];
-            const double d0 = xy_dist(xi, yi, p0), d1 = xy_dist(xi, yi, p1), d2 = xy_dist(xi, yi, p2), d3 = xy_dist(xi, yi, p3);
-            total = __dadd_rn(total, d0);
-            total = __dadd_rn(total, d1);
-            total = __dadd_rn(total, d2);
-            total = __dadd_rn(total, d3);
-          }
-          for (; jj < mt; ++jj) total = __dadd_rn(total, xy_dist(xi, yi, txy[jj]));
-        }
         Entry en;
         en.t = t;
-        en.d = __ddiv_rn(total, (double) (int) (mq * mt));  // total / (m * n) with an int product
+        en.d = 0;
         en.ord = 0;
         en.pad = 0;
         qe[pos] = en;
       }
-      __syncthreads();
       nent += tot;
     }
+    __syncthreads();
+    constexpr uint32_t WAVE_WORK = 192;  // pairs with at least this many distances go to a whole wave
+    for (uint32_t idx = tid; idx < nent; idx += AT)
+    {
+      const int t = qe[idx].t;
+      const uint32_t mt = npts[t];
+      if (mq * mt >= WAVE_WORK) continue;
+      double total = 0.0;
+      const uint2 leaf_xy = t < (int) N ? make_uint2(x[t], y[t]) : make_uint2(0u, 0u);
+      const uint2 *txy = t < (int) N ? &leaf_xy : a.ptsxy + pts_off[t];
+      for (uint32_t i = 0; i < mq; ++i)
+      {
+        const uint2 pi = qxy[i];
+        const double xi = (double) pi.x, yi = (double) pi.y;
+        for (uint32_t jj = 0; jj < mt; ++jj) total = __dadd_rn(total, xy_dist(xi, yi, txy[jj]));
+      }
+      qe[idx].d = __ddiv_rn(total, (double) (int) (mq * mt));  // total / (m * n) with an int product
+    }
+    {
+      const uint32_t lane = tid & 63, wv = tid >> 6;
+      for (uint32_t idx = wv; idx < nent; idx += AT / 64)
+      {
+        const int t = qe[idx].t;  // uniform inside the wave
+        const uint32_t mt = npts[t];
+        const uint32_t work = mq * mt;
+        if (work < WAVE_WORK) continue;
+        const uint2 *txy = t < (int) N ? nullptr : a.ptsxy + pts_off[t];
+        const uint2 leaf_xy = t < (int) N ? make_uint2(x[t], y[t]) : make_uint2(0u, 0u);
+        double total = 0.0;
+        for (uint32_t e0 = 0; e0 < work; e0 += 64)
+        {
+          const uint32_t el = e0 + lane;
+          double d = 0.0;
+          if (el < work)
+          {
+            const uint32_t i = el / mt, jj = el - i * mt;
+            const uint2 pi = qxy[i];
+            d = xy_dist((double) pi.x, (double) pi.y, txy ? txy[jj] : leaf_xy);
+          }
+          const uint32_t cnt = work - e0 < 64 ? work - e0 : 64;
+          for (uint32_t l = 0; l < cnt; ++l) total = __dadd_rn(total, __shfl(d, (int) l, 64));
+        }
+        if (lane == 0) qe[idx].d = __ddiv_rn(total, (double) (int) work);
+      }
+    }
+    __syncthreads();
     // largest root index below q that belongs to another component: the newest root of every other component
     // (its latest merged node, or its last leaf before the first merge), or a leaf that is a component of its own
     {
@@ -731,29 +755,80 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       }
     }
     __syncthreads();
-    // roots whose candidate was one of the merged nodes look further down their list (:341-354)
-    for (uint32_t k = tid; k < ncn; k += AT)
+    // roots whose candidate was one of the merged nodes look further down their list (:341-354): the affected
+    // roots are collected, then every wave takes one of them and scans its list with all lanes
     {
-      const int r = (int) members[k];
-      if (rootcomp[r] < 0) continue;
-      if (cand_t[r] == first || cand_t[r] == second)
+      if (tid == 0) s_cross = 0;
+      __syncthreads();
+      for (uint32_t k = tid; k < ncn; k += AT)
       {
-        const Entry *e = a.entries + ent_off[r];
-        int32_t ct = -1;
-        double cd = 0, co = 0;
-        for (uint32_t z = 0; z < ent_cnt[r]; ++z)
+        const int r = (int) members[k];
+        if (rootcomp[r] < 0) continue;
+        if (cand_t[r] == first || cand_t[r] == second)
         {
-          if (rootcomp[e[z].t] < 0) continue;
-          if (ct < 0 || cand_less(e[z].d, e[z].ord, cd, co))
+          const uint32_t slot = atomicAdd(&s_cross, 1u);
+          if (slot < AT)
+            s_scan[slot] = (uint32_t) r;
+          else
           {
-            ct = e[z].t;
-            cd = e[z].d;
-            co = e[z].ord;
+            // more affected roots than list slots (never seen; kept exact): this lane scans its own list
+            const Entry *e = a.entries + ent_off[r];
+            int32_t ct = -1;
+            double cd = 0, co = 0;
+            for (uint32_t z = 0; z < ent_cnt[r]; ++z)
+            {
+              if (rootcomp[e[z].t] < 0) continue;
+              if (ct < 0 || cand_less(e[z].d, e[z].ord, cd, co))
+              {
+                ct = e[z].t;
+                cd = e[z].d;
+                co = e[z].ord;
+              }
+            }
+            cand_t[r] = ct;
+            cand_d[r] = cd;
+            cand_o[r] = co;
           }
         }
-        cand_t[r] = ct;
-        cand_d[r] = cd;
-        cand_o[r] = co;
+      }
+      __syncthreads();
+      const uint32_t naff = s_cross < AT ? s_cross : AT;
+      const uint32_t lane = tid & 63;
+      for (uint32_t w = tid >> 6; w < naff; w += AT / 64)
+      {
+        const int r = (int) s_scan[w];
+        const Entry *e = a.entries + ent_off[r];
+        const uint32_t ne = ent_cnt[r];
+        int32_t ct = -1;
+        double cd = 0, co = 0;
+        for (uint32_t z = lane; z < ne; z += 64)
+        {
+          const Entry en = e[z];
+          if (rootcomp[en.t] < 0) continue;
+          if (ct < 0 || cand_less(en.d, en.ord, cd, co))
+          {
+            ct = en.t;
+            cd = en.d;
+            co = en.ord;
+          }
+        }
+        for (int off = 32; off; off >>= 1)
+        {
+          const int32_t ot = __shfl_xor(ct, off, 64);
+          const double od = __shfl_xor(cd, off, 64), oo = __shfl_xor(co, off, 64);
+          if (ot >= 0 && (ct < 0 || cand_less(od, oo, cd, co)))
+          {
+            ct = ot;
+            cd = od;
+            co = oo;
+          }
+        }
+        if (lane == 0)
+        {
+          cand_t[r] = ct;
+          cand_d[r] = cd;
+          cand_o[r] = co;
+        }
       }
     }
     __syncthreads();
