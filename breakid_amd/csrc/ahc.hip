@@ -700,9 +700,9 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       const uint32_t lane = tid & 63, wv = tid >> 6;
       for (uint32_t idx = wv; idx < nent; idx += AT / 64)
       {
-        const int t = qe[idx].t;  // uniform inside the wave
-        const uint32_t mt = npts[t];
-        const uint32_t work = mq * mt;
+        const int t = __builtin_amdgcn_readfirstlane(qe[idx].t);  // the same entry for the whole wave
+        const uint32_t mt = (uint32_t) __builtin_amdgcn_readfirstlane((int) npts[t]);
+        const uint32_t work = (uint32_t) __builtin_amdgcn_readfirstlane((int) mq) * mt;
         if (work < WAVE_WORK) continue;
         const uint2 *txy = t < (int) N ? nullptr : a.ptsxy + pts_off[t];
         const uint2 leaf_xy = t < (int) N ? make_uint2(x[t], y[t]) : make_uint2(0u, 0u);
@@ -718,7 +718,9 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
             d = xy_dist((double) pi.x, (double) pi.y, txy ? txy[jj] : leaf_xy);
           }
           const uint32_t cnt = work - e0 < 64 ? work - e0 : 64;
-          for (uint32_t l = 0; l < cnt; ++l) total = __dadd_rn(total, __shfl(d, (int) l, 64));
+          const int dlo = __double2loint(d), dhi = __double2hiint(d);
+          for (uint32_t l = 0; l < cnt; ++l)  // ordered additions, one v_readlane pair + one add each
+            total = __dadd_rn(total, __hiloint2double(__builtin_amdgcn_readlane(dhi, (int) l), __builtin_amdgcn_readlane(dlo, (int) l)));
         }
         if (lane == 0) qe[idx].d = __ddiv_rn(total, (double) (int) work);
       }
