@@ -719,8 +719,15 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
           }
           const uint32_t cnt = work - e0 < 64 ? work - e0 : 64;
           const int dlo = __double2loint(d), dhi = __double2hiint(d);
-          for (uint32_t l = 0; l < cnt; ++l)  // ordered additions, one v_readlane pair + one add each
-            total = __dadd_rn(total, __hiloint2double(__builtin_amdgcn_readlane(dhi, (int) l), __builtin_amdgcn_readlane(dlo, (int) l)));
+          // ordered additions, one v_readlane pair + one add each (full chunks unrolled: constant lane numbers)
+          if (cnt == 64)
+          {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) total = __dadd_rn(total, __hiloint2double(__builtin_amdgcn_readlane(dhi, l), __builtin_amdgcn_readlane(dlo, l)));
+          }
+          else
+            for (uint32_t l = 0; l < cnt; ++l)
+              total = __dadd_rn(total, __hiloint2double(__builtin_amdgcn_readlane(dhi, (int) l), __builtin_amdgcn_readlane(dlo, (int) l)));
         }
         if (lane == 0) qe[idx].d = __ddiv_rn(total, (double) (int) work);
       }
