@@ -118,6 +118,44 @@ def test_wgs_shape_device_resident_vs_oracle():
     o.close()
 
 
+def test_wgs_shape_100M_oracle_determinism_and_invariants():
+    """The largest table the single-thread oracle finishes in seconds (100 M records, ~6 s): bit-identical final calls,
+    the same bytes from a second run and from the sharded driver at world size 1 (routed exchange), and the
+    size-independent invariants of the cluster table (full size, 620 M: bench.py re-checks a 160 M sample every run)."""
+    import zlib
+    import torch
+    from breakid_amd import sharded, synth_gpu
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs(100_000_000, 2024, dev)
+    ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+    ctx = capi.Context(contigs)
+    crcs = []
+    for rep in range(2):
+        ctx.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+        w, n_valid = ctx.run(qual=20, fast=True)
+        cl, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+        crcs.append(zlib.crc32(cl.tobytes()))
+    assert crcs[0] == crcs[1]
+    clustered, goff = ctx.fetch(abi.STAGE_CLUSTERED)
+    assert int(cl["n_drp"].sum()) == len(clustered)
+    assert np.all(cl["p1_min"] <= cl["p1_mean"]) and np.all(cl["p1_mean"] <= cl["p1_max"])
+    assert np.all(cl["p2_min"] <= cl["p2_mean"]) and np.all(cl["p2_mean"] <= cl["p2_max"])
+    assert np.all(np.diff(cl["group"].astype(np.int64)) >= 0)
+    b = capi.Context(contigs)
+    b.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w2 = sharded.ShardedRun(b, sharded.Comm(dev)).run(0, qual=20, fast=True)
+    cl2, _ = b.fetch(abi.STAGE_CLUSTERS)
+    assert w2 == w and zlib.crc32(cl2.tobytes()) == crcs[0]
+    b.close()
+    o = pyoracle.Oracle(contigs, synth_gpu.to_numpy_cols(cols))
+    ow, rc = o.run(20, fast=True)
+    exp, _ = o.fetch(abi.STAGE_CLUSTERS)
+    assert rc == 0 and ow == w and np.array_equal(cl, exp)
+    assert n_valid == int(((exp["flags"] & 2) != 0).sum()) > 1000
+    ctx.close()
+    o.close()
+
+
 @pytest.mark.parametrize("fast", [True, False])
 def test_panel_shape_vs_oracle(fast):
     """BASELINE.json configs[3] at test size: reads piled over fusion loci, ~20 % split reads whose clip points
