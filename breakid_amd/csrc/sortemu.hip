@@ -1140,6 +1140,44 @@ __global__ __launch_bounds__(256) void k_se_decompose(const uint64_t *__restrict
 }
 }  // namespace
 
+// __final_insertion_sort.  What the introsort loop (and the heapsorts) leave is ordered between segments and arbitrary
+// only inside the left-over segments of at most 16 elements, so the stable sort by key is local: every such segment
+// lies entirely inside a 32-element window of one of two tilings (offset 0 and offset 16), and a stable sort of every
+// window of both tilings sorts the array (a window sort never disturbs what is already in order).  One half-wave per
+// window: rank by counting over the 32 elements, (group, key) compared so that windows may straddle groups.
+namespace
+{
+__global__ __launch_bounds__(256) void k_se_window_sort(uint32_t *__restrict__ key, uint32_t *__restrict__ idx, const uint32_t *__restrict__ gof, uint32_t n, uint32_t offset)
+{
+  const uint32_t lane = threadIdx.x & 63, half = lane & 32u, wl = lane & 31u;
+  const uint64_t p = (uint64_t) offset + ((uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+  unsigned long long k64 = ~0ull;
+  uint32_t kk = 0, xx = 0;
+  if (p < n)
+  {
+    kk = key[p];
+    xx = idx[p];
+    k64 = ((unsigned long long) gof[p] << 32) | kk;
+  }
+  // already in order (heapsorted stretches, sorted input): nothing to do for this wave
+  const unsigned long long prev = __shfl_up(k64, 1, 64);
+  if (__ballot(wl != 0 && prev > k64) == 0ull) return;
+  uint32_t rank = 0;
+#pragma unroll 8
+  for (uint32_t j = 0; j < 32; ++j)
+  {
+    const unsigned long long o = __shfl(k64, (int) (half + j), 64);
+    rank += (o < k64 || (o == k64 && j < wl)) ? 1u : 0u;
+  }
+  if (p < n)
+  {
+    const uint64_t d = p - wl + rank;  // elements beyond n carry the largest key and rank last
+    key[d] = kk;
+    idx[d] = xx;
+  }
+}
+}  // namespace
+
 void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const uint64_t *goff, uint32_t ng, uint64_t n64, SortEmuBufs &b, hipStream_t st)
 {
   if (n64 == 0 || ng == 0) return;
@@ -1320,7 +1358,14 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     }
     if (getenv("BK_DEBUG_SORT")) fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
   }
-  // __final_insertion_sort == stable sort by key of what the introsort loop left
+  // __final_insertion_sort == stable sort by key of what the introsort loop left: two tilings of 32-element windows
+  static const bool radix_final = getenv("BK_FINAL_RADIX") != nullptr;  // the general stable radix sort (debugging)
+  if (!radix_final)
+  {
+    hipLaunchKernelGGL(k_se_window_sort, dim3(cdiv(n, 256)), dim3(256), 0, st, key, idx, gof, n, 0u);
+    if (n > 16) hipLaunchKernelGGL(k_se_window_sort, dim3(cdiv(n - 16, 256)), dim3(256), 0, st, key, idx, gof, n, 16u);
+    return;
+  }
   uint64_t *ck = b.ck.as<uint64_t>(n);
   hipLaunchKernelGGL(k_se_compose, dim3(cdiv(n, 256)), dim3(256), 0, st, key, gof, n, ck);
   int gbits = 1;
