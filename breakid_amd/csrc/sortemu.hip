@@ -348,8 +348,21 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
 // which keeps them ordered per address for one wavefront; the loop therefore only waits for its loads
 // (`s_waitcnt vmcnt(0)` before their use also covers the older stores) and does not drain the store acknowledgements
 // at the top of every step (0.34 -> 0.26 us per step).  The caller drains before it reads the result.
-// one sift step of every pop in flight (idle lanes: len = 0 -> no store, state unchanged)
-#define BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                         \
+// Two ways to keep idle lanes (no pop in flight) harmless.  Global memory: their store is masked by EXEC and len = 0
+// marks them.  LDS: an idle lane points at a spare slot behind the heap (h1 = m + 2, v55), so it runs the same
+// unmasked instructions as everybody else - its "children" are out of range, its store hits the spare slot, and it
+// can never be an ancestor of the leaf to detach; that takes 7 instructions out of an iteration.
+#define BK_MASKED_STORE(ST) "v_cmp_ne_u32_e64 s[58:59], 0, v41\n s_and_saveexec_b64 s[56:57], s[58:59]\n" ST "s_mov_b64 exec, s[56:57]\n"
+#define BK_PLAIN_STORE(ST) ST
+#define BK_IDLE_BY_LEN "v_cndmask_b32_e64 v40, v40, v53, s[54:55]\n v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"
+#define BK_IDLE_BY_SLOT "v_cndmask_b32_e64 v40, v55, v53, s[54:55]\n"
+#define BK_CHECK_ACTIVE_LEN "v_cmp_ne_u32_e64 s[60:61], 0, v41\n s_and_b64 vcc, vcc, s[60:61]\n v_cmp_eq_u32_e64 s[60:61], s43, v54\n s_and_b64 s[60:61], s[60:61], s[58:59]\n"
+#define BK_CHECK_ACTIVE_SLOT "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"
+#define BK_ANY_ACTIVE_LEN "v_cmp_ne_u32_e32 vcc, 0, v41\n"
+#define BK_ANY_ACTIVE_SLOT "v_cmp_ne_u32_e32 vcc, v40, v55\n"
+
+// one sift step of every pop in flight
+#define BK_HEAP_SIFT(LD2_KIDS, STORE_HOLE, WAIT_LOADS, IDLE_UPD)                                                                         \
   "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
   "v_cmp_le_u32_e64 s[48:49], v44, v41\n"                                                                                  \
   "v_cmp_lt_u32_e64 s[50:51], v44, v41\n"                                                                                  \
@@ -357,7 +370,6 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
   "v_cndmask_b32_e64 v45, v60, v45, s[48:49]\n"                                                                            \
   LD2_KIDS                                                                                                                \
   "v_lshl_add_u32 v52, v40, 3, s40\n"                                                                                      \
-  "v_cmp_ne_u32_e64 s[58:59], 0, v41\n"                                                                                    \
   "v_mov_b32 v54, v40\n"                                                                                                   \
   WAIT_LOADS                                                                                                              \
   "v_cmp_ge_u32_e32 vcc, v49, v47\n"                                                                                       \
@@ -368,16 +380,13 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
   "s_and_b64 s[54:55], vcc, s[48:49]\n"                                                                                    \
   "v_cndmask_b32_e64 v51, v43, v51, s[54:55]\n"                                                                            \
   "v_cndmask_b32_e64 v50, v42, v50, s[54:55]\n"                                                                            \
-  "s_and_saveexec_b64 s[56:57], s[58:59]\n"                                                                                \
-  ST_HOLE                                                                                                                 \
-  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  STORE_HOLE                                                                                                              \
   "v_addc_co_u32_e64 v53, vcc, v44, 0, s[52:53]\n"                                                                         \
-  "v_cndmask_b32_e64 v40, v40, v53, s[54:55]\n"                                                                            \
-  "v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"
+  IDLE_UPD
 
 // Loop A = the iteration right after a launch (the next pop may not start yet: lag 2), loop B = iterations that may
 // launch: they prefetch the root and the leaf to detach together with the children of the holes.
-#define BK_HEAP_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, ST_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL)                                      \
+#define BK_HEAP_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, STORE_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL, IDLE_UPD, CHECK_ACTIVE, ANY_ACTIVE)                                      \
   "v_mov_b32 v62, %[lane]\n"                                                                                               \
   "s_mov_b32 s62, %[plo]\n s_mov_b32 s63, %[phi]\n"                                                                          \
   "s_sub_u32 s40, %[base], 8\n"                                                                                            \
@@ -386,16 +395,16 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
   "s_flbit_i32_b32 s44, s43\n"                                                                                             \
   "s_lshl_b32 s47, s43, 3\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
   "s_mov_b32 s45, %[budget]\n"                                                                                             \
-  "v_mov_b32 v40, 1\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
+  "s_add_u32 s47, %[m], 2\n v_mov_b32 v55, s47\n v_mov_b32 v40, v55\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
   "s_branch BK_B_%=\n"                                                                                                     \
   "BK_A_%=:\n"                                                                                                            \
   WAIT_ALL                                                                                                                \
-  BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                             \
+  BK_HEAP_SIFT(LD2_KIDS, STORE_HOLE, WAIT_LOADS, IDLE_UPD)                                                                             \
   "s_sub_u32 s45, s45, 1\n"                                                                                                \
   "s_cbranch_scc1 BK_DONE_%=\n"                                                                                            \
   "BK_B_%=:\n"                                                                                                            \
   WAIT_ALL LD1_ROOT LD1_LEAF                                                                                              \
-  BK_HEAP_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                             \
+  BK_HEAP_SIFT(LD2_KIDS, STORE_HOLE, WAIT_LOADS, IDLE_UPD)                                                                             \
   "s_cmp_ge_u32 s41, s46\n"                                                                                                \
   "s_cbranch_scc1 BK_NOMORE_%=\n"                                                                                          \
   "v_ffbh_u32_e32 v63, v40\n"                                                                                              \
@@ -404,10 +413,7 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
   "v_cmp_eq_u32_e32 vcc, v64, v40\n"                                                                                       \
   "v_cmp_gt_u32_e64 s[60:61], 32, v63\n"                                                                                   \
   "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
-  "v_cmp_ne_u32_e64 s[60:61], 0, v41\n"                                                                                    \
-  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
-  "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
-  "s_and_b64 s[60:61], s[60:61], s[58:59]\n"                                                                               \
+  CHECK_ACTIVE                                                                                                            \
   "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
   "s_cbranch_vccnz BK_BNEXT_%=\n"                                                                                          \
   "s_and_b32 s47, s41, 63\n"                                                                                               \
@@ -425,7 +431,7 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
   "s_cbranch_scc0 BK_A_%=\n"                                                                                               \
   "s_branch BK_DONE_%=\n"                                                                                                  \
   "BK_NOMORE_%=:\n"                                                                                                       \
-  "v_cmp_ne_u32_e32 vcc, 0, v41\n"                                                                                         \
+  ANY_ACTIVE                                                                                                              \
   "s_cbranch_vccz BK_DONE_%=\n"                                                                                            \
   "BK_BNEXT_%=:\n"                                                                                                        \
   "s_sub_u32 s45, s45, 1\n"                                                                                                \
@@ -436,7 +442,7 @@ template <class M> __device__ void sort_heap_lag2(const M &mem, const uint32_t m
 
 #define BK_HEAP_CLOBBERS                                                                                                     \
   "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v56", "v57", "v58", \
-      "v59", "v60", "v61", "v62", "v63", "v64", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",    \
+      "v55", "v59", "v60", "v61", "v62", "v63", "v64", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",    \
       "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory"
 
 template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, const uint32_t m, const uint32_t stop)
@@ -452,14 +458,15 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   uint32_t left;
   if (GLB)
     asm volatile(BK_HEAP_ASM("global_load_dwordx2 v[56:57], v60, s[62:63]\n", "global_load_dwordx2 v[58:59], v61, s[62:63]\n",
-                             "global_load_dwordx4 v[46:49], v45, s[62:63]\n", "global_store_dwordx2 v52, v[50:51], s[62:63]\n",
-                             "global_store_dwordx2 v61, v[56:57], s[62:63]\n", "s_waitcnt vmcnt(0)\n", "")
+                             "global_load_dwordx4 v[46:49], v45, s[62:63]\n", BK_MASKED_STORE("global_store_dwordx2 v52, v[50:51], s[62:63]\n"),
+                             "global_store_dwordx2 v61, v[56:57], s[62:63]\n", "s_waitcnt vmcnt(0)\n", "", BK_IDLE_BY_LEN, BK_CHECK_ACTIVE_LEN, BK_ANY_ACTIVE_LEN)
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
   else
     asm volatile(BK_HEAP_ASM("ds_read_b64 v[56:57], v60\n", "ds_read_b64 v[58:59], v61\n", "ds_read2_b64 v[46:49], v45 offset1:1\n",
-                             "ds_write_b64 v52, v[50:51]\n", "ds_write_b64 v61, v[56:57]\n", "s_waitcnt lgkmcnt(0)\n", "")
+                             BK_PLAIN_STORE("ds_write_b64 v52, v[50:51]\n"), "ds_write_b64 v61, v[56:57]\n", "s_waitcnt lgkmcnt(0)\n", "", BK_IDLE_BY_SLOT,
+                             BK_CHECK_ACTIVE_SLOT, BK_ANY_ACTIVE_SLOT)
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
@@ -472,7 +479,7 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
 }
 
 // ---- the same pipeline for 4-byte entries (rank << 16 | local index): value v42, its key v43, children v46/v47 ----
-#define BK_HEAP32_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                       \
+#define BK_HEAP32_SIFT(LD2_KIDS, STORE_HOLE, WAIT_LOADS, IDLE_UPD)                                                                       \
   "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
   "v_cmp_le_u32_e64 s[48:49], v44, v41\n"                                                                                  \
   "v_cmp_lt_u32_e64 s[50:51], v44, v41\n"                                                                                  \
@@ -480,7 +487,6 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   "v_cndmask_b32_e64 v45, v60, v45, s[48:49]\n"                                                                            \
   LD2_KIDS                                                                                                                \
   "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
-  "v_cmp_ne_u32_e64 s[58:59], 0, v41\n"                                                                                    \
   "v_mov_b32 v54, v40\n"                                                                                                   \
   WAIT_LOADS                                                                                                              \
   "v_lshrrev_b32 v48, 16, v46\n"                                                                                           \
@@ -492,14 +498,11 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   "v_cmp_ge_u32_e32 vcc, v51, v43\n"                                                                                       \
   "s_and_b64 s[54:55], vcc, s[48:49]\n"                                                                                    \
   "v_cndmask_b32_e64 v50, v42, v50, s[54:55]\n"                                                                            \
-  "s_and_saveexec_b64 s[56:57], s[58:59]\n"                                                                                \
-  ST_HOLE                                                                                                                 \
-  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  STORE_HOLE                                                                                                              \
   "v_addc_co_u32_e64 v53, vcc, v44, 0, s[52:53]\n"                                                                         \
-  "v_cndmask_b32_e64 v40, v40, v53, s[54:55]\n"                                                                            \
-  "v_cndmask_b32_e64 v41, 0, v41, s[54:55]\n"
+  IDLE_UPD
 
-#define BK_HEAP32_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, ST_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL)                                    \
+#define BK_HEAP32_ASM(LD1_ROOT, LD1_LEAF, LD2_KIDS, STORE_HOLE, ST_LEAF, WAIT_LOADS, WAIT_ALL, IDLE_UPD, CHECK_ACTIVE, ANY_ACTIVE)                                    \
   "v_mov_b32 v62, %[lane]\n"                                                                                               \
   "s_mov_b32 s62, %[plo]\n s_mov_b32 s63, %[phi]\n"                                                                          \
   "s_sub_u32 s40, %[base], 4\n"                                                                                            \
@@ -508,16 +511,16 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   "s_flbit_i32_b32 s44, s43\n"                                                                                             \
   "s_lshl_b32 s47, s43, 2\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
   "s_mov_b32 s45, %[budget]\n"                                                                                             \
-  "v_mov_b32 v40, 1\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
+  "s_add_u32 s47, %[m], 2\n v_mov_b32 v55, s47\n v_mov_b32 v40, v55\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
   "s_branch BK_B_%=\n"                                                                                                     \
   "BK_A_%=:\n"                                                                                                            \
   WAIT_ALL                                                                                                                \
-  BK_HEAP32_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                           \
+  BK_HEAP32_SIFT(LD2_KIDS, STORE_HOLE, WAIT_LOADS, IDLE_UPD)                                                                           \
   "s_sub_u32 s45, s45, 1\n"                                                                                                \
   "s_cbranch_scc1 BK_DONE_%=\n"                                                                                            \
   "BK_B_%=:\n"                                                                                                            \
   WAIT_ALL LD1_ROOT LD1_LEAF                                                                                              \
-  BK_HEAP32_SIFT(LD2_KIDS, ST_HOLE, WAIT_LOADS)                                                                           \
+  BK_HEAP32_SIFT(LD2_KIDS, STORE_HOLE, WAIT_LOADS, IDLE_UPD)                                                                           \
   "s_cmp_ge_u32 s41, s46\n"                                                                                                \
   "s_cbranch_scc1 BK_NOMORE_%=\n"                                                                                          \
   "v_ffbh_u32_e32 v63, v40\n"                                                                                              \
@@ -526,10 +529,7 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   "v_cmp_eq_u32_e32 vcc, v64, v40\n"                                                                                       \
   "v_cmp_gt_u32_e64 s[60:61], 32, v63\n"                                                                                   \
   "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
-  "v_cmp_ne_u32_e64 s[60:61], 0, v41\n"                                                                                    \
-  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
-  "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
-  "s_and_b64 s[60:61], s[60:61], s[58:59]\n"                                                                               \
+  CHECK_ACTIVE                                                                                                            \
   "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
   "s_cbranch_vccnz BK_BNEXT_%=\n"                                                                                          \
   "s_and_b32 s47, s41, 63\n"                                                                                               \
@@ -547,7 +547,7 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   "s_cbranch_scc0 BK_A_%=\n"                                                                                               \
   "s_branch BK_DONE_%=\n"                                                                                                  \
   "BK_NOMORE_%=:\n"                                                                                                       \
-  "v_cmp_ne_u32_e32 vcc, 0, v41\n"                                                                                         \
+  ANY_ACTIVE                                                                                                              \
   "s_cbranch_vccz BK_DONE_%=\n"                                                                                            \
   "BK_BNEXT_%=:\n"                                                                                                        \
   "s_sub_u32 s45, s45, 1\n"                                                                                                \
@@ -569,14 +569,15 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm32(uint32_t *bu
   uint32_t left;
   if (GLB)
     asm volatile(BK_HEAP32_ASM("global_load_dword v56, v60, s[62:63]\n", "global_load_dword v58, v61, s[62:63]\n",
-                               "global_load_dwordx2 v[46:47], v45, s[62:63]\n", "global_store_dword v52, v50, s[62:63]\n",
-                               "global_store_dword v61, v56, s[62:63]\n", "s_waitcnt vmcnt(0)\n", "")
+                               "global_load_dwordx2 v[46:47], v45, s[62:63]\n", BK_MASKED_STORE("global_store_dword v52, v50, s[62:63]\n"),
+                               "global_store_dword v61, v56, s[62:63]\n", "s_waitcnt vmcnt(0)\n", "", BK_IDLE_BY_LEN, BK_CHECK_ACTIVE_LEN, BK_ANY_ACTIVE_LEN)
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
   else
     asm volatile(BK_HEAP32_ASM("ds_read_b32 v56, v60\n", "ds_read_b32 v58, v61\n", "ds_read2_b32 v[46:47], v45 offset1:1\n",
-                               "ds_write_b32 v52, v50\n", "ds_write_b32 v61, v56\n", "s_waitcnt lgkmcnt(0)\n", "")
+                               BK_PLAIN_STORE("ds_write_b32 v52, v50\n"), "ds_write_b32 v61, v56\n", "s_waitcnt lgkmcnt(0)\n", "", BK_IDLE_BY_SLOT,
+                               BK_CHECK_ACTIVE_SLOT, BK_ANY_ACTIVE_SLOT)
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
