@@ -47,13 +47,18 @@ struct FinSeg
   uint32_t first, last;
   int32_t depth;
 };
+// two lists: segments of at most FIN_SMALL elements (one wavefront each) from the front, the others from the back
+constexpr uint32_t FIN_SMALL = 256;
 __device__ __forceinline__ void fin_append(FinSeg *__restrict__ fl, uint32_t *__restrict__ fin, uint32_t first, uint32_t last, int32_t depth)
 {
   FinSeg f;
   f.first = first;
   f.last = last;
   f.depth = depth;
-  fl[atomicAdd(fin, 1u)] = f;
+  if (last - first <= FIN_SMALL)
+    fl[atomicAdd(fin, 1u)] = f;
+  else
+    fl[fin[2] - 1 - atomicAdd(fin + 1, 1u)] = f;  // fin[2] = capacity of the list
 }
 
 // cnt entries: (#segments) | (#elements in them) << 32, scanned together
@@ -881,24 +886,38 @@ struct LSeg
   uint32_t pivot;
   int32_t depth;
 };
-constexpr uint32_t FIN_EPT = FIN_MAX / 256;
-constexpr uint32_t FIN_SEGS = 128;  // > FIN_MAX / 17 live sub-segments
 constexpr uint16_t FIN_DEAD = 0xFFFFu;
 
-__global__ __launch_bounds__(256) void k_se_finish(const FinSeg *__restrict__ fl, uint32_t nf, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
-                                                   uint2 *__restrict__ heap_list)
+// exclusive scan over the T threads of a finisher block (T = 64: one wave, no barrier; T = 256: prims' block scan)
+template <uint32_t T> __device__ __forceinline__ uint32_t fin_scan(uint32_t v, uint32_t *lds, uint32_t &total)
 {
-  __shared__ uint32_t s_key[FIN_MAX], s_idx[FIN_MAX];
-  __shared__ uint32_t s_lr[FIN_MAX + 1];  // exclusive prefix of (L-stopper | R-stopper << 16)
-  __shared__ uint16_t s_posL[FIN_MAX + 2], s_posR[FIN_MAX + 2];
-  __shared__ uint16_t s_segof[FIN_MAX];
+  if (T == 64)
+  {
+    const uint32_t inc = prims::wave_inclusive_scan(v);
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+  }
+  return prims::block_exclusive_scan(v, lds, total);
+}
+
+// FMAX = capacity in elements, T = threads; `step` = +1 / -1 walks the list from the front / the back
+template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_finish(const FinSeg *__restrict__ fl, uint32_t nf, int step, uint32_t *__restrict__ key,
+                                                                                        uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
+{
+  constexpr uint32_t FIN_EPT = FMAX / T;
+  constexpr uint32_t FIN_SEGS = FMAX / 16 + 2;  // > FMAX / 17 live sub-segments
+  static_assert(FIN_SEGS <= T, "one thread per sub-segment");
+  __shared__ uint32_t s_key[FMAX], s_idx[FMAX];
+  __shared__ uint32_t s_lr[FMAX + 1];  // exclusive prefix of (L-stopper | R-stopper << 16)
+  __shared__ uint16_t s_posL[FMAX + 2], s_posR[FMAX + 2];
+  __shared__ uint16_t s_segof[FMAX];
   __shared__ LSeg s_seg[2][FIN_SEGS];
   __shared__ uint32_t s_scan[prims::WAVES];
   __shared__ uint32_t s_ns;
   if (blockIdx.x >= nf) return;
-  const FinSeg fs = fl[blockIdx.x];
+  const FinSeg fs = fl[(long long) step * blockIdx.x];
   const uint32_t m = fs.last - fs.first, g0 = fs.first, tid = threadIdx.x;
-  for (uint32_t e = tid; e < m; e += 256)
+  for (uint32_t e = tid; e < m; e += T)
   {
     s_key[e] = key[g0 + e];
     s_idx[e] = idx[g0 + e];
@@ -985,14 +1004,14 @@ __global__ __launch_bounds__(256) void k_se_finish(const FinSeg *__restrict__ fl
         sum += v;
       }
       uint32_t total;
-      const uint32_t base = prims::block_exclusive_scan(sum, s_scan, total);
+      const uint32_t base = fin_scan<T>(sum, s_scan, total);
 #pragma unroll
       for (uint32_t k = 0; k < FIN_EPT; ++k)
       {
         const uint32_t e = tid * FIN_EPT + k;
         if (e <= m) s_lr[e] = base + loc[k];
       }
-      if (m == FIN_MAX && tid == 0) s_lr[FIN_MAX] = total;
+      if (m == FMAX && tid == 0) s_lr[FMAX] = total;
     }
     __syncthreads();
     // position lists: l_j from the left, r_j from the right
@@ -1071,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_se_finish(const FinSeg *__restrict__ fl
         }
       }
       uint32_t total;
-      uint32_t o = prims::block_exclusive_scan(cnt, s_scan, total);
+      uint32_t o = fin_scan<T>(cnt, s_scan, total);
       if (tid < ns && sg.depth >= 0)
       {
         S[tid].base = (uint16_t) o;
@@ -1118,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_se_finish(const FinSeg *__restrict__ fl
     __syncthreads();
     cur ^= 1;
   }
-  for (uint32_t e = tid; e < m; e += 256)
+  for (uint32_t e = tid; e < m; e += T)
   {
     key[g0 + e] = s_key[e];
     idx[g0 + e] = s_idx[e];
@@ -1188,9 +1207,11 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   uint32_t *err = b.err.as<uint32_t>(4);
   HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
   // level 0 segments = groups larger than 16
-  FinSeg *fin_list = b.fin_list.as<FinSeg>((uint64_t) n / 16 + ng + 16);  // every entry holds more than 16 elements
-  uint32_t *fin = b.fin_cnt.as<uint32_t>(1);
-  HIP_CHECK(hipMemsetAsync(fin, 0, 4, st));
+  const uint32_t fin_cap = (uint32_t) ((uint64_t) n / 16 + ng + 16);  // every entry holds more than 16 elements
+  FinSeg *fin_list = b.fin_list.as<FinSeg>(fin_cap);
+  uint32_t *fin = b.fin_cnt.as<uint32_t>(4);  // small count, large count, capacity
+  const uint32_t fin_init[4] = {0, 0, fin_cap, 0};
+  HIP_CHECK(hipMemcpyAsync(fin, fin_init, 16, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, fin_list, fin);
   prims::exclusive_scan<unsigned long long>(cnt, cnt, ng, b.scan_tmp, st);
   unsigned long long tot = 0;
@@ -1243,10 +1264,26 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     }
   }
   // segments of at most FIN_MAX elements: the rest of their introsort loop in LDS, one workgroup each
-  uint32_t nfin = 0;
-  HIP_CHECK(hipMemcpyAsync(&nfin, fin, 4, hipMemcpyDeviceToHost, st));
+  uint32_t nfin2[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(nfin2, fin, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
-  if (nfin) hipLaunchKernelGGL(k_se_finish, dim3(nfin), dim3(256), 0, st, fin_list, nfin, key, idx, err, heap_list);
+  const uint32_t nfin = nfin2[0] + nfin2[1];
+  static const bool dbg_fin = getenv("BK_DEBUG_SORT") != nullptr;
+  double t_fin0 = 0;
+  if (dbg_fin) t_fin0 = now_ms();
+  if (nfin2[1]) hipLaunchKernelGGL((k_se_finish<FIN_MAX, 256>), dim3(nfin2[1]), dim3(256), 0, st, fin_list + (fin_cap - 1), nfin2[1], -1, key, idx, err, heap_list);
+  if (dbg_fin)
+  {
+    HIP_CHECK(hipStreamSynchronize(st));
+    fprintf(stderr, "[sortemu] finisher: %u segments of 257..%u elements %.3f ms", nfin2[1], FIN_MAX, now_ms() - t_fin0);
+    t_fin0 = now_ms();
+  }
+  if (nfin2[0]) hipLaunchKernelGGL((k_se_finish<FIN_SMALL, 64>), dim3(nfin2[0]), dim3(64), 0, st, fin_list, nfin2[0], 1, key, idx, err, heap_list);
+  if (dbg_fin)
+  {
+    HIP_CHECK(hipStreamSynchronize(st));
+    fprintf(stderr, ", %u segments of 17..%u elements %.3f ms\n", nfin2[0], FIN_SMALL, now_ms() - t_fin0);
+  }
   if (ns_initial || nfin)
   {
     // segments that exhausted introsort's depth limit are heapsorted now (they are final: no children)
