@@ -574,16 +574,7 @@ int bk_split_breakpoints(bk_ctx *ctx, double w, uint64_t *n_valid)
       split_breakpoints(r, ctx->d_split.get<bk_split>(), ctx->hc.n_split, ctx->clusters_ptr(), ctx->n_clusters, w, (int) ctx->hc.max_span,
                         ctx->d_hdr.get<int32_t>(), ctx->bb, ctx->st);
     }
-    if (n_valid)
-    {
-      const void *d;
-      uint64_t cnt;
-      int rc = bk_fetch(ctx, BK_STAGE_CLUSTERS, &d, &cnt, nullptr, nullptr);
-      if (rc != BK_OK) throw bk_error(rc, ctx->err);
-      uint64_t v = 0;
-      for (auto &c : ctx->f_clusters) v += (c.flags & 2u) ? 1 : 0;
-      *n_valid = v;
-    }
+    if (n_valid) *n_valid = count_valid_clusters(ctx->clusters_ptr(), ctx->n_clusters, ctx->bb, ctx->st);
   });
 }
 

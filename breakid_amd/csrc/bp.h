@@ -28,10 +28,12 @@ struct BpWork
 
 struct BpBufs
 {
-  DevBuf key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted;
+  DevBuf key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted, nvalid;
   prims::RadixBufs radix;
 };
 
+// clusters with a voted breakpoint pair (flags bit 1), counted on the device
+uint64_t count_valid_clusters(const bk_cluster *cl, uint64_t ncl, BpBufs &b, hipStream_t st);
 void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st);
 // returns the number of clusters that passed the near-diagonal filter; clusters_out holds them in (group key order, id) order
 uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32_t *gof, const uint32_t *cl, uint64_t n, uint32_t ng, const uint32_t *gkey,

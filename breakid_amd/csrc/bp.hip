@@ -627,6 +627,25 @@ void bp_finish(bk_cluster *cl, uint64_t ncl, const uint32_t *depth, BpBufs &b, h
   if (ncl) hipLaunchKernelGGL(k_bp_finish, dim3(cdiv(ncl, 256)), dim3(256), 0, st, cl, (uint32_t) ncl, b.voted.get<uint32_t>(), depth);
 }
 
+// number of clusters that carry a voted breakpoint pair (flags bit 1), counted on the device
+__global__ __launch_bounds__(256) void k_count_valid(const bk_cluster *__restrict__ cl, uint32_t ncl, unsigned long long *__restrict__ out)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool v = c < ncl && (cl[c].flags & 2u);
+  const unsigned long long b = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long) __popcll(b));
+}
+uint64_t count_valid_clusters(const bk_cluster *cl, uint64_t ncl, BpBufs &b, hipStream_t st)
+{
+  if (ncl == 0) return 0;
+  unsigned long long *d = b.nvalid.as<unsigned long long>(1), h = 0;
+  HIP_CHECK(hipMemsetAsync(d, 0, 8, st));
+  hipLaunchKernelGGL(k_count_valid, dim3(cdiv(ncl, 256)), dim3(256), 0, st, cl, (uint32_t) ncl, d);
+  HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return h;
+}
+
 // single table: all four phases back to back (the counts need no exchange)
 void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
                        hipStream_t st)
