@@ -1247,11 +1247,12 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR);
       hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
       prims::exclusive_scan<unsigned long long>(cnt, cnt, ns, b.scan_tmp, st);
+      // the children are written while the host waits for their count (at most 2 per segment: 2 * ns <= capacity)
+      if (2ull * ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
+      hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin);
       HIP_CHECK(hipMemcpyAsync(&tot, cnt + ns, 8, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       const uint32_t ns2 = (uint32_t) tot;
-      if (ns2 > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-      hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin);
       std::swap(segs, segs2);
       ns = ns2;
       na = (uint32_t) (tot >> 32);
