@@ -981,6 +981,8 @@ template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_f
     // stopper flags and their prefix sums (FIN_EPT consecutive elements per thread)
     {
       uint32_t loc[FIN_EPT], sum = 0;
+      uint16_t ps = FIN_DEAD;  // the FIN_EPT consecutive elements of a thread mostly share their sub-segment
+      LSeg sg = {};
 #pragma unroll
       for (uint32_t k = 0; k < FIN_EPT; ++k)
       {
@@ -991,7 +993,11 @@ template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_f
           const uint16_t s = s_segof[e];
           if (s != FIN_DEAD)
           {
-            const LSeg sg = S[s];
+            if (s != ps)
+            {
+              sg = S[s];
+              ps = s;
+            }
             if (sg.depth >= 0 && e > sg.first)
             {
               const uint32_t kk = s_key[e];
@@ -1015,21 +1021,32 @@ template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_f
     }
     __syncthreads();
     // position lists: l_j from the left, r_j from the right
-#pragma unroll
-    for (uint32_t k = 0; k < FIN_EPT; ++k)
     {
-      const uint32_t e = tid * FIN_EPT + k;
-      if (e >= m) continue;
-      const uint16_t s = s_segof[e];
-      if (s == FIN_DEAD) continue;
-      const LSeg sg = S[s];
-      if (sg.depth < 0 || e <= sg.first) continue;
-      const uint32_t kk = s_key[e], here = s_lr[e], bs = s_lr[sg.first], en = s_lr[sg.last];
-      if (kk >= sg.pivot) s_posL[sg.first + 1 + ((here & 0xFFFFu) - (bs & 0xFFFFu))] = (uint16_t) e;
-      if (kk <= sg.pivot)
+      uint16_t ps = FIN_DEAD;
+      LSeg sg = {};
+      uint32_t bs = 0, en = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < FIN_EPT; ++k)
       {
-        const uint32_t nR = (en >> 16) - (bs >> 16), jl = (here >> 16) - (bs >> 16);
-        s_posR[sg.first + 1 + (nR - 1 - jl)] = (uint16_t) e;
+        const uint32_t e = tid * FIN_EPT + k;
+        if (e >= m) continue;
+        const uint16_t s = s_segof[e];
+        if (s == FIN_DEAD) continue;
+        if (s != ps)
+        {
+          sg = S[s];
+          ps = s;
+          bs = s_lr[sg.first];
+          en = s_lr[sg.last];
+        }
+        if (sg.depth < 0 || e <= sg.first) continue;
+        const uint32_t kk = s_key[e], here = s_lr[e];
+        if (kk >= sg.pivot) s_posL[sg.first + 1 + ((here & 0xFFFFu) - (bs & 0xFFFFu))] = (uint16_t) e;
+        if (kk <= sg.pivot)
+        {
+          const uint32_t nR = (en >> 16) - (bs >> 16), jl = (here >> 16) - (bs >> 16);
+          s_posR[sg.first + 1 + (nR - 1 - jl)] = (uint16_t) e;
+        }
       }
     }
     __syncthreads();
