@@ -67,6 +67,33 @@ def test_fast_random_vs_oracle(seed, n, loci, ppl, noise):
     o.close()
 
 
+@pytest.mark.parametrize("fast", [True, False])
+def test_fuzz_small_tables_vs_oracle(fast):
+    """Randomised shapes: few / many loci, tight jitter (equal coordinates: tie orders of every std::sort, window and
+    AHC tie rule), high duplicate and low-mapq rates, supplementary-flag partners, tiny contigs, every stage compared."""
+    contig_sets = [[("chr1", 400_000), ("chr2", 300_000)], [("chr1", 2_000_000), ("chr2", 1_500_000), ("chr3", 900_000), ("chrX", 700_000), ("chrM", 60_000)]]
+    rng = np.random.default_rng(4321 if fast else 8765)
+    for case in range(10 if fast else 6):
+        contigs = contig_sets[case % 2]
+        loci = int(rng.integers(1, 40))
+        ppl = int(rng.integers(2, 120 if fast else 60))
+        noise = int(rng.integers(0, 600))
+        jitter = int(rng.choice([0, 1, 3, 30, 250, 900]))
+        n = 2 * (loci * ppl + noise) + 3 * 8 * loci + int(rng.integers(200, 20_000))
+        ds = synth.make_cfg(int(rng.integers(1, 1 << 30)), contigs, n, loci, ppl, noise, split_every=int(rng.integers(1, 4)), splits_per_locus=int(rng.integers(0, 12)),
+                            jitter=jitter, read_len=int(rng.choice([50, 100, 150])), same_chr_frac=float(rng.choice([0.0, 0.3, 1.0])),
+                            partner_flag=int(rng.choice([0x100, 0x800])), dup_frac=float(rng.choice([0.0, 0.01, 0.3])), lowq_frac=float(rng.choice([0.0, 0.02, 0.4])))
+        cols = ds.to_soa()
+        qual = int(rng.choice([0, 20, 30]))
+        ctx, mean, sd, w = _run_gpu(contigs, cols, fast=fast, qual=qual)
+        o = pyoracle.Oracle(contigs, cols)
+        assert (mean, sd) == o.isize_stats(), case
+        o.run(qual, fast=fast)
+        _compare_stages(ctx, o)
+        ctx.close()
+        o.close()
+
+
 def test_empty_and_tiny_inputs():
     contigs = [("chr1", 100000), ("chr2", 100000)]
     ds = synth.Dataset(contigs)
