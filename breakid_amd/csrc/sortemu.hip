@@ -11,7 +11,13 @@
 // level is a data-parallel step: with l_j the j-th position (from the left) whose key >= pivot and r_j
 // the j-th position (from the right) whose key <= pivot, the loop swaps (l_j, r_j) for every j < J,
 // J = #{j : l_j < r_j}, and returns cut = min(l_J, r_{J-1}) (l_0 when J = 0).  All segments of all groups
-// advance one level per pass (prefix sums give the ranks), then one stable radix sort finishes.
+// advance one level per pass (prefix sums give the ranks).
+//
+// Layout of this file, in the order a sort goes through it:
+//   device-wide level loop (k_se_pivot / flags / lists / swap / child_*)  segments of more than FIN_MAX elements, compact index space
+//   k_se_finish                                                          segments of at most FIN_MAX elements: the same loop in LDS
+//   k_hr_* + k_se_heapsort<0,1,2>                                        segments that hit the depth limit: make_heap + pipelined sort_heap
+//   k_se_window_sort                                                     __final_insertion_sort as two tilings of stable window sorts
 #include "bk_common.h"
 #include "prims.h"
 #include "sortemu.h"
