@@ -65,6 +65,18 @@ class BgzfWriter:
             self._flush_block(bytes(self.buf[:0xFF00]))
             del self.buf[:0xFF00]
 
+    def flush(self) -> None:
+        """ends the current block (htslib's bgzf_flush)"""
+        if self.buf:
+            self._flush_block(bytes(self.buf))
+            self.buf.clear()
+
+    def write_record(self, rec: bytes) -> None:
+        """htslib's bam_write1: bgzf_flush_try first, so that no record straddles two blocks"""
+        if len(self.buf) + len(rec) > 0xFF00:
+            self.flush()
+        self.write(rec)
+
     def _flush_block(self, data: bytes) -> None:
         c = zlib.compressobj(self.level, zlib.DEFLATED, -15)
         comp = c.compress(data) + c.flush()
@@ -101,8 +113,9 @@ def encode_record(qname: str, flag: int, tid: int, pos: int, mapq: int, cigar: S
 
 
 def write_bam(path: str, contigs: Sequence[Tuple[str, int]], records: Iterable[bytes],
-              header_text: Optional[str] = None) -> None:
-    """records: iterable of encode_record() bytes, already coordinate sorted."""
+              header_text: Optional[str] = None, aligned: bool = False) -> None:
+    """records: iterable of encode_record() bytes, already coordinate sorted.  aligned=True writes blocks the way
+    htslib does (header flushed, no record across a block boundary); the default cuts blocks at fixed 0xFF00 bytes."""
     if header_text is None:
         header_text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join(
             "@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in contigs)
@@ -113,6 +126,12 @@ def write_bam(path: str, contigs: Sequence[Tuple[str, int]], records: Iterable[b
         nb = n.encode() + b"\0"
         hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
     w.write(hdr)
+    if aligned:
+        w.flush()
+        for r in records:
+            w.write_record(r)
+        w.close()
+        return
     chunk = bytearray()
     for r in records:
         chunk += r

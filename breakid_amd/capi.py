@@ -36,7 +36,7 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_debug_std_sort", "bk_debug_ahc", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
            "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
@@ -100,6 +100,10 @@ def lib():
         L.bk_bam_header.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint32))]
         L.bk_bam_decode.argtypes = [vp, C.POINTER(abi.Soa), C.c_char_p, C.c_size_t]
         L.bk_bam_close.argtypes = [vp]
+        L.bk_bam_decode_device.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(abi.Soa), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)),
+                                           C.POINTER(C.POINTER(C.c_uint32)), C.c_char_p, C.c_size_t]
+        L.bk_bam_dev_free.argtypes = [vp]
+        L.bk_debug_bgzf_inflate.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.c_char_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -154,6 +158,11 @@ class Context:
         soa = abi.soa_from_numpy(cols)
         self._keep = (cols, soa)
         self._check(self.L.bk_upload_records(self.h, C.byref(soa), abi.BK_MEM_HOST))
+
+    def attach_device_table(self, table):
+        """table: DeviceBamTable; the columns are used in place (BK_MEM_DEVICE)"""
+        self._keep = table
+        self._check(self.L.bk_upload_records(self.h, C.byref(table.soa), abi.BK_MEM_DEVICE))
 
     def upload_soa(self, handle):
         """handle: BamTable from decode_bam(keep=True); the decoder's (pinned) columns go straight to bk_upload_records."""
@@ -242,6 +251,34 @@ class Context:
         n = C.c_int()
         self._check(self.L.bk_timing(self.h, C.byref(names), C.byref(ms), C.byref(by), C.byref(n)))
         return [(names[i].decode(), float(ms[i]), int(by[i])) for i in range(n.value)]
+
+
+class DeviceBamTable:
+    """Record table decoded on the GPU (bk_bam_decode_device): device-resident columns owned by the library."""
+
+    def __init__(self, L, h, soa, contigs):
+        self.L, self.h, self.soa, self.contigs = L, h, soa, contigs
+
+    def close(self):
+        if self.h:
+            self.L.bk_bam_dev_free(self.h)
+            self.h = None
+
+
+def decode_bam_device(path, device=0):
+    """GPU BGZF inflate + BAM decode -> DeviceBamTable; raises BreakIDError(BK_ERR_IO) for files that are not block aligned."""
+    L = lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    s = abi.Soa()
+    nt = C.c_int()
+    names = C.POINTER(C.c_char_p)()
+    lens = C.POINTER(C.c_uint32)()
+    rc = L.bk_bam_decode_device(path.encode(), device, C.byref(h), C.byref(s), C.byref(nt), C.byref(names), C.byref(lens), err, 512)
+    if rc != 0:
+        raise BreakIDError(rc, err.value.decode())
+    contigs = [(names[i].decode(), int(lens[i])) for i in range(nt.value)]
+    return DeviceBamTable(L, h, s, contigs)
 
 
 class BamTable:

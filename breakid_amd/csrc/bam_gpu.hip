@@ -123,3 +123,372 @@ extern "C" int bk_debug_bgzf_inflate(const void *file, uint64_t n, void *out, ui
     return ex.code;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// BAM records -> columns, on the device.  htslib never lets a record straddle two BGZF blocks (bgzf_flush_try before
+// every record), so the blocks of such a file are independent jobs here as well: one lane walks the records of one
+// block (the 4-byte length chain is serial only inside a block).  A first pass validates the chain (it must end
+// exactly at the end of the block, every record must be well formed) and counts records / CIGAR words / aux bytes per
+// block; exclusive scans place the blocks; a second pass writes the columns.  Files whose records do straddle blocks
+// (other writers) are reported with BK_ERR_IO "not block aligned" and take the host decoder.
+namespace
+{
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24); }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8); }
+
+struct BamCols
+{
+  int32_t *tid, *pos, *mtid, *mpos, *isize;
+  uint16_t *flag;
+  uint8_t *mapq;
+  uint64_t *qhash;
+  uint32_t *cigar_off, *cigar, *aux_off;
+  uint8_t *aux;
+};
+struct BlockCount
+{
+  uint32_t n_rec, n_cig, n_aux, bad;
+};
+
+// aux walk of one record (sam.c:1267-1279 semantics, as bam_reader.cc): first SA:Z and OC:Z
+__device__ __forceinline__ void aux_scan(const uint8_t *r, uint32_t q, uint32_t bs, uint32_t &sa_at, uint32_t &sa_len, uint32_t &oc_at, uint32_t &oc_len)
+{
+  sa_at = oc_at = 0;
+  sa_len = oc_len = 0;
+  bool has_sa = false, has_oc = false;
+  while (q + 3 <= bs)
+  {
+    const uint8_t t0 = r[q], t1 = r[q + 1], type = r[q + 2];
+    q += 3;
+    uint32_t len;
+    switch (type)
+    {
+    case 'A': case 'c': case 'C': len = 1; break;
+    case 's': case 'S': len = 2; break;
+    case 'i': case 'I': case 'f': len = 4; break;
+    case 'd': len = 8; break;
+    case 'Z': case 'H':
+    {
+      uint32_t e = q;
+      while (e < bs && r[e]) ++e;
+      if (type == 'Z')
+      {
+        if (!has_sa && t0 == 'S' && t1 == 'A')
+        {
+          has_sa = true;
+          sa_at = q;
+          sa_len = e - q;
+        }
+        if (!has_oc && t0 == 'O' && t1 == 'C')
+        {
+          has_oc = true;
+          oc_at = q;
+          oc_len = e - q;
+        }
+      }
+      len = e - q + 1;
+      break;
+    }
+    case 'B':
+    {
+      if (q + 5 > bs) return;
+      const uint8_t sub = r[q];
+      const uint32_t cnt = ld32(r + q + 1);
+      const uint32_t es = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u : 4u;
+      const unsigned long long l64 = 5ull + (unsigned long long) cnt * es;
+      if (l64 > bs) return;
+      len = (uint32_t) l64;
+      break;
+    }
+    default:
+      return;
+    }
+    q += len;
+  }
+}
+
+__device__ __forceinline__ uint64_t qname_hash_dev(const uint8_t *name, uint32_t l_name)
+{
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (uint32_t i = 0; i < l_name; ++i)
+  {
+    const uint8_t c = name[i];
+    if (!c) break;  // bam_get_qname is a C string
+    h ^= c;
+    h *= 0x100000001B3ull;
+  }
+  h ^= h >> 30;
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 27;
+  h *= 0x94D049BB133111EBull;
+  h ^= h >> 31;
+  return h;
+}
+
+// EMIT = false: validate + count; EMIT = true: write the columns (bases from the scans)
+template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk,
+                                                                         uint32_t first_off, int32_t n_ref, BlockCount *__restrict__ cnt, const uint64_t *__restrict__ rec_base,
+                                                                         const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, BamCols c)
+{
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  BlockCount bc = {0, 0, 0, 0};
+  if (b >= first_blk)
+  {
+    const BgzfBlock bb = blk[b];
+    const uint8_t *d = data + bb.out_off;
+    uint32_t p = b == first_blk ? first_off : 0u;
+    uint64_t ri = EMIT ? rec_base[b] : 0, ci = EMIT ? cig_base[b] : 0, ai = EMIT ? aux_base[b] : 0;
+    while (p < bb.isize)
+    {
+      if (p + 36 > bb.isize)
+      {
+        bc.bad = 1;
+        break;
+      }
+      const uint32_t bs = ld32(d + p);
+      const uint8_t *r = d + p + 4;
+      if (bs < 32 || (unsigned long long) p + 4 + bs > bb.isize)
+      {
+        bc.bad = 1;  // a record that continues in the next block (or garbage)
+        break;
+      }
+      const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
+      const unsigned long long need = 32ull + l_name + 4ull * n_cig + ((unsigned long long) l_seq + 1) / 2 + l_seq;
+      const int32_t tid = (int32_t) ld32(r);
+      if (need > bs || tid < -1 || tid >= n_ref)
+      {
+        bc.bad = 1;
+        break;
+      }
+      const uint32_t q = (uint32_t) need;
+      uint32_t sa_at, sa_len, oc_at, oc_len;
+      aux_scan(r, q, bs, sa_at, sa_len, oc_at, oc_len);
+      const uint32_t blob = sa_len ? sa_len + (oc_len ? oc_len + 1 : 0) : 0;
+      if (EMIT)
+      {
+        c.tid[ri] = tid;
+        c.pos[ri] = (int32_t) ld32(r + 4);
+        c.mapq[ri] = r[9];
+        c.flag[ri] = (uint16_t) ld16(r + 14);
+        c.mtid[ri] = (int32_t) ld32(r + 20);
+        c.mpos[ri] = (int32_t) ld32(r + 24);
+        c.isize[ri] = (int32_t) ld32(r + 28);
+        c.qhash[ri] = qname_hash_dev(r + 32, l_name);
+        c.cigar_off[ri] = (uint32_t) ci;
+        c.aux_off[ri] = (uint32_t) ai;
+        const uint8_t *cg = r + 32 + l_name;
+        for (uint32_t k = 0; k < n_cig; ++k) c.cigar[ci + k] = ld32(cg + 4 * k);
+        if (blob)
+        {
+          uint64_t w = ai;
+          if (oc_len)
+          {
+            for (uint32_t k = 0; k < oc_len; ++k) c.aux[w++] = r[oc_at + k];
+            c.aux[w++] = '\t';
+          }
+          for (uint32_t k = 0; k < sa_len; ++k) c.aux[w++] = r[sa_at + k];
+        }
+      }
+      ++ri;
+      ci += n_cig;
+      ai += blob;
+      ++bc.n_rec;
+      bc.n_cig += n_cig;
+      bc.n_aux += blob;
+      p += 4 + bs;
+    }
+  }
+  if (!EMIT) cnt[b] = bc;
+}
+
+__global__ void k_bam_count_split(const BlockCount *__restrict__ cnt, uint32_t nblk, uint64_t *__restrict__ nr, uint64_t *__restrict__ nc, uint64_t *__restrict__ na, uint32_t *__restrict__ err)
+{
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  nr[b] = cnt[b].n_rec;
+  nc[b] = cnt[b].n_cig;
+  na[b] = cnt[b].n_aux;
+  if (cnt[b].bad) atomicOr(err, 2u);
+}
+}  // namespace
+
+#include <zlib.h>
+#include <cstdio>
+#include <ctime>
+#include "prims.h"
+
+struct bk_bam_dev
+{
+  std::vector<std::string> names;
+  std::vector<const char *> name_ptrs;
+  std::vector<uint32_t> lens;
+  DevBuf tid, pos, mtid, mpos, isize, flag, mapq, qhash, cigar_off, cigar, aux_off, aux;
+};
+
+namespace
+{
+double now_s2()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+bool host_inflate_block(const uint8_t *file, const BgzfBlock &b, std::vector<uint8_t> &out)
+{
+  const size_t base = out.size();
+  out.resize(base + b.isize);
+  if (!b.isize) return true;
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  zs.next_in = const_cast<Bytef *>(file + b.in_off);
+  zs.avail_in = b.clen;
+  zs.next_out = out.data() + base;
+  zs.avail_out = b.isize;
+  const int rc = inflate(&zs, Z_FINISH);
+  inflateEnd(&zs);
+  return rc == Z_STREAM_END;
+}
+}  // namespace
+
+extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
+                                    char *err, size_t errlen)
+{
+  bk_bam_dev *h = nullptr;
+  try
+  {
+    if (!path || !out || !cols) throw bk_error(BK_ERR_ARG, "bk_bam_decode_device: null argument");
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(device));
+    const double t0 = now_s2();
+    FILE *f = fopen(path, "rb");
+    if (!f) throw bk_error(BK_ERR_IO, std::string("cannot open ") + path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> file(sz > 0 ? (size_t) sz : 0);
+    const bool read_ok = sz <= 0 || fread(file.data(), 1, (size_t) sz, f) == (size_t) sz;
+    fclose(f);
+    if (!read_ok) throw bk_error(BK_ERR_IO, "short read");
+    std::vector<BgzfBlock> blocks;
+    uint64_t total = 0;
+    std::string why;
+    if (!bgzf_scan_blocks(file.data(), file.size(), blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+    // header: inflated on the host, block by block, until the reference list is complete
+    h = new bk_bam_dev();
+    std::vector<uint8_t> head;
+    size_t hb = 0;  // blocks inflated so far
+    auto need = [&](size_t bytes) {
+      while (head.size() < bytes)
+      {
+        if (hb >= blocks.size()) throw bk_error(BK_ERR_IO, "truncated BAM header");
+        if (!host_inflate_block(file.data(), blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
+        ++hb;
+      }
+    };
+    need(12);
+    if (memcmp(head.data(), "BAM\1", 4) != 0) throw bk_error(BK_ERR_IO, "not a BAM file");
+    size_t p = 4;
+    const uint32_t l_text = rd32h(head.data() + p);
+    p += 4 + (size_t) l_text;
+    need(p + 4);
+    const uint32_t n_ref = rd32h(head.data() + p);
+    p += 4;
+    for (uint32_t i = 0; i < n_ref; ++i)
+    {
+      need(p + 4);
+      const uint32_t l_name = rd32h(head.data() + p);
+      p += 4;
+      need(p + l_name + 4);
+      h->names.emplace_back((const char *) head.data() + p, l_name ? l_name - 1 : 0);
+      p += l_name;
+      h->lens.push_back(rd32h(head.data() + p));
+      p += 4;
+    }
+    for (auto &s : h->names) h->name_ptrs.push_back(s.c_str());
+    // first record: block and offset
+    uint32_t first_blk = 0;
+    uint64_t acc = 0;
+    while (first_blk < blocks.size() && acc + blocks[first_blk].isize <= p) acc += blocks[first_blk++].isize;
+    const uint32_t first_off = (uint32_t) (p - acc);
+    const uint32_t nblk = (uint32_t) blocks.size();
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    if ((double) file.size() + (double) total * 1.25 > 0.8 * (double) free_b)
+      throw bk_error(BK_ERR_LIMIT, "BAM too large for the single-batch GPU decoder (use bk_bam_open / bk_bam_decode)");
+    const double t1 = now_s2();
+    DevBuf dfile, dblk, ddata, derr, dcnt, dnr, dnc, dna, dscan;
+    uint8_t *df = dfile.as<uint8_t>(file.size() + 8);
+    BgzfBlock *db = dblk.as<BgzfBlock>((uint64_t) nblk + 1);
+    uint8_t *dd = ddata.as<uint8_t>(total + 64);
+    uint32_t *de = derr.as<uint32_t>(1);
+    HIP_CHECK(hipMemcpy(df, file.data(), file.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(db, blocks.data(), (size_t) nblk * sizeof(BgzfBlock), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(de, 0, 4));
+    const double t2 = now_s2();
+    hipStream_t st = nullptr;
+    launch_bgzf_inflate(df, db, nblk, dd, de, st);
+    BlockCount *dc = dcnt.as<BlockCount>((uint64_t) nblk + 1);
+    uint64_t *nr = dnr.as<uint64_t>((uint64_t) nblk + 1), *nc = dnc.as<uint64_t>((uint64_t) nblk + 1), *na = dna.as<uint64_t>((uint64_t) nblk + 1);
+    BamCols none = {};
+    hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, none);
+    hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nblk, 256)), dim3(256), 0, st, dc, nblk, nr, nc, na, de);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) nr, (unsigned long long *) nr, nblk, dscan, st);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) nc, (unsigned long long *) nc, nblk, dscan, st);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) na, (unsigned long long *) na, nblk, dscan, st);
+    uint64_t tot[3] = {0, 0, 0};
+    uint32_t he = 0;
+    HIP_CHECK(hipMemcpyAsync(&tot[0], nr + nblk, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&tot[1], nc + nblk, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&tot[2], na + nblk, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&he, de, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (he & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
+    if (he & 2u) throw bk_error(BK_ERR_IO, "BAM records are not BGZF-block aligned (or a record is corrupt): use the host decoder");
+    const uint64_t n = tot[0];
+    if (n >= 0xFFFFFFF0ull || tot[1] >= 0xFFFFFFF0ull || tot[2] >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one BAM");
+    BamCols c;
+    c.tid = h->tid.as<int32_t>(n + 4);
+    c.pos = h->pos.as<int32_t>(n + 4);
+    c.mtid = h->mtid.as<int32_t>(n + 4);
+    c.mpos = h->mpos.as<int32_t>(n + 4);
+    c.isize = h->isize.as<int32_t>(n + 4);
+    c.flag = h->flag.as<uint16_t>(n + 4);
+    c.mapq = h->mapq.as<uint8_t>(n + 4);
+    c.qhash = h->qhash.as<uint64_t>(n + 4);
+    c.cigar_off = h->cigar_off.as<uint32_t>(n + 4);
+    c.aux_off = h->aux_off.as<uint32_t>(n + 4);
+    c.cigar = h->cigar.as<uint32_t>(tot[1] + 4);
+    c.aux = h->aux.as<uint8_t>(tot[2] + 4);
+    hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nr, nc, na, c);
+    const uint32_t ends[2] = {(uint32_t) tot[1], (uint32_t) tot[2]};
+    HIP_CHECK(hipMemcpyAsync(c.cigar_off + n, &ends[0], 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c.aux_off + n, &ends[1], 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const double t3 = now_s2();
+    memset(cols, 0, sizeof *cols);
+    cols->n = n;
+    cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
+    cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
+    cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
+    cols->n_cigar_words = (uint32_t) tot[1];
+    cols->n_aux_bytes = (uint32_t) tot[2];
+    if (n_targets) *n_targets = (int) h->names.size();
+    if (names) *names = h->name_ptrs.data();
+    if (lens) *lens = h->lens.data();
+    if (getenv("BREAKID_FEED_STATS"))
+      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %u BGZF blocks: read+scan+header %.3f s, H2D %.3f s, inflate+decode on the GPU %.3f s\n",
+              (unsigned long long) n, file.size() / 1e6, nblk, t1 - t0, t2 - t1, t3 - t2);
+    *out = h;
+    return BK_OK;
+  }
+  catch (const bk_error &ex)
+  {
+    delete h;
+    if (err && errlen) snprintf(err, errlen, "%s", ex.what());
+    return ex.code;
+  }
+}
+
+extern "C" void bk_bam_dev_free(bk_bam_dev *h) { delete h; }

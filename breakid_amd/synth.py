@@ -67,7 +67,7 @@ class Dataset:
         self.recs.sort(key=lambda r: ((r.tid if r.tid >= 0 else big), r.pos))
 
     # ---- BAM + side files -------------------------------------------------------------
-    def write_bam(self, path: str) -> None:
+    def write_bam(self, path: str, aligned: bool = False) -> None:
         def gen():
             for r in self.recs:
                 aux = []
@@ -77,7 +77,7 @@ class Dataset:
                     aux.append(("OC", r.oc))
                 yield bamio.encode_record(r.qname, r.flag, r.tid, r.pos, r.mapq, bamio.parse_cigar(r.cigar),
                                           r.mtid, r.mpos, r.isize, aux)
-        bamio.write_bam(path, self.contigs, gen())
+        bamio.write_bam(path, self.contigs, gen(), aligned=aligned)
 
     # ---- SoA ---------------------------------------------------------------------------
     def to_soa(self) -> Dict[str, np.ndarray]:

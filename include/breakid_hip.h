@@ -217,6 +217,17 @@ int bk_bam_header(const bk_bam *b, int *n_targets, const char *const **names, co
 int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen);
 void bk_bam_close(bk_bam *b);
 
+/* The same feed on the GPU: the file image goes to HBM, BGZF blocks are inflated one wavefront each (bgzf_gpu.hip) and
+ * the records are decoded into device-resident columns (cols holds device pointers: bk_upload_records(ctx, cols,
+ * BK_MEM_DEVICE)).  Needs a BAM whose records do not straddle BGZF blocks (every htslib / samtools file); others fail
+ * with BK_ERR_IO and take bk_bam_open / bk_bam_decode.  Single batch: file image + inflated stream must fit in HBM. */
+typedef struct bk_bam_dev bk_bam_dev;
+int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
+                         char *err, size_t errlen);
+void bk_bam_dev_free(bk_bam_dev *h);
+/* test / measurement hook: inflates a whole BGZF file image on the GPU, bytes back to the host */
+int bk_debug_bgzf_inflate(const void *file, uint64_t n, void *out, uint64_t out_cap, uint64_t *out_len, float *kernel_ms, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif
