@@ -310,22 +310,42 @@ int main(int argc, char *argv[])
     exit(1);
   }
   std::cout << "start to stats the insert size...\n";
+  // feed: the GPU decoder first (BGZF inflate + record decode on the device; every htslib-written BAM qualifies), the
+  // host decoder (all cores, pinned columns) for files whose records straddle BGZF blocks or that exceed one batch.
+  // BREAKID_HOST_DECODE=1 forces the host path.
   char err[512];
   bk_bam *bam = nullptr;
-  if (bk_bam_open(inp_file.c_str(), &bam, err, sizeof err) != BK_OK)
-  {
-    std::cerr << "Error: can not open bam-file: " << inp_file << std::endl;
-    exit(1);
-  }
+  bk_bam_dev *dbam = nullptr;
   int nt = 0;
   const char *const *names = nullptr;
   const uint32_t *lens = nullptr;
-  bk_bam_header(bam, &nt, &names, &lens);
   bk_soa soa;
-  if (bk_bam_decode(bam, &soa, err, sizeof err) != BK_OK)
+  int soa_where = BK_MEM_HOST;
   {
-    std::cerr << "Error: " << err << std::endl;
-    exit(1);
+    FILE *probe = fopen(inp_file.c_str(), "rb");
+    if (!probe)
+    {
+      std::cerr << "Error: can not open bam-file: " << inp_file << std::endl;
+      exit(1);
+    }
+    fclose(probe);
+  }
+  if (!getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device(inp_file.c_str(), 0, &dbam, &soa, &nt, &names, &lens, err, sizeof err) == BK_OK)
+    soa_where = BK_MEM_DEVICE;
+  else
+  {
+    dbam = nullptr;
+    if (bk_bam_open(inp_file.c_str(), &bam, err, sizeof err) != BK_OK)
+    {
+      std::cerr << "Error: can not open bam-file: " << inp_file << std::endl;
+      exit(1);
+    }
+    bk_bam_header(bam, &nt, &names, &lens);
+    if (bk_bam_decode(bam, &soa, err, sizeof err) != BK_OK)
+    {
+      std::cerr << "Error: " << err << std::endl;
+      exit(1);
+    }
   }
   {
     std::ifstream rn((nib_dir + "/ref_names.txt").c_str());
@@ -346,7 +366,7 @@ int main(int argc, char *argv[])
     exit(rc == BK_ERR_CIGAR ? -1 : 1);
   };
   int rc;
-  if ((rc = bk_upload_records(ctx, &soa, BK_MEM_HOST)) != BK_OK) die(rc);
+  if ((rc = bk_upload_records(ctx, &soa, soa_where)) != BK_OK) die(rc);
   double mean = 0, sd = 0;
   if ((rc = bk_isize_stats(ctx, &mean, &sd)) != BK_OK) die(rc);
   std::cout << "the insert size mean: " << mean << ", the insert size sd:" << sd << " .\n";
@@ -450,6 +470,7 @@ int main(int argc, char *argv[])
       << (cluster_end - cluster_start) / double(CLOCKS_PER_SEC) << "\t" << 0.0 << "\t" << (end - start) / double(CLOCKS_PER_SEC) << std::endl;
   }
   bk_free(ctx);
-  bk_bam_close(bam);
+  if (bam) bk_bam_close(bam);
+  if (dbam) bk_bam_dev_free(dbam);
   return 0;
 }

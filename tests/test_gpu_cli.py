@@ -29,13 +29,15 @@ def test_cli_txt_outputs_match_reference(golden_dir, name, mode):
     ds, refgene = _dataset(name)
     with tempfile.TemporaryDirectory() as tmp:
         bam = os.path.join(tmp, name + ".bam")
-        ds.write_bam(bam)
+        aligned = mode == "fast"   # blocks as htslib writes them -> the GPU decoder; fixed-size blocks -> the host decoder
+        ds.write_bam(bam, aligned=aligned)
         open(bam + ".bai", "wb").close()  # the hot path streams the BAM; only the presence of the index is part of the CLI contract
         side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
         prefix = os.path.join(tmp, "out")
         cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all"] + (["-fast"] if mode == "fast" else [])
-        r = subprocess.run(cmd, env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True)
+        r = subprocess.run(cmd, env=dict(os.environ, BREAKID_INSTALLDIR=side["install"], BREAKID_FEED_STATS="1"), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
+        assert ("[feed/gpu]" in r.stderr) == aligned and ("[feed]" in r.stderr) == (not aligned), r.stderr[-500:]
         for suffix in ("_fusion.txt", "_fusion_all.txt"):
             got = open(prefix + suffix).read()
             exp = open(os.path.join(golden_dir, "%s.%s%s" % (name, mode, suffix))).read()

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def write_bam(path, n_pairs, seed=7, read_len=150):
+def write_bam(path, n_pairs, seed=7, read_len=150, aligned=True):
     rng = np.random.default_rng(seed)
     contigs = [("chr1", 249250621), ("chr2", 243199373), ("chr3", 198022430)]
     lens = np.asarray([l for _, l in contigs])
@@ -39,10 +39,15 @@ def write_bam(path, n_pairs, seed=7, read_len=150):
     hdr = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(contigs))
     for nm, ln in contigs:
         hdr += struct.pack("<I", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<I", ln)
-    raw = hdr + a.tobytes()
+    body = a.tobytes()
+    raw = hdr + body
+    if aligned:   # blocks as htslib writes them: header flushed, whole records per block
+        per = (0xFF00 // (rec_len + 4)) * (rec_len + 4)
+        chunks = [hdr] + [body[o:o + per] for o in range(0, len(body), per)]
+    else:
+        chunks = [raw[o:o + 0xFF00] for o in range(0, len(raw), 0xFF00)]
     with open(path, "wb") as f:
-        for off in range(0, len(raw), 0xFF00):
-            blk = raw[off:off + 0xFF00]
+        for blk in chunks:
             c = zlib.compressobj(1, zlib.DEFLATED, -15)
             comp = c.compress(blk) + c.flush()
             f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(blk), len(blk)))
@@ -83,3 +88,17 @@ if __name__ == "__main__":
                     (t3 - t2) * 1e3, handle.nbytes / (t3 - t2) / 1e9, n / (t3 - t2) / 1e6, (t4 - t3) * 1e3, n / (t4 - t2) / 1e6), flush=True)
             ctx.close()
         handle.close()
+    # the same file through the GPU decoder (file image -> HBM, inflate + record decode on the device)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        table = capi.decode_bam_device(path)
+        t1 = time.perf_counter()
+        ctx = capi.Context(table.contigs)
+        ctx.attach_device_table(table)
+        w, nv = ctx.run(qual=20, fast=True)
+        ctx.sync()
+        t2 = time.perf_counter()
+        print("GPU decoder: file -> device table %.3f s = %.1f M records/s, %.0f MB/s of BAM; run %.1f ms" % (t1 - t0, n / (t1 - t0) / 1e6, comp / (t1 - t0) / 1e6, (t2 - t1) * 1e3), flush=True)
+        ctx.close()
+        table.close()
