@@ -11,5 +11,12 @@ struct BgzfBlock
 };
 
 constexpr uint64_t BGZF_OUT_ALIGN = 256;
-// one wavefront per block; *err_dev |= 1 when a block is malformed or does not produce isize bytes
-void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, uint32_t *err_dev, hipStream_t st);
+constexpr uint32_t BGZF_BATCH_BLOCKS = 16384;          // blocks per decode/resolve launch pair
+constexpr uint32_t BGZF_TOKENS_PER_BLOCK = 21846;      // a match produces >= 3 bytes: at most 65536 / 3 per block
+// scratch of launch_bgzf_inflate: 8-byte match tokens + one counter per block of a batch
+uint32_t bgzf_scratch_blocks(uint32_t nblk);
+inline uint64_t bgzf_scratch_bytes(uint32_t nblk) { return (uint64_t) bgzf_scratch_blocks(nblk) * ((uint64_t) BGZF_TOKENS_PER_BLOCK * 8u + 4u) + 64u; }
+// decode (one wavefront per block) + resolve (one workgroup per block); scratch_dev = bgzf_scratch_bytes(nblk) bytes;
+// file_dev must be 4-byte aligned with >= 4 readable bytes after the last block; *err_dev |= 1 when a block is malformed
+// or does not produce isize bytes
+void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st);

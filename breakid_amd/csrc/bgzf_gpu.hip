@@ -1,171 +1,94 @@
-// BGZF inflate on the GPU (RFC 1951 DEFLATE, one wavefront per BGZF block).
+// BGZF inflate on the GPU (RFC 1951 DEFLATE) in two kernels.
 //
 // the host decoder is the feed limit (all cores of the box: ~3.6 GB/s of inflated BAM).  BGZF blocks are
-// independent <= 64 KiB deflate streams, so a file is thousands to millions of independent jobs.  One wave takes one
-// block; all 64 lanes run the Huffman decoder redundantly on the same state (every load is a broadcast, the control
-// flow is uniform), lane 0 stores literals, and a match of `len` bytes at distance `dist` is copied by the whole wave
-// at once: out[o + k] = out[o - dist + k mod dist] reads only bytes that are already final.  The decoder is a serial
-// chain of LDS round trips (~0.3 us per symbol), so throughput comes from many blocks in flight and everything hot sits
-// in a small LDS footprint: the last 16 KiB of output as a ring (flushed to global memory in aligned 256-byte chunks;
-// the rare match that reaches farther back reads the flushed bytes from global memory), a 512-byte window of the
-// compressed input refilled by the whole wave, and the decode tables (a 10-bit direct table for literal/length codes,
-// 8-bit for distances, canonical count/symbol arrays for the rare longer codes, as in zlib's puff.c).  Output offsets of
-// the blocks are multiples of 256 bytes, so every flush is 64 aligned dword stores.  (Earlier versions: input and
-// output in global memory - every refill and every match copy paid a full memory round trip, 29 ms per block; the
-// whole 64 KiB block staged in LDS - only two waves per CU.)
+// independent <= 64 KiB deflate streams, so a file is thousands to millions of independent jobs, but inside a block
+// the Huffman decode is one serial chain (a code's position depends on every code before it) and the LZ77 copies
+// depend on earlier output.  The two dependences are separated:
+//
+//  k_bgzf_decode   one wavefront per block walks the bit stream, 64 bit positions per round.  Lane k decodes the
+//                  symbol that WOULD start at bit k of the unread input - literal/length code from a 10-bit direct
+//                  table whose entries carry the pre-computed base value and extra-bit count, the length's extra
+//                  bits, the distance code (8-bit direct table) and its extra bits - and so knows where the next
+//                  symbol would start.  The scalar unit then only follows that chain from bit 0 (one readlane per
+//                  symbol) and collects the mask of lanes that hold real symbols.  Those lanes get their output
+//                  positions from a wave prefix sum of the output lengths; literal lanes store their byte, match lanes
+//                  store one token (position, length, distance).  No byte is copied here, so there is no output
+//                  window in LDS and no load->store chain; ~7 KiB of LDS per wave (tables, 768-byte input window fed by
+//                  a register prefetch).  Codes longer than the direct tables, and the block headers, take a
+//                  scalar path.  The Huffman tables are built by the 64 lanes in parallel (counts by LDS atomics,
+//                  canonical ranks by ballots).  (Measured before this layout: the whole decoder on the scalar unit,
+//                  ~110 scalar instructions per symbol; the CU's scalar issue rate was the limit whatever the
+//                  occupancy: 33 ms for 8736 blocks.)
+//  k_bgzf_resolve  one 1024-thread workgroup per block builds parent[p] for all positions in LDS (p itself for
+//                  literals, p - dist inside a match) and runs pointer jumping, parent[p] = parent[parent[p]], in place
+//                  and without barriers until every position points at a literal (a jump only ever replaces an
+//                  ancestor by an older ancestor, so racing reads are harmless); ~log2(longest copy chain) sweeps.
+//                  Then out[p] = out[parent[p]].
+//
+// (Earlier versions, 8736 blocks / 570 MB inflated: matches copied through an LDS ring of the last 16-32 KiB of output -
+// 62-90 ms, bound by waves per CU and the copy's LDS round trips; input and output in global memory - every refill and
+// every match copy paid a full memory round trip, 29 ms per block.)
 #include "bk_common.h"
 #include "bgzf_gpu.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace
 {
 constexpr int LIT_FAST = 10, DIST_FAST = 8;
-constexpr uint32_t IN_WIN = 512;  // bytes of compressed input held in LDS
-constexpr uint32_t RING = 16384;  // bytes of recent output held in LDS (power of two; 8 KiB measured ~10 % faster on synthetic data, but real BAMs match farther back)
-constexpr uint32_t FLUSH = 256;   // the ring is written out in aligned chunks of this size
-constexpr uint32_t NEAR = RING - 2 * FLUSH - 258;  // matches up to this distance read the ring, farther ones read global memory
+// symbol statistics (build with -DBGZF_STATS, run with BK_BGZF_STATS=1); off by default
+#ifdef BGZF_STATS
+__device__ unsigned long long g_bgzf_stats[8];
+#define ST(x) x
+#else
+#define ST(x)
+#endif
+constexpr uint32_t CHUNK_DW = 64;            // one dword per lane
+constexpr uint32_t WIN_DW = 3 * CHUNK_DW;    // input window: three chunks in LDS, the fourth on its way in a register
+constexpr uint32_t RESOLVE_THREADS = 1024;
+
+// direct-table entries
+//   literal/length: bits 0-3 code length (0 = longer than the table), 4-6 extra bits, 7-15 length base, 16-23 literal, 24-25 kind
+//   distance:       bits 0-3 code length, 4-7 extra bits, 8-23 distance base, 24 invalid code
+//   code-length code: (symbol << 4) | code length
+enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_BAD = 3 };
+enum : int { T_LITLEN = 0, T_DIST = 1, T_CLEN = 2 };
 
 struct HuffLds
 {
-  uint16_t lfast[1 << LIT_FAST];   // (symbol << 4) | length, 0 = longer than LIT_FAST bits
-  uint16_t dfast[1 << DIST_FAST];
-  uint16_t lsym[288], dsym[32];    // symbols ordered by (length, symbol)
-  uint16_t lcount[16], dcount[16];
-  uint8_t lens[320];               // code lengths while a dynamic header is read
-  uint32_t win[IN_WIN / 4 + 4];    // input window [win_base, win_base + IN_WIN) + slack for the 8-byte reads
+  uint32_t lfast[1 << LIT_FAST];
+  uint32_t dfast[1 << DIST_FAST];
+  uint16_t lsym[288], dsym[32];    // symbols ordered by (length, symbol): the canonical walk for long codes
+  uint32_t lcount[16], dcount[16];
+  uint32_t offs[16], nextc[16];    // table build scratch
+  uint8_t lens[344];               // code lengths: literal/length [0,288), distance [288,320), code-length code [320,339)
+  uint32_t win[WIN_DW];
 };
 
-struct BitReader
-{
-  const uint8_t *in;   // compressed stream (global)
-  uint32_t *win;       // LDS window
-  uint32_t pos, end;   // byte offsets of the next unread byte / the end of the stream
-  uint32_t win_base;   // stream offset of win[0] (multiple of 4 relative to `in`'s own alignment)
-  uint64_t buf;
-  int cnt;
-  // the whole wave loads IN_WIN bytes starting at stream offset `at` (rounded down to the window grid)
-  __device__ __forceinline__ void load_window(uint32_t at)
-  {
-    const uint32_t lane = threadIdx.x & 63;
-    win_base = at & ~(IN_WIN - 1);
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t k = lane; k < IN_WIN / 4 + 4; k += 64)
-    {
-      const uint32_t off = win_base + 4 * k;
-      uint32_t v = 0;
-      if (off + 4 <= end)
-        v = (uint32_t) in[off] | ((uint32_t) in[off + 1] << 8) | ((uint32_t) in[off + 2] << 16) | ((uint32_t) in[off + 3] << 24);
-      else
-        for (uint32_t b = 0; b < 4; ++b)
-          if (off + b < end) v |= (uint32_t) in[off + b] << (8 * b);
-      win[k] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // tops the bit buffer up to >= 56 bits with one unaligned 8-byte read of the window (three aligned words)
-  __device__ __forceinline__ void refill()
-  {
-    if (pos - win_base >= IN_WIN) load_window(pos);
-    const uint32_t r = pos - win_base, i = r >> 2, sh = (r & 3) * 8;
-    // (readfirstlane: every lane holds the same value; saying so moves the decoder's arithmetic to the scalar unit)
-    const uint32_t w0 = __builtin_amdgcn_readfirstlane(win[i]), w1 = __builtin_amdgcn_readfirstlane(win[i + 1]), w2 = __builtin_amdgcn_readfirstlane(win[i + 2]);
-    uint64_t v = ((uint64_t) w1 << 32) | w0;
-    if (sh) v = (v >> sh) | ((uint64_t) w2 << (64 - sh));
-    buf |= v << cnt;                     // bits beyond 64 fall off; they are read again next time
-    const uint32_t took = (uint32_t) (63 - cnt) >> 3;  // whole bytes that fitted
-    pos += took;
-    cnt += (int) took * 8;
-  }
-  __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t) (buf & ((1ull << n) - 1)); }
-  __device__ __forceinline__ void drop(int n)
-  {
-    buf >>= n;
-    cnt -= n;
-  }
-  __device__ __forceinline__ uint32_t bits(int n)
-  {
-    if (cnt < n) refill();
-    const uint32_t v = peek(n);
-    drop(n);
-    return v;
-  }
-};
+// every lane holds the same decoder state; saying so keeps it in scalar registers (the compiler cannot prove it
+// across LDS round trips)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ uint32_t bitrev(uint32_t c, uint32_t len) { return __brev(c) >> (32 - len); }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); }
 
-__device__ __forceinline__ uint32_t bitrev(uint32_t c, int len) { return __brev(c) >> (32 - len); }
-
-// canonical Huffman tables from code lengths (all lanes run it; the LDS writes are identical)
-__device__ __forceinline__ bool build_tables(const uint8_t *lens, int n, uint16_t *fast, int fast_bits, uint16_t *sym, uint16_t *count)
+// inclusive prefix sum over the wave (DPP row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-  for (int i = 0; i < 16; ++i) count[i] = 0;
-  for (int i = 0; i < n; ++i) count[lens[i]]++;
-  for (int i = 0; i < (1 << fast_bits); ++i) fast[i] = 0;
-  if (count[0] == n) return true;  // no codes at all (a distance tree of a literal-only block)
-  int left = 1;
-  for (int len = 1; len < 16; ++len)
-  {
-    left <<= 1;
-    left -= count[len];
-    if (left < 0) return false;  // over-subscribed
-  }
-  uint16_t offs[16], nextc[16];
-  offs[1] = 0;
-  for (int len = 1; len < 15; ++len) offs[len + 1] = offs[len] + count[len];
-  uint32_t code = 0;
-  for (int len = 1; len < 16; ++len)
-  {
-    nextc[len] = (uint16_t) code;
-    code = (code + count[len]) << 1;
-  }
-  for (int s = 0; s < n; ++s)
-  {
-    const int len = lens[s];
-    if (!len) continue;
-    sym[offs[len]++] = (uint16_t) s;
-    const uint32_t c = nextc[len]++;
-    if (len <= fast_bits)
-    {
-      const uint32_t r = bitrev(c, len);
-      for (uint32_t j = r; j < (1u << fast_bits); j += 1u << len) fast[j] = (uint16_t) ((s << 4) | len);
-    }
-  }
-  return true;
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return v;
 }
 
-// one symbol: direct table, else the canonical walk of puff.c (bits arrive LSB first, codes are MSB first)
-__device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *fast, int fast_bits, const uint16_t *sym, const uint16_t *count)
-{
-  const uint32_t e = __builtin_amdgcn_readfirstlane((uint32_t) fast[br.peek(fast_bits)]);
-  if (e)
-  {
-    br.drop(e & 15);
-    return e >> 4;
-  }
-  int code = 0, first = 0, index = 0;
-  uint64_t b = br.buf;
-  for (int len = 1; len < 16; ++len)
-  {
-    code |= (int) (b & 1);
-    b >>= 1;
-    const int c = __builtin_amdgcn_readfirstlane((int) count[len]);
-    if (code - c < first)
-    {
-      br.drop(len);
-      return __builtin_amdgcn_readfirstlane((int) sym[index + (code - first)]);
-    }
-    index += c;
-    first += c;
-    first <<= 1;
-    code <<= 1;
-  }
-  return -1;
-}
-
-// base value and extra bits of length code 257 + ls / distance code ds (RFC 1951 section 3.2.5), computed: a table in
-// constant memory costs a memory round trip per match on this serial path
-__device__ __forceinline__ void len_code(int ls, uint32_t &base, int &extra)
+// base value and extra bits of length code 257 + ls / distance code ds (RFC 1951 section 3.2.5)
+__device__ __forceinline__ void len_code(uint32_t ls, uint32_t &base, uint32_t &extra)
 {
   if (ls < 8)
   {
-    base = 3u + (uint32_t) ls;
+    base = 3u + ls;
     extra = 0;
   }
   else if (ls == 28)
@@ -176,213 +99,523 @@ __device__ __forceinline__ void len_code(int ls, uint32_t &base, int &extra)
   else
   {
     extra = (ls - 4) >> 2;
-    base = 3u + ((4u + (uint32_t) (ls & 3)) << extra);
+    base = 3u + ((4u + (ls & 3)) << extra);
   }
 }
-__device__ __forceinline__ void dist_code(int ds, uint32_t &base, int &extra)
+__device__ __forceinline__ void dist_code(uint32_t ds, uint32_t &base, uint32_t &extra)
 {
   if (ds < 4)
   {
-    base = 1u + (uint32_t) ds;
+    base = 1u + ds;
     extra = 0;
   }
   else
   {
     extra = (ds - 2) >> 1;
-    base = 1u + ((2u + (uint32_t) (ds & 1)) << extra);
+    base = 1u + ((2u + (ds & 1)) << extra);
   }
 }
-__constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+template <int T>
+__device__ __forceinline__ uint32_t make_entry(uint32_t s, uint32_t len)
+{
+  if (T == T_CLEN) return (s << 4) | len;
+  uint32_t base, extra;
+  if (T == T_DIST)
+  {
+    if (s >= 30) return len | (1u << 24);
+    dist_code(s, base, extra);
+    return len | (extra << 4) | (base << 8);
+  }
+  if (s < 256) return len | (s << 16) | (K_LIT << 24);
+  if (s == 256) return len | (K_EOB << 24);
+  if (s > 285) return len | (K_BAD << 24);
+  len_code(s - 257, base, extra);
+  return len | (extra << 4) | (base << 7) | (K_LEN << 24);
+}
 
-// returns the number of bytes produced, or ~0u on a malformed stream
-__device__ __forceinline__ uint32_t inflate_wave(const uint8_t *in, uint32_t in_len, uint8_t *ring, uint8_t *gout, uint32_t out_cap, HuffLds &h)
+// Canonical Huffman tables from n code lengths, built by the wave: counts per length (LDS atomics), first code and
+// first slot of every length (15 serial steps), then 64 symbols at a time: a symbol's rank among the symbols of its
+// length is the number of such symbols in earlier chunks plus the lanes below it in a ballot.  Symbols whose code fits
+// the direct table fill their 2^(fast_bits - len) slots.  Returns false for an over-subscribed set of lengths.
+template <int T>
+__device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint32_t n, uint32_t *fast, uint32_t fast_bits, uint16_t *sym, uint32_t *count)
 {
   const uint32_t lane = threadIdx.x & 63;
-  BitReader br;
-  br.in = in;
-  br.win = h.win;
-  br.pos = 0;
-  br.end = in_len;
-  br.buf = 0;
-  br.cnt = 0;
-  br.load_window(0);
-  uint32_t o = 0, flushed = 0;
-  constexpr uint32_t M = RING - 1;
-  // completed FLUSH-byte chunks leave the ring: 64 lanes x 4 bytes, aligned on both sides
-  auto flush = [&]() {
-    while (flushed + FLUSH <= o)
+  if (lane < 16) count[lane] = 0;
+  for (uint32_t i = lane; i < (1u << fast_bits); i += 64) fast[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t s = lane; s < n; s += 64) atomicAdd(&count[lens[s]], 1u);
+  __builtin_amdgcn_wave_barrier();
+  if (uni(count[0]) == n) return true;  // no codes at all (the distance tree of a literal-only block)
+  int left = 1;
+  uint32_t code = 0, off = 0;
+  for (uint32_t len = 1; len < 16; ++len)
+  {
+    const uint32_t c = uni(count[len]);
+    left = (left << 1) - (int) c;
+    if (left < 0) return false;
+    if (lane == 0)
     {
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(ring + ((flushed + 4 * lane) & M));
-      *reinterpret_cast<uint32_t *>(gout + flushed + 4 * lane) = v;
-      flushed += FLUSH;
+      h.offs[len] = off;
+      h.nextc[len] = code;
     }
-  };
+    off += c;
+    code = (code + c) << 1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t seen[16];  // symbols of each length in earlier chunks (uniform; the loops below are fully unrolled)
+#pragma unroll
+  for (int len = 1; len < 16; ++len) seen[len] = 0;
+  for (uint32_t base = 0; base < n; base += 64)
+  {
+    const uint32_t s = base + lane;
+    const uint32_t mylen = s < n ? lens[s] : 0u;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int len = 1; len < 16; ++len)
+    {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(mylen == (uint32_t) len);
+      if (mylen == (uint32_t) len) rank = seen[len] + lanes_below(m);
+      seen[len] += (uint32_t) __popcll(m);
+    }
+    if (mylen)
+    {
+      sym[h.offs[mylen] + rank] = (uint16_t) s;
+      if (mylen <= fast_bits)
+      {
+        const uint32_t e = make_entry<T>(s, mylen);
+        for (uint32_t j = bitrev(h.nextc[mylen] + rank, mylen); j < (1u << fast_bits); j += 1u << mylen) fast[j] = e;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
+struct Decoder
+{
+  HuffLds &h;
+  const uint32_t *in32;  // the stream's dwords, from the 4-byte boundary at or below its first byte (global)
+  uint32_t bitpos;       // next unread bit, relative to in32
+  uint32_t end_bit;      // end of the stream
+  uint32_t end_dw;       // dwords that may be loaded
+  uint32_t win_dw;       // dword index of win[0]
+  uint32_t pre;          // prefetched dword win_dw + WIN_DW + lane
+  uint32_t lane;
+
+  __device__ __forceinline__ uint32_t load_dw(uint32_t d) const { return d < end_dw ? in32[d] : 0u; }
+  // window = [at, at + WIN_DW) dwords, prefetch of the following chunk under way
+  __device__ __forceinline__ void seek(uint32_t at)
+  {
+    win_dw = at;
+    const uint32_t a = load_dw(at + lane), b = load_dw(at + CHUNK_DW + lane), c = load_dw(at + 2 * CHUNK_DW + lane);
+    pre = load_dw(at + WIN_DW + lane);
+    __builtin_amdgcn_wave_barrier();
+    h.win[lane] = a;
+    h.win[CHUNK_DW + lane] = b;
+    h.win[2 * CHUNK_DW + lane] = c;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // keeps the read position inside the first chunk + a few dwords: the window slides by one chunk, the prefetched
+  // chunk lands in LDS and the next one is requested
+  __device__ __forceinline__ void ensure()
+  {
+    uint32_t ahead = (bitpos >> 5) - win_dw;
+    if (ahead < CHUNK_DW) return;
+    if (ahead >= 2 * CHUNK_DW)
+    {
+      seek(bitpos >> 5);
+      return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t b = h.win[CHUNK_DW + lane], c = h.win[2 * CHUNK_DW + lane];
+    h.win[lane] = b;
+    h.win[CHUNK_DW + lane] = c;
+    h.win[2 * CHUNK_DW + lane] = pre;
+    win_dw += CHUNK_DW;
+    pre = load_dw(win_dw + WIN_DW + lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the next 32 unread bits (uniform)
+  __device__ __forceinline__ uint32_t peek()
+  {
+    ensure();
+    const uint32_t b = bitpos - (win_dw << 5), di = b >> 5, sh = b & 31;
+    const uint32_t w0 = uni(h.win[di]), w1 = uni(h.win[di + 1]);
+    return (uint32_t) ((((uint64_t) w1 << 32) | w0) >> sh);
+  }
+  __device__ __forceinline__ uint32_t bits(uint32_t n)
+  {
+    const uint32_t v = peek() & ((1u << n) - 1u);
+    bitpos += n;
+    return v;
+  }
+};
+
+// canonical walk of puff.c over the bits in w (LSB first; codes are MSB first): symbol and its length, or false
+__device__ __forceinline__ bool walk_code(uint32_t w, const uint16_t *sym, const uint32_t *count, uint32_t &s, uint32_t &len_out)
+{
+  int code = 0, first = 0, index = 0;
+  for (uint32_t len = 1; len < 16; ++len)
+  {
+    code |= (int) (w & 1u);
+    w >>= 1;
+    const int c = (int) uni(count[len]);
+    if (code - c < first)
+    {
+      s = uni(sym[index + (code - first)]);
+      len_out = len;
+      return true;
+    }
+    index += c;
+    first += c;
+    first <<= 1;
+    code <<= 1;
+  }
+  return false;
+}
+
+// Walks one deflate stream: literals -> gout, matches -> tok[] (position | length << 16 | distance << 32).  Returns the
+// number of output positions (ntok = number of tokens), or ~0u on a malformed stream.
+__device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in_off, uint32_t in_len, uint8_t *gout, unsigned long long *tok, uint32_t out_cap, HuffLds &h, uint32_t &ntok)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  Decoder dc = {h};
+  dc.lane = lane;
+  dc.in32 = reinterpret_cast<const uint32_t *>(file + (in_off & ~3ull));
+  const uint8_t *in8 = reinterpret_cast<const uint8_t *>(dc.in32);
+  dc.bitpos = (uint32_t) (in_off & 3ull) * 8u;
+  dc.end_bit = dc.bitpos + in_len * 8u;
+  dc.end_dw = (dc.end_bit + 31u) >> 5;
+  dc.seek(0);
+  uint32_t o = 0;
+  ntok = 0;
+  ST(uint32_t st_rounds = 0; uint32_t st_slow = 0; uint32_t st_dyn = 0; uint64_t st_tb = 0; const uint64_t st_t0 = wall_clock64();)
   for (int guard = 0; guard < 4096; ++guard)
   {
-    const uint32_t last = br.bits(1), type = br.bits(2);
+    const uint32_t hdr = dc.bits(3), last = hdr & 1u, type = hdr >> 1;
     if (type == 0)
     {
-      br.drop(br.cnt & 7);  // to the byte boundary
-      if (br.cnt < 32) br.refill();
-      const uint32_t len = br.bits(16), nlen = br.bits(16);
-      if ((len ^ 0xFFFFu) != nlen || o + len > out_cap) return ~0u;
-      // the bytes still in the bit buffer come first, the rest straight from the input
-      uint32_t src = br.pos - (uint32_t) (br.cnt >> 3);
-      if (src + len > br.end) return ~0u;
-      // stored bytes pass through the ring in chunks so that the flush logic stays the only writer of the output
-      for (uint32_t done = 0; done < len;)
-      {
-        const uint32_t n = len - done < FLUSH ? len - done : FLUSH;
-        for (uint32_t k = lane; k < n; k += 64) ring[(o + k) & M] = in[src + done + k];
-        __builtin_amdgcn_wave_barrier();
-        o += n;
-        done += n;
-        flush();
-      }
-      br.pos = src + len;
-      br.buf = 0;
-      br.cnt = 0;
+      dc.bitpos = (dc.bitpos + 7u) & ~7u;  // to the byte boundary
+      const uint32_t len = dc.bits(16), nlen = dc.bits(16);
+      if ((len ^ 0xFFFFu) != nlen || o + len > out_cap || dc.bitpos + 8u * len > dc.end_bit) return ~0u;
+      const uint32_t src = dc.bitpos >> 3;
+      for (uint32_t k = lane; k < len; k += 64) gout[o + k] = in8[src + k];
+      o += len;
+      dc.bitpos += 8u * len;
     }
     else if (type == 1 || type == 2)
     {
-      int nlen, ndist;
+      uint32_t nlen, ndist;
+      ST(const uint64_t tb0 = wall_clock64();)
       if (type == 1)
       {
-        for (int i = 0; i < 144; ++i) h.lens[i] = 8;
-        for (int i = 144; i < 256; ++i) h.lens[i] = 9;
-        for (int i = 256; i < 280; ++i) h.lens[i] = 7;
-        for (int i = 280; i < 288; ++i) h.lens[i] = 8;
-        for (int i = 0; i < 30; ++i) h.lens[288 + i] = 5;
+        for (uint32_t i = lane; i < 288; i += 64) h.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+        if (lane < 32) h.lens[288 + lane] = lane < 30 ? 5 : 0;
         nlen = 288;
         ndist = 30;
       }
       else
       {
-        nlen = (int) br.bits(5) + 257;
-        ndist = (int) br.bits(5) + 1;
-        const int ncode = (int) br.bits(4) + 4;
+        const uint32_t hd = dc.bits(14);
+        nlen = (hd & 31u) + 257u;
+        ndist = ((hd >> 5) & 31u) + 1u;
+        const uint32_t ncode = (hd >> 10) + 4u;
         if (nlen > 286 || ndist > 30) return ~0u;
-        uint8_t cl[19];
-        for (int i = 0; i < 19; ++i) cl[i] = 0;
-        for (int i = 0; i < ncode; ++i) cl[CL_ORDER[i]] = (uint8_t) br.bits(3);
-        // the code-length code uses the distance tables' storage for a moment
+        static constexpr uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        if (lane < 19) h.lens[320 + lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        if (!build_tables(cl, 19, h.dfast, 7, h.dsym, h.dcount)) return ~0u;
+        for (uint32_t i = 0; i < ncode; ++i) h.lens[320 + ORDER[i]] = (uint8_t) dc.bits(3);
+        // the code-length code uses the distance tables' storage for a moment (its codes are at most 7 bits: all direct)
         __builtin_amdgcn_wave_barrier();
-        int idx = 0;
+        if (!uni(build_tables<T_CLEN>(h, h.lens + 320, 19, h.dfast, 7, h.dsym, h.dcount))) return ~0u;
+        uint32_t idx = 0;
         while (idx < nlen + ndist)
         {
-          if (br.cnt < 32) br.refill();  // a code (<= 7 bits) + its repeat count (<= 7 bits)
-          const int s = decode_sym(br, h.dfast, 7, h.dsym, h.dcount);
-          if (s < 0) return ~0u;
+          const uint32_t w = dc.peek();
+          const uint32_t e = uni(h.dfast[w & 127u]);
+          if (e == 0) return ~0u;
+          const uint32_t s = e >> 4, cl = e & 15u;
           if (s < 16)
+          {
             h.lens[idx++] = (uint8_t) s;
+            dc.bitpos += cl;
+          }
           else
           {
-            int prev = 0, rep;
+            uint32_t prev = 0, rep;
             if (s == 16)
             {
               if (idx == 0) return ~0u;
-              prev = h.lens[idx - 1];
-              rep = 3 + (int) br.bits(2);
+              prev = uni(h.lens[idx - 1]);
+              rep = 3 + ((w >> cl) & 3u);
+              dc.bitpos += cl + 2;
             }
             else if (s == 17)
-              rep = 3 + (int) br.bits(3);
+            {
+              rep = 3 + ((w >> cl) & 7u);
+              dc.bitpos += cl + 3;
+            }
             else
-              rep = 11 + (int) br.bits(7);
+            {
+              rep = 11 + ((w >> cl) & 127u);
+              dc.bitpos += cl + 7;
+            }
             if (idx + rep > nlen + ndist) return ~0u;
-            while (rep--) h.lens[idx++] = (uint8_t) prev;
+            for (uint32_t k = lane; k < rep; k += 64) h.lens[idx + k] = (uint8_t) prev;
+            idx += rep;
           }
         }
-        if (h.lens[256] == 0) return ~0u;  // no end-of-block code
-        // the distance lengths move behind a fixed offset so that both builds read their own range
         __builtin_amdgcn_wave_barrier();
-        uint8_t dl[32];
-        for (int i = 0; i < ndist; ++i) dl[i] = h.lens[nlen + i];
-        for (int i = 0; i < ndist; ++i) h.lens[288 + i] = dl[i];
+        if (uni(h.lens[256]) == 0) return ~0u;  // no end-of-block code
+        // the distance lengths move to their fixed place
+        const uint32_t dl = lane < ndist ? h.lens[nlen + lane] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) h.lens[288 + lane] = (uint8_t) dl;
       }
       __builtin_amdgcn_wave_barrier();
-      if (!build_tables(h.lens, nlen, h.lfast, LIT_FAST, h.lsym, h.lcount)) return ~0u;
-      if (!build_tables(h.lens + 288, ndist, h.dfast, DIST_FAST, h.dsym, h.dcount)) return ~0u;
-      __builtin_amdgcn_wave_barrier();
+      ST(++st_dyn;)
+      if (!uni(build_tables<T_LITLEN>(h, h.lens, nlen, h.lfast, LIT_FAST, h.lsym, h.lcount))) return ~0u;
+      if (!uni(build_tables<T_DIST>(h, h.lens + 288, ndist, h.dfast, DIST_FAST, h.dsym, h.dcount))) return ~0u;
+      ST(st_tb += wall_clock64() - tb0;)
       while (true)
       {
-        if (br.cnt < 48) br.refill();  // literal/length code + extra + distance code + extra <= 15 + 5 + 15 + 13 bits
-        const int s = decode_sym(br, h.lfast, LIT_FAST, h.lsym, h.lcount);
-        if (s < 0) return ~0u;
-        if (s < 256)
+        dc.ensure();
+        dc.bitpos = uni(dc.bitpos);
+        dc.win_dw = uni(dc.win_dw);
+        o = uni(o);
+        ntok = uni(ntok);
+        // ---- all 64 bit positions at once
+        const uint32_t lb = dc.bitpos - (dc.win_dw << 5) + lane, di = lb >> 5, sh = lb & 31u;
+        const uint32_t w0 = h.win[di], w1 = h.win[di + 1], w2 = h.win[di + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        const uint32_t e = h.lfast[lo & ((1u << LIT_FAST) - 1u)];
+        const uint32_t cl = e & 15u, lextra = (e >> 4) & 7u, kind = (e >> 24) & 3u;
+        const uint32_t t = cl + lextra;
+        const uint32_t dbits = __builtin_amdgcn_alignbit(hi, lo, t);
+        const uint32_t d = h.dfast[dbits & ((1u << DIST_FAST) - 1u)];
+        const uint32_t dl = d & 15u, dextra = (d >> 4) & 15u;
+        const uint32_t len = ((e >> 7) & 511u) + __builtin_amdgcn_ubfe(lo, cl, lextra);
+        const uint32_t dist = ((d >> 8) & 0xFFFFu) + __builtin_amdgcn_ubfe(dbits, dl, dextra);
+        const bool is_len = kind == K_LEN;
+        const uint32_t n = lane + (is_len ? t + dl + dextra : cl);
+        const bool ok = cl != 0 && kind != K_BAD && (!is_len || (dl != 0 && (d >> 24) == 0)) && n <= 64 && dc.bitpos + n <= dc.end_bit;
+        const uint32_t nxt = ok ? (n | (kind == K_EOB ? 256u : 0u)) : 0u;
+        // ---- the chain of real symbols from bit 0
+        uint32_t k = 0, nn;
+        unsigned long long sel = 0;
+        while (true)
+        {
+          nn = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) k);
+          if (nn - 1u >= 63u) break;  // undecodable here, end of block, or the 64 bits are used up
+          sel |= 1ull << k;
+          k = nn;
+        }
+        if (nn)
+        {
+          sel |= 1ull << k;
+          k = nn & 127u;
+        }
+        ST(++st_rounds;)
+        if (sel)
+        {
+          const bool start = (sel >> lane) & 1ull;
+          const bool is_lit = start && kind == K_LIT, is_match = start && is_len;
+          const uint32_t olen = is_lit ? 1u : is_match ? len : 0u;
+          const uint32_t incl = wave_incl_scan(olen), opos = o + incl - olen;
+          const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+          if (o + total > out_cap || __builtin_amdgcn_ballot_w64(is_match && dist > opos)) return ~0u;
+          if (is_lit) gout[opos] = (uint8_t) (e >> 16);
+          const unsigned long long mm = __builtin_amdgcn_ballot_w64(is_match);
+          if (is_match) tok[ntok + lanes_below(mm)] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) dist << 32);
+          ntok += (uint32_t) __popcll(mm);
+          o += total;
+          dc.bitpos += k;
+          if (nn >> 8) break;  // end of block
+          continue;
+        }
+        // ---- the symbol at the head did not decode from the direct tables (a long code): scalar path
+        ST(++st_slow;)
+        uint32_t w = dc.peek();
+        uint32_t se = uni(h.lfast[w & ((1u << LIT_FAST) - 1u)]);
+        if ((se & 15u) == 0)
+        {
+          uint32_t s, sl;
+          if (!walk_code(w, h.lsym, h.lcount, s, sl)) return ~0u;
+          se = make_entry<T_LITLEN>(s, sl);
+        }
+        const uint32_t scl = se & 15u, skind = (se >> 24) & 3u;
+        if (skind == K_BAD) return ~0u;
+        if (skind == K_LIT)
         {
           if (o >= out_cap) return ~0u;
-          if (lane == 0) ring[o & M] = (uint8_t) s;
+          if (lane == 0) gout[o] = (uint8_t) (se >> 16);
           ++o;
-          if ((o & (FLUSH - 1)) == 0) flush();
+          dc.bitpos += scl;
         }
-        else if (s == 256)
+        else if (skind == K_EOB)
+        {
+          dc.bitpos += scl;
+          if (dc.bitpos > dc.end_bit) return ~0u;
           break;
+        }
         else
         {
-          const int ls = s - 257;
-          if (ls >= 29) return ~0u;
-          uint32_t lbase, dbase;
-          int lextra, dextra;
-          len_code(ls, lbase, lextra);
-          const uint32_t len = lbase + br.bits(lextra);
-          const int ds = decode_sym(br, h.dfast, DIST_FAST, h.dsym, h.dcount);
-          if (ds < 0 || ds >= 30) return ~0u;
-          dist_code(ds, dbase, dextra);
-          const uint32_t dist = dbase + br.bits(dextra);
-          if (dist > o || o + len > out_cap) return ~0u;
-          // the whole wave copies the match; sources lie in the finished part of the output
-          if (dist <= NEAR)
+          const uint32_t sx = (se >> 4) & 7u;
+          const uint32_t slen = ((se >> 7) & 511u) + ((w >> scl) & ((1u << sx) - 1u));
+          dc.bitpos += scl + sx;
+          w = dc.peek();
+          uint32_t sd = uni(h.dfast[w & ((1u << DIST_FAST) - 1u)]);
+          if ((sd & 15u) == 0)
           {
-            if (dist >= len)
-            {
-              for (uint32_t k = lane; k < len; k += 64) ring[(o + k) & M] = ring[(o - dist + k) & M];
-            }
-            else
-            {
-              for (uint32_t k = lane; k < len; k += 64) ring[(o + k) & M] = ring[(o - dist + k % dist) & M];
-            }
+            uint32_t s, sl;
+            if (!walk_code(w, h.dsym, h.dcount, s, sl)) return ~0u;
+            sd = make_entry<T_DIST>(s, sl);
           }
-          else
-          {
-            // farther back than the ring keeps: those bytes were flushed long ago (dist > NEAR > len)
-            for (uint32_t k = lane; k < len; k += 64) ring[(o + k) & M] = gout[o - dist + k];
-          }
-          __builtin_amdgcn_wave_barrier();
-          o += len;
-          if ((o ^ (o - len)) >= FLUSH) flush();
+          if (sd >> 24) return ~0u;
+          const uint32_t sdl = sd & 15u, sdx = (sd >> 4) & 15u;
+          const uint32_t sdist = ((sd >> 8) & 0xFFFFu) + ((w >> sdl) & ((1u << sdx) - 1u));
+          dc.bitpos += sdl + sdx;
+          if (sdist > o || o + slen > out_cap) return ~0u;
+          if (lane == 0) tok[ntok] = (unsigned long long) o | ((unsigned long long) slen << 16) | ((unsigned long long) sdist << 32);
+          ++ntok;
+          o += slen;
         }
+        if (dc.bitpos > dc.end_bit) return ~0u;
       }
     }
     else
       return ~0u;
     if (last)
     {
-      flush();
-      for (uint32_t k = flushed + lane; k < o; k += 64) gout[k] = ring[k & M];  // ragged tail
+#ifdef BGZF_STATS
+      if (lane == 0)
+      {
+        atomicAdd(&g_bgzf_stats[1], (unsigned long long) st_rounds);
+        atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
+        atomicAdd(&g_bgzf_stats[5], (unsigned long long) st_slow);
+        atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
+        atomicAdd(&g_bgzf_stats[3], (unsigned long long) st_tb);
+        atomicAdd(&g_bgzf_stats[7], (unsigned long long) (wall_clock64() - st_t0));
+      }
+#endif
       return o;
     }
   }
   return ~0u;
 }
 
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint8_t *__restrict__ out,
-                                                     uint32_t *__restrict__ err)
+// blk[first + blockIdx.x]: literals into out, match tokens into slab block blockIdx.x, their number into ntok[blockIdx.x]
+__global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+                                                    unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
   __shared__ HuffLds s_h;
-  const uint32_t w = blockIdx.x;
-  if (w >= nblk) return;
-  const BgzfBlock b = blk[w];
-  if (b.isize == 0) return;
-  const uint32_t got = inflate_wave(file + b.in_off, b.clen, s_ring, out + b.out_off, b.isize, s_h);
-  if (got != b.isize && threadIdx.x == 0) atomicOr(err, 1u);
+  if (blockIdx.x >= nblk) return;
+  const BgzfBlock b = blk[first + blockIdx.x];
+  uint32_t got = ~0u, nt = 0;
+  if (b.isize == 0)
+    got = 0;
+  else if (b.isize <= 65536u)
+    got = decode_wave(file, b.in_off, b.clen, out + b.out_off, slab + (size_t) blockIdx.x * BGZF_TOKENS_PER_BLOCK, b.isize, s_h, nt);
+  const bool bad = got != b.isize;
+  if (threadIdx.x == 0)
+  {
+    ntok[blockIdx.x] = bad ? 0u : nt;
+    if (bad) atomicOr(err, 1u);
+  }
+}
+
+// LZ77 resolution of one block by pointer jumping in LDS (file comment).  Thread t owns positions t + 1024 i.
+__global__ __launch_bounds__(RESOLVE_THREADS) void k_bgzf_resolve(const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+                                                                  const unsigned long long *__restrict__ slab, const uint32_t *__restrict__ ntok)
+{
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_par[];
+  if (blockIdx.x >= nblk) return;
+  const BgzfBlock b = blk[first + blockIdx.x];
+  const uint32_t n = b.isize <= 65536u ? b.isize : 0u, t = threadIdx.x, nt = ntok[blockIdx.x];
+  if (n == 0 || nt == 0) return;  // literals only: the decoder wrote every byte
+  const unsigned long long *tok = slab + (size_t) blockIdx.x * BGZF_TOKENS_PER_BLOCK;
+  uint8_t *o = out + b.out_off;
+  for (uint32_t p = 8 * t; p < n; p += 8 * RESOLVE_THREADS)
+  {
+    const uint32_t a = p | ((p + 1) << 16);
+    *reinterpret_cast<uint4 *>(s_par + p) = make_uint4(a, a + 0x00020002u, a + 0x00040004u, a + 0x00060006u);
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < nt; i += RESOLVE_THREADS)
+  {
+    const unsigned long long k = tok[i];
+    const uint32_t pos = (uint32_t) k & 0xFFFFu, len = (uint32_t) (k >> 16) & 0xFFFFu, dist = (uint32_t) (k >> 32);
+    for (uint32_t j = 0; j < len; ++j) s_par[pos + j] = (uint16_t) (pos + j - dist);
+  }
+  __syncthreads();
+  unsigned long long todo = 0;
+  for (uint32_t i = 0; i < 64; ++i)
+  {
+    const uint32_t p = t + RESOLVE_THREADS * i;
+    if (p < n && s_par[p] != p) todo |= 1ull << i;
+  }
+  while (todo)
+  {
+    unsigned long long m = todo;
+    while (m)
+    {
+      const uint32_t i = (uint32_t) __ffsll((long long) m) - 1u;
+      m &= m - 1ull;
+      const uint32_t p = t + RESOLVE_THREADS * i;
+      const uint32_t s = s_par[p], r = s_par[s];
+      if (r == s)
+        todo &= ~(1ull << i);  // s is a literal
+      else
+        s_par[p] = (uint16_t) r;
+    }
+  }
+  __syncthreads();
+  // four output bytes per thread and store (output offsets of blocks are multiples of 256)
+  const uint32_t n4 = n & ~3u;
+  for (uint32_t p = 4 * t; p < n4; p += 4 * RESOLVE_THREADS)
+  {
+    const uint2 s = *reinterpret_cast<const uint2 *>(s_par + p);
+    const uint32_t v = (uint32_t) o[s.x & 0xFFFFu] | ((uint32_t) o[s.x >> 16] << 8) | ((uint32_t) o[s.y & 0xFFFFu] << 16) | ((uint32_t) o[s.y >> 16] << 24);
+    *reinterpret_cast<uint32_t *>(o + p) = v;
+  }
+  if (t < n - n4)
+  {
+    const uint32_t p = n4 + t, s = s_par[p];
+    if (s != p) o[p] = o[s];
+  }
 }
 }  // namespace
 
-void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, uint32_t *err_dev, hipStream_t st)
+uint32_t bgzf_scratch_blocks(uint32_t nblk) { return nblk < BGZF_BATCH_BLOCKS ? nblk : BGZF_BATCH_BLOCKS; }
+
+void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st)
 {
   if (nblk == 0) return;
-  hipLaunchKernelGGL(k_bgzf_inflate, dim3(nblk), dim3(64), 0, st, file_dev, blk_dev, nblk, out_dev, err_dev);
+  static bool attr_set = false;
+  if (!attr_set)
+  {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
+    attr_set = true;
+  }
+  const uint32_t cap = bgzf_scratch_blocks(nblk);
+  unsigned long long *slab = static_cast<unsigned long long *>(scratch_dev);
+  uint32_t *ntok = reinterpret_cast<uint32_t *>(slab + (size_t) cap * BGZF_TOKENS_PER_BLOCK);
+  for (uint32_t first = 0; first < nblk; first += BGZF_BATCH_BLOCKS)
+  {
+    const uint32_t nb = nblk - first < BGZF_BATCH_BLOCKS ? nblk - first : BGZF_BATCH_BLOCKS;
+    hipLaunchKernelGGL(k_bgzf_decode, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
+    hipLaunchKernelGGL(k_bgzf_resolve, dim3(nb), dim3(RESOLVE_THREADS), 65536 * 2, st, blk_dev, first, nb, out_dev, slab, ntok);
+  }
+#ifdef BGZF_STATS
+  if (getenv("BK_BGZF_STATS"))
+  {
+    unsigned long long h[8], z[8] = {0};
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bgzf_stats), 64));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bgzf_stats), z, 64));
+    fprintf(stderr, "[bgzf] %u blocks: %llu rounds, %llu symbols on the scalar path, %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[1],
+            h[5], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
+  }
+#endif
 }
