@@ -35,7 +35,7 @@
 
 namespace
 {
-constexpr int LIT_FAST = 10, DIST_FAST = 8;
+constexpr int LIT_FAST = 11, DIST_FAST = 9;
 // symbol statistics (build with -DBGZF_STATS, run with BK_BGZF_STATS=1); off by default
 #ifdef BGZF_STATS
 __device__ unsigned long long g_bgzf_stats[8];
@@ -47,17 +47,18 @@ constexpr uint32_t CHUNK_DW = 64;            // one dword per lane
 constexpr uint32_t WIN_DW = 3 * CHUNK_DW;    // input window: three chunks in LDS, the fourth on its way in a register
 constexpr uint32_t RESOLVE_THREADS = 1024;
 
-// direct-table entries
-//   literal/length: bits 0-3 code length (0 = longer than the table), 4-6 extra bits, 7-15 length base, 16-23 literal, 24-25 kind
-//   distance:       bits 0-3 code length, 4-7 extra bits, 8-23 distance base, 24 invalid code
+// direct-table entries (u16)
+//   literal/length: bits 0-3 code length (0 = longer than the table); bit 4 clear: literal in bits 8-15; bit 4 set: bits 5-7 extra
+//                   bits x, bits 8-15 m with length = 3 + (m << x) + extra value; x = 7 marks end of block (m = 0) / an invalid symbol (m = 1)
+//   distance:       bits 0-3 code length, 4-7 extra bits x, 8-9 m with distance = 1 + (m << x) + extra value, bit 10 invalid symbol
 //   code-length code: (symbol << 4) | code length
-enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_BAD = 3 };
 enum : int { T_LITLEN = 0, T_DIST = 1, T_CLEN = 2 };
+constexpr uint32_t E_EOB = 0x00F0u, E_BAD = 0x01F0u;  // | code length
 
 struct HuffLds
 {
-  uint32_t lfast[1 << LIT_FAST];
-  uint32_t dfast[1 << DIST_FAST];
+  uint16_t lfast[1 << LIT_FAST];
+  uint16_t dfast[1 << DIST_FAST];
   uint16_t lsym[288], dsym[32];    // symbols ordered by (length, symbol): the canonical walk for long codes
   uint32_t lcount[16], dcount[16];
   uint32_t offs[16], nextc[16];    // table build scratch
@@ -83,54 +84,23 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
   return v;
 }
 
-// base value and extra bits of length code 257 + ls / distance code ds (RFC 1951 section 3.2.5)
-__device__ __forceinline__ void len_code(uint32_t ls, uint32_t &base, uint32_t &extra)
-{
-  if (ls < 8)
-  {
-    base = 3u + ls;
-    extra = 0;
-  }
-  else if (ls == 28)
-  {
-    base = 258;
-    extra = 0;
-  }
-  else
-  {
-    extra = (ls - 4) >> 2;
-    base = 3u + ((4u + (ls & 3)) << extra);
-  }
-}
-__device__ __forceinline__ void dist_code(uint32_t ds, uint32_t &base, uint32_t &extra)
-{
-  if (ds < 4)
-  {
-    base = 1u + ds;
-    extra = 0;
-  }
-  else
-  {
-    extra = (ds - 2) >> 1;
-    base = 1u + ((2u + (ds & 1)) << extra);
-  }
-}
+// RFC 1951 section 3.2.5 in the table's terms: length code 257 + ls -> 3 + (m << x), distance code ds -> 1 + (m << x)
 template <int T>
 __device__ __forceinline__ uint32_t make_entry(uint32_t s, uint32_t len)
 {
   if (T == T_CLEN) return (s << 4) | len;
-  uint32_t base, extra;
   if (T == T_DIST)
   {
-    if (s >= 30) return len | (1u << 24);
-    dist_code(s, base, extra);
-    return len | (extra << 4) | (base << 8);
+    if (s >= 30) return len | (1u << 10);
+    const uint32_t x = s < 4 ? 0u : (s - 2) >> 1, m = s < 4 ? s : 2u + (s & 1u);
+    return len | (x << 4) | (m << 8);
   }
-  if (s < 256) return len | (s << 16) | (K_LIT << 24);
-  if (s == 256) return len | (K_EOB << 24);
-  if (s > 285) return len | (K_BAD << 24);
-  len_code(s - 257, base, extra);
-  return len | (extra << 4) | (base << 7) | (K_LEN << 24);
+  if (s < 256) return len | (s << 8);
+  if (s == 256) return len | E_EOB;
+  if (s > 285) return len | E_BAD;
+  const uint32_t ls = s - 257;
+  const uint32_t x = (ls < 8 || ls == 28) ? 0u : (ls - 4) >> 2, m = ls < 8 ? ls : ls == 28 ? 255u : 4u + (ls & 3u);
+  return len | 16u | (x << 5) | (m << 8);
 }
 
 // Canonical Huffman tables from n code lengths, built by the wave: counts per length (LDS atomics), first code and
@@ -138,7 +108,7 @@ __device__ __forceinline__ uint32_t make_entry(uint32_t s, uint32_t len)
 // length is the number of such symbols in earlier chunks plus the lanes below it in a ballot.  Symbols whose code fits
 // the direct table fill their 2^(fast_bits - len) slots.  Returns false for an over-subscribed set of lengths.
 template <int T>
-__device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint32_t n, uint32_t *fast, uint32_t fast_bits, uint16_t *sym, uint32_t *count)
+__device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint32_t n, uint16_t *fast, uint32_t fast_bits, uint16_t *sym, uint32_t *count)
 {
   const uint32_t lane = threadIdx.x & 63;
   if (lane < 16) count[lane] = 0;
@@ -183,7 +153,7 @@ __device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint3
       sym[h.offs[mylen] + rank] = (uint16_t) s;
       if (mylen <= fast_bits)
       {
-        const uint32_t e = make_entry<T>(s, mylen);
+        const uint16_t e = (uint16_t) make_entry<T>(s, mylen);
         for (uint32_t j = bitrev(h.nextc[mylen] + rank, mylen); j < (1u << fast_bits); j += 1u << mylen) fast[j] = e;
       }
     }
@@ -290,7 +260,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
   dc.seek(0);
   uint32_t o = 0;
   ntok = 0;
-  ST(uint32_t st_rounds = 0; uint32_t st_slow = 0; uint32_t st_dyn = 0; uint64_t st_tb = 0; const uint64_t st_t0 = wall_clock64();)
+  ST(uint32_t st_ll = 0; uint32_t st_dlong = 0; uint32_t st_rounds = 0; uint32_t st_slow = 0; uint32_t st_dyn = 0; uint64_t st_tb = 0; const uint64_t st_t0 = wall_clock64();)
   for (int guard = 0; guard < 4096; ++guard)
   {
     const uint32_t hdr = dc.bits(3), last = hdr & 1u, type = hdr >> 1;
@@ -385,53 +355,76 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         dc.win_dw = uni(dc.win_dw);
         o = uni(o);
         ntok = uni(ntok);
-        // ---- all 64 bit positions at once
+        // ---- all 64 bit positions at once (straight-line code: flags are combined with & and |)
         const uint32_t lb = dc.bitpos - (dc.win_dw << 5) + lane, di = lb >> 5, sh = lb & 31u;
         const uint32_t w0 = h.win[di], w1 = h.win[di + 1], w2 = h.win[di + 2];
         const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
         const uint32_t e = h.lfast[lo & ((1u << LIT_FAST) - 1u)];
-        const uint32_t cl = e & 15u, lextra = (e >> 4) & 7u, kind = (e >> 24) & 3u;
+        const uint32_t cl = e & 15u, lextra = (e >> 5) & 7u;
         const uint32_t t = cl + lextra;
         const uint32_t dbits = __builtin_amdgcn_alignbit(hi, lo, t);
         const uint32_t d = h.dfast[dbits & ((1u << DIST_FAST) - 1u)];
         const uint32_t dl = d & 15u, dextra = (d >> 4) & 15u;
-        const uint32_t len = ((e >> 7) & 511u) + __builtin_amdgcn_ubfe(lo, cl, lextra);
-        const uint32_t dist = ((d >> 8) & 0xFFFFu) + __builtin_amdgcn_ubfe(dbits, dl, dextra);
-        const bool is_len = kind == K_LEN;
-        const uint32_t n = lane + (is_len ? t + dl + dextra : cl);
-        const bool ok = cl != 0 && kind != K_BAD && (!is_len || (dl != 0 && (d >> 24) == 0)) && n <= 64 && dc.bitpos + n <= dc.end_bit;
-        const uint32_t nxt = ok ? (n | (kind == K_EOB ? 256u : 0u)) : 0u;
-        // ---- the chain of real symbols from bit 0
-        uint32_t k = 0, nn;
-        unsigned long long sel = 0;
-        while (true)
+        const uint32_t len = 3u + ((e >> 8) << lextra) + __builtin_amdgcn_ubfe(lo, cl, lextra);
+        const uint32_t dist = 1u + (((d >> 8) & 3u) << dextra) + __builtin_amdgcn_ubfe(dbits, dl, dextra);
+        const uint32_t other = (e >> 4) & 1u, special = (uint32_t) (lextra == 7u);
+        const uint32_t is_len = other & (special ^ 1u), is_eob = (uint32_t) ((e & 0xFFF0u) == E_EOB), is_bad = (uint32_t) ((e & 0xFFF0u) == E_BAD);
+        const uint32_t n = lane + (is_len ? t + dl + dextra : cl);  // < 128
+        const uint32_t ok = (uint32_t) (cl != 0u) & (is_bad ^ 1u) & ((is_len ^ 1u) | ((uint32_t) (dl != 0u) & (((d >> 10) & 1u) ^ 1u))) & (uint32_t) (dc.bitpos + n <= dc.end_bit);
+        const uint32_t nxt1 = ok ? (n | (is_eob << 8)) - 1u : 0xFFFFFFFFu;
+        // ---- the chain of real symbols from bit 0: sel = lanes that start one; the walk ends at a symbol that cannot be
+        // decoded here (nn = ~0), at the end of block, or at one that ends at or beyond bit 64 (both: nn >= 63)
+        uint32_t k, nn;
+        unsigned long long sel;
+        asm volatile("s_mov_b32 %1, 0\n\t"
+                     "s_mov_b64 %0, 0\n"
+                     "1:\n\t"
+                     "v_readlane_b32 %2, %3, %1\n\t"
+                     "s_cmp_ge_u32 %2, 63\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_bitset1_b64 %0, %1\n\t"
+                     "s_add_u32 %1, %2, 1\n\t"
+                     "v_readlane_b32 %2, %3, %1\n\t"
+                     "s_cmp_ge_u32 %2, 63\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_bitset1_b64 %0, %1\n\t"
+                     "s_add_u32 %1, %2, 1\n\t"
+                     "v_readlane_b32 %2, %3, %1\n\t"
+                     "s_cmp_ge_u32 %2, 63\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_bitset1_b64 %0, %1\n\t"
+                     "s_add_u32 %1, %2, 1\n\t"
+                     "v_readlane_b32 %2, %3, %1\n\t"
+                     "s_cmp_ge_u32 %2, 63\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_bitset1_b64 %0, %1\n\t"
+                     "s_add_u32 %1, %2, 1\n\t"
+                     "s_branch 1b\n"
+                     "2:"
+                     : "=&s"(sel), "=&s"(k), "=&s"(nn)
+                     : "v"(nxt1)
+                     : "scc");
+        if (nn != 0xFFFFFFFFu)
         {
-          nn = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) k);
-          if (nn - 1u >= 63u) break;  // undecodable here, end of block, or the 64 bits are used up
           sel |= 1ull << k;
-          k = nn;
-        }
-        if (nn)
-        {
-          sel |= 1ull << k;
-          k = nn & 127u;
+          k = (nn + 1u) & 127u;
         }
         ST(++st_rounds;)
         if (sel)
         {
-          const bool start = (sel >> lane) & 1ull;
-          const bool is_lit = start && kind == K_LIT, is_match = start && is_len;
-          const uint32_t olen = is_lit ? 1u : is_match ? len : 0u;
+          const uint32_t start = (uint32_t) (sel >> lane) & 1u;
+          const uint32_t is_lit = start & (other ^ 1u), is_match = start & is_len;
+          const uint32_t olen = is_lit | (is_match ? len : 0u);
           const uint32_t incl = wave_incl_scan(olen), opos = o + incl - olen;
           const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-          if (o + total > out_cap || __builtin_amdgcn_ballot_w64(is_match && dist > opos)) return ~0u;
-          if (is_lit) gout[opos] = (uint8_t) (e >> 16);
-          const unsigned long long mm = __builtin_amdgcn_ballot_w64(is_match);
+          if (o + total > out_cap || __builtin_amdgcn_ballot_w64(is_match & (uint32_t) (dist > opos))) return ~0u;
+          if (is_lit) gout[opos] = (uint8_t) (e >> 8);
+          const unsigned long long mm = __builtin_amdgcn_ballot_w64(is_match != 0u);
           if (is_match) tok[ntok + lanes_below(mm)] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) dist << 32);
           ntok += (uint32_t) __popcll(mm);
           o += total;
           dc.bitpos += k;
-          if (nn >> 8) break;  // end of block
+          if (nn != 0xFFFFFFFFu && ((nn + 1u) >> 8)) break;  // end of block
           continue;
         }
         // ---- the symbol at the head did not decode from the direct tables (a long code): scalar path
@@ -440,20 +433,21 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         uint32_t se = uni(h.lfast[w & ((1u << LIT_FAST) - 1u)]);
         if ((se & 15u) == 0)
         {
+          ST(++st_ll;)
           uint32_t s, sl;
           if (!walk_code(w, h.lsym, h.lcount, s, sl)) return ~0u;
           se = make_entry<T_LITLEN>(s, sl);
         }
-        const uint32_t scl = se & 15u, skind = (se >> 24) & 3u;
-        if (skind == K_BAD) return ~0u;
-        if (skind == K_LIT)
+        const uint32_t scl = se & 15u;
+        if ((se & 0xFFF0u) == E_BAD) return ~0u;
+        if ((se & 16u) == 0)
         {
           if (o >= out_cap) return ~0u;
-          if (lane == 0) gout[o] = (uint8_t) (se >> 16);
+          if (lane == 0) gout[o] = (uint8_t) (se >> 8);
           ++o;
           dc.bitpos += scl;
         }
-        else if (skind == K_EOB)
+        else if ((se & 0xFFF0u) == E_EOB)
         {
           dc.bitpos += scl;
           if (dc.bitpos > dc.end_bit) return ~0u;
@@ -461,20 +455,21 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         }
         else
         {
-          const uint32_t sx = (se >> 4) & 7u;
-          const uint32_t slen = ((se >> 7) & 511u) + ((w >> scl) & ((1u << sx) - 1u));
+          const uint32_t sx = (se >> 5) & 7u;
+          const uint32_t slen = 3u + ((se >> 8) << sx) + ((w >> scl) & ((1u << sx) - 1u));
           dc.bitpos += scl + sx;
           w = dc.peek();
           uint32_t sd = uni(h.dfast[w & ((1u << DIST_FAST) - 1u)]);
           if ((sd & 15u) == 0)
           {
+            ST(++st_dlong;)
             uint32_t s, sl;
             if (!walk_code(w, h.dsym, h.dcount, s, sl)) return ~0u;
             sd = make_entry<T_DIST>(s, sl);
           }
-          if (sd >> 24) return ~0u;
+          if (sd & (1u << 10)) return ~0u;
           const uint32_t sdl = sd & 15u, sdx = (sd >> 4) & 15u;
-          const uint32_t sdist = ((sd >> 8) & 0xFFFFu) + ((w >> sdl) & ((1u << sdx) - 1u));
+          const uint32_t sdist = 1u + (((sd >> 8) & 3u) << sdx) + ((w >> sdl) & ((1u << sdx) - 1u));
           dc.bitpos += sdl + sdx;
           if (sdist > o || o + slen > out_cap) return ~0u;
           if (lane == 0) tok[ntok] = (unsigned long long) o | ((unsigned long long) slen << 16) | ((unsigned long long) sdist << 32);
@@ -495,6 +490,8 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
         atomicAdd(&g_bgzf_stats[5], (unsigned long long) st_slow);
         atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
+        atomicAdd(&g_bgzf_stats[0], (unsigned long long) st_ll);
+        atomicAdd(&g_bgzf_stats[4], (unsigned long long) st_dlong);
         atomicAdd(&g_bgzf_stats[3], (unsigned long long) st_tb);
         atomicAdd(&g_bgzf_stats[7], (unsigned long long) (wall_clock64() - st_t0));
       }
@@ -614,8 +611,8 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bgzf_stats), 64));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bgzf_stats), z, 64));
-    fprintf(stderr, "[bgzf] %u blocks: %llu rounds, %llu symbols on the scalar path, %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[1],
-            h[5], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
+    fprintf(stderr, "[bgzf] %u blocks: %llu rounds, %llu symbols on the scalar path (%llu long literal/length codes, %llu long distance codes), %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[1],
+            h[5], h[0], h[4], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
   }
 #endif
 }
