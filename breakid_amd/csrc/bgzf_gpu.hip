@@ -59,7 +59,8 @@ struct HuffLds
 {
   uint16_t lfast[1 << LIT_FAST];
   uint16_t dfast[1 << DIST_FAST];
-  uint16_t lsym[288], dsym[32];    // symbols ordered by (length, symbol): the canonical walk for long codes
+  uint16_t lent[288], dent[32];    // table entries of all symbols ordered by (length, symbol): codes longer than the direct tables
+  uint32_t llim[16], lbas[16];     // literal/length code: codes of length L have 15-bit left-justified values < llim[L], slot = lbas[L] + (value >> (15 - L))
   uint32_t lcount[16], dcount[16];
   uint32_t offs[16], nextc[16];    // table build scratch
   uint8_t lens[344];               // code lengths: literal/length [0,288), distance [288,320), code-length code [320,339)
@@ -128,6 +129,11 @@ __device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint3
     {
       h.offs[len] = off;
       h.nextc[len] = code;
+      if (T == T_LITLEN)
+      {
+        h.llim[len] = (code + c) << (15 - len);
+        h.lbas[len] = off - code;
+      }
     }
     off += c;
     code = (code + c) << 1;
@@ -150,10 +156,10 @@ __device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint3
     }
     if (mylen)
     {
-      sym[h.offs[mylen] + rank] = (uint16_t) s;
+      const uint16_t e = (uint16_t) make_entry<T>(s, mylen);
+      sym[h.offs[mylen] + rank] = e;
       if (mylen <= fast_bits)
       {
-        const uint16_t e = (uint16_t) make_entry<T>(s, mylen);
         for (uint32_t j = bitrev(h.nextc[mylen] + rank, mylen); j < (1u << fast_bits); j += 1u << mylen) fast[j] = e;
       }
     }
@@ -222,8 +228,8 @@ struct Decoder
   }
 };
 
-// canonical walk of puff.c over the bits in w (LSB first; codes are MSB first): symbol and its length, or false
-__device__ __forceinline__ bool walk_code(uint32_t w, const uint16_t *sym, const uint32_t *count, uint32_t &s, uint32_t &len_out)
+// canonical walk of puff.c over the bits in w (LSB first; codes are MSB first): the symbol's table entry, or 0
+__device__ __forceinline__ uint32_t walk_code(uint32_t w, const uint16_t *ent, const uint32_t *count)
 {
   int code = 0, first = 0, index = 0;
   for (uint32_t len = 1; len < 16; ++len)
@@ -231,18 +237,13 @@ __device__ __forceinline__ bool walk_code(uint32_t w, const uint16_t *sym, const
     code |= (int) (w & 1u);
     w >>= 1;
     const int c = (int) uni(count[len]);
-    if (code - c < first)
-    {
-      s = uni(sym[index + (code - first)]);
-      len_out = len;
-      return true;
-    }
+    if (code - c < first) return uni(ent[index + (code - first)]);
     index += c;
     first += c;
     first <<= 1;
     code <<= 1;
   }
-  return false;
+  return 0;
 }
 
 // Walks one deflate stream: literals -> gout, matches -> tok[] (position | length << 16 | distance << 32).  Returns the
@@ -260,7 +261,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
   dc.seek(0);
   uint32_t o = 0;
   ntok = 0;
-  ST(uint32_t st_ll = 0; uint32_t st_dlong = 0; uint32_t st_rounds = 0; uint32_t st_slow = 0; uint32_t st_dyn = 0; uint64_t st_tb = 0; const uint64_t st_t0 = wall_clock64();)
+  ST(uint32_t st_fix = 0; uint32_t st_ll = 0; uint32_t st_dlong = 0; uint32_t st_rounds = 0; uint32_t st_slow = 0; uint32_t st_dyn = 0; uint64_t st_tb = 0; const uint64_t st_t0 = wall_clock64();)
   for (int guard = 0; guard < 4096; ++guard)
   {
     const uint32_t hdr = dc.bits(3), last = hdr & 1u, type = hdr >> 1;
@@ -298,7 +299,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         for (uint32_t i = 0; i < ncode; ++i) h.lens[320 + ORDER[i]] = (uint8_t) dc.bits(3);
         // the code-length code uses the distance tables' storage for a moment (its codes are at most 7 bits: all direct)
         __builtin_amdgcn_wave_barrier();
-        if (!uni(build_tables<T_CLEN>(h, h.lens + 320, 19, h.dfast, 7, h.dsym, h.dcount))) return ~0u;
+        if (!uni(build_tables<T_CLEN>(h, h.lens + 320, 19, h.dfast, 7, h.dent, h.dcount))) return ~0u;
         uint32_t idx = 0;
         while (idx < nlen + ndist)
         {
@@ -345,8 +346,8 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
       }
       __builtin_amdgcn_wave_barrier();
       ST(++st_dyn;)
-      if (!uni(build_tables<T_LITLEN>(h, h.lens, nlen, h.lfast, LIT_FAST, h.lsym, h.lcount))) return ~0u;
-      if (!uni(build_tables<T_DIST>(h, h.lens + 288, ndist, h.dfast, DIST_FAST, h.dsym, h.dcount))) return ~0u;
+      if (!uni(build_tables<T_LITLEN>(h, h.lens, nlen, h.lfast, LIT_FAST, h.lent, h.lcount))) return ~0u;
+      if (!uni(build_tables<T_DIST>(h, h.lens + 288, ndist, h.dfast, DIST_FAST, h.dent, h.dcount))) return ~0u;
       ST(st_tb += wall_clock64() - tb0;)
       while (true)
       {
@@ -359,51 +360,72 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         const uint32_t lb = dc.bitpos - (dc.win_dw << 5) + lane, di = lb >> 5, sh = lb & 31u;
         const uint32_t w0 = h.win[di], w1 = h.win[di + 1], w2 = h.win[di + 2];
         const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        const uint32_t e = h.lfast[lo & ((1u << LIT_FAST) - 1u)];
-        const uint32_t cl = e & 15u, lextra = (e >> 5) & 7u;
-        const uint32_t t = cl + lextra;
-        const uint32_t dbits = __builtin_amdgcn_alignbit(hi, lo, t);
-        const uint32_t d = h.dfast[dbits & ((1u << DIST_FAST) - 1u)];
-        const uint32_t dl = d & 15u, dextra = (d >> 4) & 15u;
-        const uint32_t len = 3u + ((e >> 8) << lextra) + __builtin_amdgcn_ubfe(lo, cl, lextra);
-        const uint32_t dist = 1u + (((d >> 8) & 3u) << dextra) + __builtin_amdgcn_ubfe(dbits, dl, dextra);
-        const uint32_t other = (e >> 4) & 1u, special = (uint32_t) (lextra == 7u);
-        const uint32_t is_len = other & (special ^ 1u), is_eob = (uint32_t) ((e & 0xFFF0u) == E_EOB), is_bad = (uint32_t) ((e & 0xFFF0u) == E_BAD);
-        const uint32_t n = lane + (is_len ? t + dl + dextra : cl);  // < 128
-        const uint32_t ok = (uint32_t) (cl != 0u) & (is_bad ^ 1u) & ((is_len ^ 1u) | ((uint32_t) (dl != 0u) & (((d >> 10) & 1u) ^ 1u))) & (uint32_t) (dc.bitpos + n <= dc.end_bit);
-        const uint32_t nxt1 = ok ? (n | (is_eob << 8)) - 1u : 0xFFFFFFFFu;
+        uint32_t e = h.lfast[lo & ((1u << LIT_FAST) - 1u)];
+        uint32_t other, is_len, len, dist, nxt1;
+        auto from_entry = [&]() {
+          const uint32_t cl = e & 15u, lextra = (e >> 5) & 7u;
+          const uint32_t t = cl + lextra;
+          const uint32_t dbits = __builtin_amdgcn_alignbit(hi, lo, t);
+          const uint32_t d = h.dfast[dbits & ((1u << DIST_FAST) - 1u)];
+          const uint32_t dl = d & 15u, dextra = (d >> 4) & 15u;
+          len = 3u + ((e >> 8) << lextra) + __builtin_amdgcn_ubfe(lo, cl, lextra);
+          dist = 1u + (((d >> 8) & 3u) << dextra) + __builtin_amdgcn_ubfe(dbits, dl, dextra);
+          other = (e >> 4) & 1u;
+          is_len = other & (uint32_t) (lextra != 7u);
+          const uint32_t is_eob = (uint32_t) ((e & 0xFFF0u) == E_EOB), is_bad = (uint32_t) ((e & 0xFFF0u) == E_BAD);
+          const uint32_t n = lane + (is_len ? t + dl + dextra : cl);  // < 128
+          const uint32_t ok = (uint32_t) (cl != 0u) & (is_bad ^ 1u) & ((is_len ^ 1u) | ((uint32_t) (dl != 0u) & (((d >> 10) & 1u) ^ 1u))) & (uint32_t) (dc.bitpos + n <= dc.end_bit);
+          nxt1 = ok ? (n | (is_eob << 8)) - 1u : 0xFFFFFFFFu;
+        };
+        from_entry();
         // ---- the chain of real symbols from bit 0: sel = lanes that start one; the walk ends at a symbol that cannot be
         // decoded here (nn = ~0), at the end of block, or at one that ends at or beyond bit 64 (both: nn >= 63)
-        uint32_t k, nn;
-        unsigned long long sel;
-        asm volatile("s_mov_b32 %1, 0\n\t"
-                     "s_mov_b64 %0, 0\n"
-                     "1:\n\t"
-                     "v_readlane_b32 %2, %3, %1\n\t"
-                     "s_cmp_ge_u32 %2, 63\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "s_bitset1_b64 %0, %1\n\t"
-                     "s_add_u32 %1, %2, 1\n\t"
-                     "v_readlane_b32 %2, %3, %1\n\t"
-                     "s_cmp_ge_u32 %2, 63\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "s_bitset1_b64 %0, %1\n\t"
-                     "s_add_u32 %1, %2, 1\n\t"
-                     "v_readlane_b32 %2, %3, %1\n\t"
-                     "s_cmp_ge_u32 %2, 63\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "s_bitset1_b64 %0, %1\n\t"
-                     "s_add_u32 %1, %2, 1\n\t"
-                     "v_readlane_b32 %2, %3, %1\n\t"
-                     "s_cmp_ge_u32 %2, 63\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "s_bitset1_b64 %0, %1\n\t"
-                     "s_add_u32 %1, %2, 1\n\t"
-                     "s_branch 1b\n"
-                     "2:"
-                     : "=&s"(sel), "=&s"(k), "=&s"(nn)
-                     : "v"(nxt1)
-                     : "scc");
+        uint32_t k = 0, nn;
+        unsigned long long sel = 0;
+        auto hop = [&]() {
+          asm volatile("1:\n\t"
+                       "v_readlane_b32 %2, %3, %1\n\t"
+                       "s_cmp_ge_u32 %2, 63\n\t"
+                       "s_cbranch_scc1 2f\n\t"
+                       "s_bitset1_b64 %0, %1\n\t"
+                       "s_add_u32 %1, %2, 1\n\t"
+                       "v_readlane_b32 %2, %3, %1\n\t"
+                       "s_cmp_ge_u32 %2, 63\n\t"
+                       "s_cbranch_scc1 2f\n\t"
+                       "s_bitset1_b64 %0, %1\n\t"
+                       "s_add_u32 %1, %2, 1\n\t"
+                       "v_readlane_b32 %2, %3, %1\n\t"
+                       "s_cmp_ge_u32 %2, 63\n\t"
+                       "s_cbranch_scc1 2f\n\t"
+                       "s_bitset1_b64 %0, %1\n\t"
+                       "s_add_u32 %1, %2, 1\n\t"
+                       "v_readlane_b32 %2, %3, %1\n\t"
+                       "s_cmp_ge_u32 %2, 63\n\t"
+                       "s_cbranch_scc1 2f\n\t"
+                       "s_bitset1_b64 %0, %1\n\t"
+                       "s_add_u32 %1, %2, 1\n\t"
+                       "s_branch 1b\n"
+                       "2:"
+                       : "+s"(sel), "+s"(k), "=&s"(nn)
+                       : "v"(nxt1)
+                       : "scc");
+        };
+        hop();
+        if (nn == 0xFFFFFFFFu && ((uint32_t) __builtin_amdgcn_readlane((int) e, (int) k) & 15u) == 0u)
+        {
+          // the chain ran into a code longer than the direct table: every lane that looks at such a code decodes it
+          // from the canonical limits (codes of length L lie below llim[L] when left-justified in 15 bits), the lanes
+          // are re-evaluated and the walk goes on where it stopped
+          ST(++st_fix;)
+          const uint32_t v = __brev(lo) >> 17;
+          uint32_t L = LIT_FAST + 1;
+#pragma unroll
+          for (uint32_t q = LIT_FAST + 1; q < 15; ++q) L += (uint32_t) (v >= h.llim[q]);
+          const uint32_t slot = h.lbas[L] + (v >> (15u - L));
+          if ((e & 15u) == 0u && v < h.llim[15] && slot < 288u) e = h.lent[slot];
+          from_entry();
+          hop();
+        }
         if (nn != 0xFFFFFFFFu)
         {
           sel |= 1ull << k;
@@ -434,9 +456,8 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         if ((se & 15u) == 0)
         {
           ST(++st_ll;)
-          uint32_t s, sl;
-          if (!walk_code(w, h.lsym, h.lcount, s, sl)) return ~0u;
-          se = make_entry<T_LITLEN>(s, sl);
+          se = walk_code(w, h.lent, h.lcount);
+          if (se == 0) return ~0u;
         }
         const uint32_t scl = se & 15u;
         if ((se & 0xFFF0u) == E_BAD) return ~0u;
@@ -463,9 +484,8 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
           if ((sd & 15u) == 0)
           {
             ST(++st_dlong;)
-            uint32_t s, sl;
-            if (!walk_code(w, h.dsym, h.dcount, s, sl)) return ~0u;
-            sd = make_entry<T_DIST>(s, sl);
+            sd = walk_code(w, h.dent, h.dcount);
+            if (sd == 0) return ~0u;
           }
           if (sd & (1u << 10)) return ~0u;
           const uint32_t sdl = sd & 15u, sdx = (sd >> 4) & 15u;
@@ -490,7 +510,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
         atomicAdd(&g_bgzf_stats[5], (unsigned long long) st_slow);
         atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
-        atomicAdd(&g_bgzf_stats[0], (unsigned long long) st_ll);
+        atomicAdd(&g_bgzf_stats[0], (unsigned long long) st_ll | ((unsigned long long) st_fix << 32));
         atomicAdd(&g_bgzf_stats[4], (unsigned long long) st_dlong);
         atomicAdd(&g_bgzf_stats[3], (unsigned long long) st_tb);
         atomicAdd(&g_bgzf_stats[7], (unsigned long long) (wall_clock64() - st_t0));
@@ -611,8 +631,8 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bgzf_stats), 64));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bgzf_stats), z, 64));
-    fprintf(stderr, "[bgzf] %u blocks: %llu rounds, %llu symbols on the scalar path (%llu long literal/length codes, %llu long distance codes), %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[1],
-            h[5], h[0], h[4], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
+    fprintf(stderr, "[bgzf] %u blocks: %llu long-code fix-ups, %llu rounds, %llu symbols on the scalar path (%llu long literal/length codes, %llu long distance codes), %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[0] >> 32, h[1],
+            h[5], h[0] & 0xFFFFFFFFull, h[4], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
   }
 #endif
 }
