@@ -2,6 +2,7 @@
 #include "bk_common.h"
 #include "bgzf_gpu.h"
 #include "../../include/breakid_hip.h"
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,14 +13,13 @@ inline uint32_t rd32h(const uint8_t *p) { return (uint32_t) p[0] | ((uint32_t) p
 inline uint16_t rd16h(const uint8_t *p) { return (uint16_t) (p[0] | (p[1] << 8)); }
 }  // namespace
 
-// hops over the BGZF block headers of a file image (18 bytes each); false + why on a malformed file.
-// total = bytes of the (256-byte aligned per block) device output buffer
-bool bgzf_scan_blocks(const uint8_t *file, uint64_t n, std::vector<BgzfBlock> &blocks, uint64_t &total, std::string &why)
+// hops over BGZF block headers (18 bytes each) from file offset `off` until at least max_bytes of the file are covered or
+// the file ends; appends to blocks (in_off = absolute file offset of the deflate stream, out_off = total before the block,
+// total grows by the 256-byte aligned block sizes); false + why on a malformed file
+bool bgzf_scan_range(const uint8_t *file, uint64_t n, uint64_t &off, uint64_t max_bytes, std::vector<BgzfBlock> &blocks, uint64_t &total, std::string &why)
 {
-  blocks.clear();
-  total = 0;
-  uint64_t off = 0;
-  while (off < n)
+  const uint64_t start = off;
+  while (off < n && off - start < max_bytes)
   {
     if (off + 18 > n)
     {
@@ -65,6 +65,15 @@ bool bgzf_scan_blocks(const uint8_t *file, uint64_t n, std::vector<BgzfBlock> &b
     off += (uint64_t) bsize + 1;
   }
   return true;
+}
+
+// the whole file image
+bool bgzf_scan_blocks(const uint8_t *file, uint64_t n, std::vector<BgzfBlock> &blocks, uint64_t &total, std::string &why)
+{
+  blocks.clear();
+  total = 0;
+  uint64_t off = 0;
+  return bgzf_scan_range(file, n, off, ~0ull, blocks, total, why);
 }
 
 // Test / measurement hook: inflates a whole BGZF file image on the GPU and hands the bytes back.
@@ -229,7 +238,7 @@ __device__ __forceinline__ uint64_t qname_hash_dev(const uint8_t *name, uint32_t
 // EMIT = false: validate + count; EMIT = true: write the columns (bases from the scans)
 template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk,
                                                                          uint32_t first_off, int32_t n_ref, BlockCount *__restrict__ cnt, const uint64_t *__restrict__ rec_base,
-                                                                         const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, BamCols c)
+                                                                         const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, uint64_t rec0, uint64_t cig0, uint64_t aux0, BamCols c)
 {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
@@ -239,7 +248,7 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
     const BgzfBlock bb = blk[b];
     const uint8_t *d = data + bb.out_off;
     uint32_t p = b == first_blk ? first_off : 0u;
-    uint64_t ri = EMIT ? rec_base[b] : 0, ci = EMIT ? cig_base[b] : 0, ai = EMIT ? aux_base[b] : 0;
+    uint64_t ri = EMIT ? rec0 + rec_base[b] : 0, ci = EMIT ? cig0 + cig_base[b] : 0, ai = EMIT ? aux0 + aux_base[b] : 0;  // rec0.. = totals of the chunks before this one
     while (p < bb.isize)
     {
       if (p + 36 > bb.isize)
@@ -395,6 +404,44 @@ bool host_inflate_block(const uint8_t *file, const BgzfBlock &b, std::vector<uin
 }
 }  // namespace
 
+namespace
+{
+// one chunk of the file in flight: its compressed bytes, inflated bytes, match tokens and per-block counts
+struct FeedSlot
+{
+  DevBuf dfile, dblk, ddata, dslab, dcnt, dnr, dnc, dna, dscan, derr;
+  hipStream_t st = nullptr;
+  hipEvent_t ev_count = nullptr, ev_emit = nullptr;
+  uint64_t *tot = nullptr;  // pinned: records, CIGAR words, aux bytes, error flags of the chunk
+  std::vector<BgzfBlock> blocks;
+  uint32_t first_blk = 0, first_off = 0;
+  bool used = false;
+  ~FeedSlot()
+  {
+    if (st) (void) hipStreamDestroy(st);
+    if (ev_count) (void) hipEventDestroy(ev_count);
+    if (ev_emit) (void) hipEventDestroy(ev_emit);
+    if (tot) (void) hipHostFree(tot);
+  }
+};
+// buffer of at least `need` bytes that keeps its first `used` bytes (device-to-device copy when it moves)
+void grow_keep(DevBuf &b, size_t used, size_t need)
+{
+  if (need <= b.cap) return;
+  DevBuf nb;
+  (void) nb.ensure(need);
+  if (used) HIP_CHECK(hipMemcpy(nb.p, b.p, used, hipMemcpyDeviceToDevice));
+  b = std::move(nb);
+}
+}  // namespace
+
+// The file is taken in chunks of BREAKID_FEED_CHUNK_MB (64) MiB of BGZF blocks.  Per chunk: H2D copy of the mapped
+// bytes, inflate, per-block record counts + scans, D2H of the three totals - all on the chunk's own stream - and, once the
+// totals are on the host, the emit kernel at the running offsets of the columns.  Three chunks are in flight, so the
+// copy of one overlaps the inflate of the one before and the emit of the one before that, kernels of neighbouring chunks
+// fill each other's tails, and device memory holds three chunks plus the columns whatever the size of the file.  The
+// columns are sized from the first chunk (records per compressed byte x file size) and grow by copying when that was
+// too small.
 extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                                     char *err, size_t errlen)
 {
@@ -405,132 +452,214 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
     *out = nullptr;
     HIP_CHECK(hipSetDevice(device));
     const double t0 = now_s2();
-    // the file image is mapped, not copied: the header hop touches 18 bytes per block and the H2D copy streams the rest
-    MappedFile file(path);
-    std::vector<BgzfBlock> blocks;
-    uint64_t total = 0;
-    std::string why;
-    if (!bgzf_scan_blocks(file.data(), file.size(), blocks, total, why)) throw bk_error(BK_ERR_IO, why);
-    // header: inflated on the host, block by block, until the reference list is complete
-    h = new bk_bam_dev();
-    std::vector<uint8_t> head;
-    size_t hb = 0;  // blocks inflated so far
-    auto need = [&](size_t bytes) {
-      while (head.size() < bytes)
-      {
-        if (hb >= blocks.size()) throw bk_error(BK_ERR_IO, "truncated BAM header");
-        if (!host_inflate_block(file.data(), blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
-        ++hb;
-      }
-    };
-    need(12);
-    if (memcmp(head.data(), "BAM\1", 4) != 0) throw bk_error(BK_ERR_IO, "not a BAM file");
-    size_t p = 4;
-    const uint32_t l_text = rd32h(head.data() + p);
-    p += 4 + (size_t) l_text;
-    need(p + 4);
-    const uint32_t n_ref = rd32h(head.data() + p);
-    p += 4;
-    for (uint32_t i = 0; i < n_ref; ++i)
+    MappedFile file(path);  // mapped, not read: the header hop touches 18 bytes per block and the H2D copies stream the rest
+    uint64_t chunk_bytes = 64ull << 20;
+    if (const char *e = getenv("BREAKID_FEED_CHUNK_MB"))
+      if (atof(e) > 0) chunk_bytes = (uint64_t) (atof(e) * 1048576.0);
+    constexpr int NS = 3;
+    FeedSlot slot[NS];
+    for (auto &s : slot)
     {
-      need(p + 4);
-      const uint32_t l_name = rd32h(head.data() + p);
-      p += 4;
-      need(p + l_name + 4);
-      h->names.emplace_back((const char *) head.data() + p, l_name ? l_name - 1 : 0);
-      p += l_name;
-      h->lens.push_back(rd32h(head.data() + p));
-      p += 4;
+      HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&s.ev_count, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
+      HIP_CHECK(hipHostMalloc((void **) &s.tot, 4 * sizeof(uint64_t), hipHostMallocDefault));
     }
-    for (auto &s : h->names) h->name_ptrs.push_back(s.c_str());
-    // first record: block and offset
-    uint32_t first_blk = 0;
-    uint64_t acc = 0;
-    while (first_blk < blocks.size() && acc + blocks[first_blk].isize <= p) acc += blocks[first_blk++].isize;
-    const uint32_t first_off = (uint32_t) (p - acc);
-    const uint32_t nblk = (uint32_t) blocks.size();
-    size_t free_b = 0, total_b = 0;
-    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    if ((double) file.size() + (double) total * 1.25 > 0.8 * (double) free_b)
-      throw bk_error(BK_ERR_LIMIT, "BAM too large for the single-batch GPU decoder (use bk_bam_open / bk_bam_decode)");
-    const double t1 = now_s2();
-    DevBuf dfile, dblk, ddata, derr, dcnt, dnr, dnc, dna, dscan, dslab;
-    uint8_t *df = dfile.as<uint8_t>(file.size() + 8);
-    BgzfBlock *db = dblk.as<BgzfBlock>((uint64_t) nblk + 1);
-    uint8_t *dd = ddata.as<uint8_t>(total + 64);
-    uint32_t *de = derr.as<uint32_t>(1);
-    uint8_t *slab = dslab.as<uint8_t>(bgzf_scratch_bytes(nblk));
-    HIP_CHECK(hipMemcpy(df, file.data(), file.size(), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(db, blocks.data(), (size_t) nblk * sizeof(BgzfBlock), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(de, 0, 4));
-    const double t2 = now_s2();
-    hipStream_t st = nullptr;
-    hipEvent_t ev[3];
-    for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
-    HIP_CHECK(hipEventRecord(ev[0], st));
-    launch_bgzf_inflate(df, db, nblk, dd, slab, de, st);
-    HIP_CHECK(hipEventRecord(ev[1], st));
-    BlockCount *dc = dcnt.as<BlockCount>((uint64_t) nblk + 1);
-    uint64_t *nr = dnr.as<uint64_t>((uint64_t) nblk + 1), *nc = dnc.as<uint64_t>((uint64_t) nblk + 1), *na = dna.as<uint64_t>((uint64_t) nblk + 1);
-    BamCols none = {};
-    hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, none);
-    hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nblk, 256)), dim3(256), 0, st, dc, nblk, nr, nc, na, de);
-    prims::exclusive_scan<unsigned long long>((unsigned long long *) nr, (unsigned long long *) nr, nblk, dscan, st);
-    prims::exclusive_scan<unsigned long long>((unsigned long long *) nc, (unsigned long long *) nc, nblk, dscan, st);
-    prims::exclusive_scan<unsigned long long>((unsigned long long *) na, (unsigned long long *) na, nblk, dscan, st);
-    uint64_t tot[3] = {0, 0, 0};
-    uint32_t he = 0;
-    HIP_CHECK(hipMemcpyAsync(&tot[0], nr + nblk, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&tot[1], nc + nblk, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&tot[2], na + nblk, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&he, de, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (he & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
-    if (he & 2u) throw bk_error(BK_ERR_IO, "BAM records are not BGZF-block aligned (or a record is corrupt): use the host decoder");
-    const uint64_t n = tot[0];
-    if (n >= 0xFFFFFFF0ull || tot[1] >= 0xFFFFFFF0ull || tot[2] >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one BAM");
-    BamCols c;
-    c.tid = h->tid.as<int32_t>(n + 4);
-    c.pos = h->pos.as<int32_t>(n + 4);
-    c.mtid = h->mtid.as<int32_t>(n + 4);
-    c.mpos = h->mpos.as<int32_t>(n + 4);
-    c.isize = h->isize.as<int32_t>(n + 4);
-    c.flag = h->flag.as<uint16_t>(n + 4);
-    c.mapq = h->mapq.as<uint8_t>(n + 4);
-    c.qhash = h->qhash.as<uint64_t>(n + 4);
-    c.cigar_off = h->cigar_off.as<uint32_t>(n + 4);
-    c.aux_off = h->aux_off.as<uint32_t>(n + 4);
-    c.cigar = h->cigar.as<uint32_t>(tot[1] + 4);
-    c.aux = h->aux.as<uint8_t>(tot[2] + 4);
-    hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nr, nc, na, c);
-    const uint32_t ends[2] = {(uint32_t) tot[1], (uint32_t) tot[2]};
-    HIP_CHECK(hipMemcpyAsync(c.cigar_off + n, &ends[0], 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c.aux_off + n, &ends[1], 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipEventRecord(ev[2], st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    float ms_inflate = 0, ms_decode = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms_inflate, ev[0], ev[1]));
-    HIP_CHECK(hipEventElapsedTime(&ms_decode, ev[1], ev[2]));
-    for (auto &e : ev) (void) hipEventDestroy(e);
+    h = new bk_bam_dev();
+    uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
+    uint32_t n_ref = 0;
+    double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0;
+    std::string why;
+    BamCols c = {};
+    auto sync_all = [&]() {
+      for (auto &s : slot) HIP_CHECK(hipStreamSynchronize(s.st));
+    };
+    // columns for at least (r, g, a) records / CIGAR words / aux bytes; the emits in flight finish before a buffer moves
+    auto reserve = [&](uint64_t r, uint64_t g, uint64_t a) {
+      if (r <= cap_rec && g <= cap_cig && a <= cap_aux) return;
+      sync_all();
+      if (r > cap_rec)
+      {
+        const uint64_t nc = std::max(r, cap_rec + cap_rec / 2) + 1024;
+        grow_keep(h->tid, n_rec * 4, (nc + 4) * 4);
+        grow_keep(h->pos, n_rec * 4, (nc + 4) * 4);
+        grow_keep(h->mtid, n_rec * 4, (nc + 4) * 4);
+        grow_keep(h->mpos, n_rec * 4, (nc + 4) * 4);
+        grow_keep(h->isize, n_rec * 4, (nc + 4) * 4);
+        grow_keep(h->flag, n_rec * 2, (nc + 4) * 2);
+        grow_keep(h->mapq, n_rec, nc + 4);
+        grow_keep(h->qhash, n_rec * 8, (nc + 4) * 8);
+        grow_keep(h->cigar_off, n_rec * 4, (nc + 4) * 4);
+        grow_keep(h->aux_off, n_rec * 4, (nc + 4) * 4);
+        cap_rec = nc;
+      }
+      if (g > cap_cig)
+      {
+        const uint64_t nc = std::max(g, cap_cig + cap_cig / 2) + 1024;
+        grow_keep(h->cigar, n_cig * 4, (nc + 4) * 4);
+        cap_cig = nc;
+      }
+      if (a > cap_aux)
+      {
+        const uint64_t nc = std::max(a, cap_aux + cap_aux / 2) + 1024;
+        grow_keep(h->aux, n_aux, nc + 4);
+        cap_aux = nc;
+      }
+      c.tid = h->tid.get<int32_t>();
+      c.pos = h->pos.get<int32_t>();
+      c.mtid = h->mtid.get<int32_t>();
+      c.mpos = h->mpos.get<int32_t>();
+      c.isize = h->isize.get<int32_t>();
+      c.flag = h->flag.get<uint16_t>();
+      c.mapq = h->mapq.get<uint8_t>();
+      c.qhash = h->qhash.get<uint64_t>();
+      c.cigar_off = h->cigar_off.get<uint32_t>();
+      c.aux_off = h->aux_off.get<uint32_t>();
+      c.cigar = h->cigar.get<uint32_t>();
+      c.aux = h->aux.get<uint8_t>();
+    };
+    // chunk -> slot: scan its block headers, copy, inflate, count
+    auto stage = [&](FeedSlot &s, bool first) {
+      if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
+      s.used = true;
+      s.blocks.clear();
+      s.first_blk = 0;
+      s.first_off = 0;
+      const uint64_t lo = off;
+      uint64_t total = 0;
+      const double ts0 = now_s2();
+      if (!bgzf_scan_range(file.data(), file.size(), off, chunk_bytes, s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+      if (first)
+      {
+        // header: inflated on the host, block by block, until the reference list is complete
+        std::vector<uint8_t> head;
+        size_t hb = 0;
+        auto need = [&](size_t bytes) {
+          while (head.size() < bytes)
+          {
+            if (hb >= s.blocks.size()) throw bk_error(hb && off < file.size() ? BK_ERR_LIMIT : BK_ERR_IO, "truncated BAM header (or a header larger than one feed chunk)");
+            if (!host_inflate_block(file.data(), s.blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
+            ++hb;
+          }
+        };
+        need(12);
+        if (memcmp(head.data(), "BAM\1", 4) != 0) throw bk_error(BK_ERR_IO, "not a BAM file");
+        size_t p = 4;
+        const uint32_t l_text = rd32h(head.data() + p);
+        p += 4 + (size_t) l_text;
+        need(p + 4);
+        n_ref = rd32h(head.data() + p);
+        p += 4;
+        for (uint32_t i = 0; i < n_ref; ++i)
+        {
+          need(p + 4);
+          const uint32_t l_name = rd32h(head.data() + p);
+          p += 4;
+          need(p + l_name + 4);
+          h->names.emplace_back((const char *) head.data() + p, l_name ? l_name - 1 : 0);
+          p += l_name;
+          h->lens.push_back(rd32h(head.data() + p));
+          p += 4;
+        }
+        for (auto &nm : h->names) h->name_ptrs.push_back(nm.c_str());
+        uint64_t acc = 0;
+        while (s.first_blk < s.blocks.size() && acc + s.blocks[s.first_blk].isize <= p) acc += s.blocks[s.first_blk++].isize;
+        s.first_off = (uint32_t) (p - acc);
+      }
+      const uint32_t nb = (uint32_t) s.blocks.size();
+      nblk_all += nb;
+      if (nb == 0) return;
+      for (auto &b : s.blocks) b.in_off -= lo;
+      const double ts1 = now_s2();
+      t_scan += ts1 - ts0;
+      uint8_t *df = s.dfile.as<uint8_t>(off - lo + 8);
+      BgzfBlock *db = s.dblk.as<BgzfBlock>((uint64_t) nb + 1);
+      uint8_t *dd = s.ddata.as<uint8_t>(total + 64);
+      uint32_t *de = s.derr.as<uint32_t>(1);
+      uint8_t *slab = s.dslab.as<uint8_t>(bgzf_scratch_bytes(nb));
+      BlockCount *dc = s.dcnt.as<BlockCount>((uint64_t) nb + 1);
+      uint64_t *nr = s.dnr.as<uint64_t>((uint64_t) nb + 1), *nc = s.dnc.as<uint64_t>((uint64_t) nb + 1), *na = s.dna.as<uint64_t>((uint64_t) nb + 1);
+      const double ta = now_s2();
+      t_alloc += ta - ts1;
+      HIP_CHECK(hipMemcpyAsync(df, file.data() + lo, off - lo, hipMemcpyHostToDevice, s.st));
+      HIP_CHECK(hipMemcpyAsync(db, s.blocks.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
+      t_h2d += now_s2() - ta;
+      HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
+      launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st);
+      BamCols none = {};
+      hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, dd, db, nb, s.first_blk, s.first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, 0ull, 0ull, 0ull, none);
+      hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nb, 256)), dim3(256), 0, s.st, dc, nb, nr, nc, na, de);
+      prims::exclusive_scan<unsigned long long>((unsigned long long *) nr, (unsigned long long *) nr, nb, s.dscan, s.st);
+      prims::exclusive_scan<unsigned long long>((unsigned long long *) nc, (unsigned long long *) nc, nb, s.dscan, s.st);
+      prims::exclusive_scan<unsigned long long>((unsigned long long *) na, (unsigned long long *) na, nb, s.dscan, s.st);
+      s.tot[3] = 0;
+      HIP_CHECK(hipMemcpyAsync(&s.tot[0], nr + nb, 8, hipMemcpyDeviceToHost, s.st));
+      HIP_CHECK(hipMemcpyAsync(&s.tot[1], nc + nb, 8, hipMemcpyDeviceToHost, s.st));
+      HIP_CHECK(hipMemcpyAsync(&s.tot[2], na + nb, 8, hipMemcpyDeviceToHost, s.st));
+      HIP_CHECK(hipMemcpyAsync(&s.tot[3], de, 4, hipMemcpyDeviceToHost, s.st));
+      HIP_CHECK(hipEventRecord(s.ev_count, s.st));
+    };
+    // totals of the chunk are known: room in the columns, emit at the running offsets
+    auto finish = [&](FeedSlot &s, bool first, bool more) {
+      const uint32_t nb = (uint32_t) s.blocks.size();
+      if (nb == 0) return;
+      const double tw0 = now_s2();
+      HIP_CHECK(hipEventSynchronize(s.ev_count));
+      if (s.tot[3] & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
+      if (s.tot[3] & 2u) throw bk_error(BK_ERR_IO, "BAM records are not BGZF-block aligned (or a record is corrupt): use the host decoder");
+      const uint64_t r = n_rec + s.tot[0], g = n_cig + s.tot[1], a = n_aux + s.tot[2];
+      if (r >= 0xFFFFFFF0ull || g >= 0xFFFFFFF0ull || a >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one BAM");
+      if (first && more)
+      {
+        // the rest of the file at the first chunk's densities, 5 % on top
+        const double scale = 1.05 * (double) file.size() / (double) std::max<uint64_t>(first_bytes, 1);
+        reserve((uint64_t) (r * scale), (uint64_t) (g * scale), (uint64_t) (a * scale));
+      }
+      reserve(r, g, a);
+      t_reserve += now_s2() - tw0;
+      hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref,
+                         s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(), s.dna.get<uint64_t>(), n_rec, n_cig, n_aux, c);
+      HIP_CHECK(hipEventRecord(s.ev_emit, s.st));
+      n_rec = r;
+      n_cig = g;
+      n_aux = a;
+    };
+    // the host runs one chunk ahead of the totals it waits for
+    uint64_t nchunk = 0;
+    while (off < file.size())
+    {
+      const uint64_t ci = nchunk++;
+      stage(slot[ci % NS], ci == 0);
+      if (ci == 0) first_bytes = off;
+      if (ci > 0) finish(slot[(ci - 1) % NS], ci == 1, true);
+    }
+    if (nchunk) finish(slot[(nchunk - 1) % NS], nchunk == 1, false);
+    const double t_end_loop = now_s2();
+    reserve(n_rec, n_cig, n_aux);  // (an empty file still gets its end entries)
+    sync_all();
+    const uint32_t ends[2] = {(uint32_t) n_cig, (uint32_t) n_aux};
+    HIP_CHECK(hipMemcpy(c.cigar_off + n_rec, &ends[0], 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c.aux_off + n_rec, &ends[1], 4, hipMemcpyHostToDevice));
     const double t3 = now_s2();
     memset(cols, 0, sizeof *cols);
-    cols->n = n;
+    cols->n = n_rec;
     cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
     cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
     cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
-    cols->n_cigar_words = (uint32_t) tot[1];
-    cols->n_aux_bytes = (uint32_t) tot[2];
+    cols->n_cigar_words = (uint32_t) n_cig;
+    cols->n_aux_bytes = (uint32_t) n_aux;
     if (n_targets) *n_targets = (int) h->names.size();
     if (names) *names = h->name_ptrs.data();
     if (lens) *lens = h->lens.data();
     if (getenv("BREAKID_FEED_STATS"))
-      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %u BGZF blocks: read+scan+header %.3f s, H2D %.3f s, inflate+decode on the GPU %.3f s (inflate kernel %.1f ms, record decode %.1f ms)\n",
-              (unsigned long long) n, file.size() / 1e6, nblk, t1 - t0, t2 - t1, t3 - t2, ms_inflate, ms_decode);
+      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (host side: header hops %.3f s, buffers %.3f s, H2D calls %.3f s, waiting for chunk totals + column growth %.3f s, final sync %.3f s)\n",
+              (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_scan, t_alloc, t_h2d, t_reserve, t3 - t_end_loop);
     *out = h;
     return BK_OK;
   }
   catch (const bk_error &ex)
   {
+    (void) hipDeviceSynchronize();  // nothing of a failed decode is still running when its buffers go
     delete h;
     if (err && errlen) snprintf(err, errlen, "%s", ex.what());
     return ex.code;

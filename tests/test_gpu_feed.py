@@ -155,3 +155,99 @@ def test_gpu_inflate_matches_zlib(level):
     src2 = np.frombuffer(bytes(bad), np.uint8)
     rc = L.bk_debug_bgzf_inflate(src2.ctypes.data, len(bad), out.ctypes.data, len(out), C.byref(olen), C.byref(ms), err, 256)
     assert rc != 0 or out[:len(raw)].tobytes() != raw
+
+
+def _bgzf(blocks_raw, compress):
+    out = []
+    for blk in blocks_raw:
+        comp = compress(blk)
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(blk), len(blk)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+def _gpu_inflate(data, n_out):
+    L = capi.lib()
+    import torch  # noqa: F401
+    src = np.frombuffer(data, np.uint8)
+    out = np.zeros(n_out + 16, np.uint8)
+    olen, ms, err = C.c_uint64(), C.c_float(), C.create_string_buffer(256)
+    rc = L.bk_debug_bgzf_inflate(src.ctypes.data, len(data), out.ctypes.data, len(out), C.byref(olen), C.byref(ms), err, 256)
+    return rc, olen.value, out[:n_out].tobytes(), err.value
+
+
+def test_gpu_inflate_block_kinds_and_code_shapes():
+    """deflate streams the BAM writers do not usually produce: fixed-Huffman blocks, several deflate blocks per BGZF
+    block (sync flushes, a stored block between two compressed ones), skewed alphabets whose rare symbols get 12-15 bit
+    codes, maximal-length matches and distance-1 runs across the whole block, one-byte and empty blocks"""
+    rng = np.random.default_rng(5)
+    # geometric byte frequencies: code lengths up to 15 for the tail of the alphabet
+    p = 0.5 ** (np.arange(256) / 6.0)
+    skew = rng.choice(256, 0xFF00, p=p / p.sum()).astype(np.uint8).tobytes()
+    texty = (b"chr1\t100\t+\t60M40S\t60\t0;" * 3000)[:0xFF00]
+    runs = bytes(0xFF00)
+    mixed = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes() + b"A" * 20000 + rng.integers(0, 4, 30000, dtype=np.uint8).tobytes()
+    for name, blks in (("skewed", [skew]), ("text", [texty]), ("runs", [runs]), ("mixed", [mixed, skew[:777], b"x", b"", texty[:5000]])):
+        raw = b"".join(blks)
+        # (a) one dynamic block per BGZF block, best compression
+        def dyn(b):
+            c = zlib.compressobj(9, zlib.DEFLATED, -15)
+            return c.compress(b) + c.flush()
+        # (b) fixed Huffman codes only
+        def fixed(b):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+            return c.compress(b) + c.flush()
+        # (c) several deflate blocks in one BGZF block: sync flushes (each adds an empty stored block) and a level-0 piece
+        def multi(b):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            out = b""
+            step = max(1, len(b) // 5)
+            for i in range(0, len(b), step):
+                out += c.compress(b[i:i + step]) + c.flush(zlib.Z_SYNC_FLUSH if (i // step) % 2 else zlib.Z_FULL_FLUSH)
+            return out + c.flush()
+        # (d) Huffman only (no matches) and RLE (distance 1 only)
+        def huff(b):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+            return c.compress(b) + c.flush()
+        def rle(b):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_RLE)
+            return c.compress(b) + c.flush()
+        for kind, fn in (("dyn", dyn), ("fixed", fixed), ("multi", multi), ("huff", huff), ("rle", rle)):
+            data = _bgzf(blks, fn)
+            rc, n, got, err = _gpu_inflate(data, len(raw))
+            assert rc == 0 and n == len(raw) and got == raw, (name, kind, rc, err)
+    # truncated / corrupted streams: flagged, never a hang or a wrong "success"
+    data = bytearray(_bgzf([texty], lambda b: zlib.compress(b, 6)[2:-4]))
+    for at in (30, 100, len(data) // 2):
+        bad = bytearray(data)
+        bad[at] ^= 0xA5
+        rc, n, got, err = _gpu_inflate(bytes(bad), len(texty))
+        assert rc != 0 or n == len(texty)   # (a flipped bit may still be a valid stream of the same length)
+
+
+def test_device_decode_in_chunks_equals_one_chunk():
+    """the streaming feed (bk_bam_decode_device takes the file in chunks; three in flight) with chunks of a few blocks:
+    same table, including the growth of the columns when the first chunk under-estimates the rest"""
+    contigs, ds = _dataset()
+    # denser tail: the first chunk's records-per-byte under-estimates the file
+    for i in range(len(ds.recs) // 2, len(ds.recs), 3):
+        ds.recs[i].sa = "chr1,%d,-,30M70S,50,1;" % (5 + i)
+    ref = ds.to_soa()
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "a.bam")
+        ds.write_bam(p, aligned=True)
+        size = os.path.getsize(p)
+        for mb in (None, size / 5 / 1048576.0, 0.07):
+            if mb is None:
+                os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
+            else:
+                os.environ["BREAKID_FEED_CHUNK_MB"] = repr(mb)
+            try:
+                table = capi.decode_bam_device(p)
+            finally:
+                os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
+            got = _device_cols(table)
+            assert table.contigs == contigs
+            for k, _ in abi.SOA_COLS:
+                assert np.array_equal(got[k], ref[k]), (mb, k)
+            table.close()
