@@ -3,7 +3,10 @@
 #include "bgzf_gpu.h"
 #include "../../include/breakid_hip.h"
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -406,6 +409,162 @@ bool host_inflate_block(const uint8_t *file, const BgzfBlock &b, std::vector<uin
 
 namespace
 {
+// Host staging of the mapped file: from the fourth chunk on, a producer thread copies fixed ranges of the file
+// ([k C, (k + 1) C + 64 KiB + 64): every block that starts inside chunk k ends inside the range) into page-locked buffers
+// with a few helper threads, ahead of the thread that drives the GPU.  The page faults of the mapping and the copy run on
+// those threads; the H2D copy out of a staging buffer is a plain asynchronous DMA.  The first three chunks are copied
+// straight from the mapping (the runtime pins and unpins the pages of every piece on the calling thread: 16-19 GB/s)
+// because a fresh staging buffer costs more than that (first touch + registration, ~10 ms per 64 MiB); the buffers stay
+// with the process for the next file.
+struct StageCache
+{
+  std::mutex mu;
+  std::vector<std::pair<uint8_t *, uint64_t>> idle;  // registered buffers and their sizes
+  uint8_t *take(uint64_t bytes)
+  {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < idle.size(); ++i)
+        if (idle[i].second == bytes)
+        {
+          uint8_t *p = idle[i].first;
+          idle.erase(idle.begin() + (long) i);
+          return p;
+        }
+    }
+    uint8_t *p = (uint8_t *) aligned_alloc(2u << 20, (bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20));
+    if (!p) return nullptr;
+    (void) madvise(p, bytes, MADV_HUGEPAGE);  // fewer first-touch faults and a shorter registration where the kernel allows it
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess)
+    {
+      free(p);
+      return nullptr;
+    }
+    return p;
+  }
+  void give(uint8_t *p, uint64_t bytes)
+  {
+    std::lock_guard<std::mutex> g(mu);
+    idle.emplace_back(p, bytes);
+  }
+};
+StageCache &stage_cache()
+{
+  static StageCache *c = new StageCache();  // never destroyed: the buffers go with the process
+  return *c;
+}
+
+struct StagePool
+{
+  static constexpr int NB = 3;
+  static constexpr uint64_t FIRST = 3;  // chunks before this one are copied from the mapping
+  static constexpr uint64_t SLACK = 65536 + 64;
+  struct Buf
+  {
+    uint8_t *p = nullptr;
+    int state = 0;  // 0 free, 1 filled (chunk), 2 in flight (ev recorded by the consumer)
+    uint64_t chunk = 0, lo = 0, n = 0;
+    hipEvent_t ev = nullptr;
+  };
+  Buf buf[NB];
+  const uint8_t *file;
+  uint64_t size, chunk_bytes, nchunks, buf_bytes;
+  int threads, device;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread producer;
+  bool stop = false;
+  std::string error;
+
+  StagePool(const uint8_t *f, uint64_t n, uint64_t cb, int th, int dev)
+      : file(f), size(n), chunk_bytes(cb), nchunks((n + cb - 1) / cb), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
+  {
+    for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+    if (nchunks > FIRST) producer = std::thread([this] { run(); });
+  }
+  ~StagePool() { shutdown(); }
+  void shutdown()
+  {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (producer.joinable()) producer.join();
+    for (auto &b : buf)
+    {
+      if (b.state == 2 && b.ev) (void) hipEventSynchronize(b.ev);
+      if (b.p) stage_cache().give(b.p, buf_bytes);
+      if (b.ev) (void) hipEventDestroy(b.ev);
+      b.p = nullptr;
+      b.ev = nullptr;
+      b.state = 0;
+    }
+  }
+  void run()
+  {
+    (void) hipSetDevice(device);
+    for (uint64_t k = FIRST; k < nchunks; ++k)
+    {
+      Buf &b = buf[k % NB];
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return stop || b.state == 0 || b.state == 2; });
+        if (stop) return;
+        if (b.state == 2)
+        {
+          g.unlock();
+          (void) hipEventSynchronize(b.ev);  // the DMA out of this buffer is done
+          g.lock();
+          b.state = 0;
+        }
+      }
+      const uint64_t lo = k * chunk_bytes, n = std::min(size - lo, chunk_bytes + SLACK);
+      if (!b.p) b.p = stage_cache().take(buf_bytes);
+      if (!b.p)
+      {
+        std::lock_guard<std::mutex> g(mu);
+        error = "no page-locked host memory for the feed's staging buffers";
+        cv.notify_all();
+        return;
+      }
+      std::vector<std::thread> ts;
+      const uint64_t per = ((n + threads - 1) / threads + 4095) / 4096 * 4096;
+      for (int t = 1; t < threads; ++t)
+        if ((uint64_t) t * per < n) ts.emplace_back([&, t] { memcpy(b.p + t * per, file + lo + t * per, std::min(per, n - t * per)); });
+      memcpy(b.p, file + lo, std::min(per, n));
+      for (auto &t : ts) t.join();
+      {
+        std::lock_guard<std::mutex> g(mu);
+        b.chunk = k;
+        b.lo = lo;
+        b.n = n;
+        b.state = 1;
+      }
+      cv.notify_all();
+    }
+  }
+  // chunk k >= FIRST: blocks until it is staged
+  Buf &get(uint64_t k)
+  {
+    Buf &b = buf[k % NB];
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return !error.empty() || (b.state == 1 && b.chunk == k); });
+    if (!error.empty()) throw bk_error(BK_ERR_LIMIT, error);
+    return b;
+  }
+  // the consumer has queued its copy out of b on st
+  void release(Buf &b, hipStream_t st)
+  {
+    HIP_CHECK(hipEventRecord(b.ev, st));
+    {
+      std::lock_guard<std::mutex> g(mu);
+      b.state = 2;
+    }
+    cv.notify_all();
+  }
+};
+
 // one chunk of the file in flight: its compressed bytes, inflated bytes, match tokens and per-block counts
 struct FeedSlot
 {
@@ -437,9 +596,9 @@ void grow_keep(DevBuf &b, size_t used, size_t need)
 
 // The file is taken in chunks of BREAKID_FEED_CHUNK_MB (64) MiB of BGZF blocks.  Per chunk: H2D copy of the mapped
 // bytes, inflate, per-block record counts + scans, D2H of the three totals - all on the chunk's own stream - and, once the
-// totals are on the host, the emit kernel at the running offsets of the columns.  Three chunks are in flight, so the
+// totals are on the host, the emit kernel at the running offsets of the columns.  Up to four chunks are in flight, so the
 // copy of one overlaps the inflate of the one before and the emit of the one before that, kernels of neighbouring chunks
-// fill each other's tails, and device memory holds three chunks plus the columns whatever the size of the file.  The
+// fill each other's tails, and device memory holds four chunks plus the columns whatever the size of the file.  The
 // columns are sized from the first chunk (records per compressed byte x file size) and grow by copying when that was
 // too small.
 extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
@@ -453,10 +612,17 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
     HIP_CHECK(hipSetDevice(device));
     const double t0 = now_s2();
     MappedFile file(path);  // mapped, not read: the header hop touches 18 bytes per block and the H2D copies stream the rest
-    uint64_t chunk_bytes = 64ull << 20;
+    if (file.size() == 0) throw bk_error(BK_ERR_IO, "empty file");
+    // a chunk's inflate kernel lasts as long as its slowest block (~3 ms) however few blocks it has, and kernels of
+    // neighbouring chunks mostly run one after the other: big files take bigger chunks
+    uint64_t chunk_bytes = file.size() >= (1ull << 30) ? 128ull << 20 : 64ull << 20;
     if (const char *e = getenv("BREAKID_FEED_CHUNK_MB"))
       if (atof(e) > 0) chunk_bytes = (uint64_t) (atof(e) * 1048576.0);
-    constexpr int NS = 3;
+    chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000) / 4096 * 4096 + 4096;  // a chunk is longer than the longest block
+    int copy_threads = 4;
+    if (const char *e = getenv("BREAKID_THREADS"))
+      if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
+    constexpr int NS = 4, LAG = 2;  // chunks in flight; how far the driver thread runs ahead of the totals it waits for
     FeedSlot slot[NS];
     for (auto &s : slot)
     {
@@ -466,9 +632,10 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       HIP_CHECK(hipHostMalloc((void **) &s.tot, 4 * sizeof(uint64_t), hipHostMallocDefault));
     }
     h = new bk_bam_dev();
+    StagePool pool(file.data(), file.size(), chunk_bytes, copy_threads, device);
     uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
     uint32_t n_ref = 0;
-    double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0;
+    double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0;
     std::string why;
     BamCols c = {};
     auto sync_all = [&]() {
@@ -518,17 +685,24 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       c.cigar = h->cigar.get<uint32_t>();
       c.aux = h->aux.get<uint8_t>();
     };
-    // chunk -> slot: scan its block headers, copy, inflate, count
-    auto stage = [&](FeedSlot &s, bool first) {
+    // chunk k -> slot: hop over the block headers in the staged bytes, copy, inflate, count
+    auto stage = [&](FeedSlot &s, uint64_t k) {
+      const bool first = k == 0;
       if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
       s.used = true;
       s.blocks.clear();
       s.first_blk = 0;
       s.first_off = 0;
-      const uint64_t lo = off;
-      uint64_t total = 0;
+      const double ts00 = now_s2();
+      StagePool::Buf *sb = k >= StagePool::FIRST ? &pool.get(k) : nullptr;
+      const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
+      const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
       const double ts0 = now_s2();
-      if (!bgzf_scan_range(file.data(), file.size(), off, chunk_bytes, s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+      t_stage_wait += ts0 - ts00;
+      // the blocks that start inside [k C, (k + 1) C); offsets are relative to the start of the range
+      uint64_t total = 0, rel = off - src_lo;
+      if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+      off = src_lo + rel;
       if (first)
       {
         // header: inflated on the host, block by block, until the reference list is complete
@@ -538,7 +712,7 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
           while (head.size() < bytes)
           {
             if (hb >= s.blocks.size()) throw bk_error(hb && off < file.size() ? BK_ERR_LIMIT : BK_ERR_IO, "truncated BAM header (or a header larger than one feed chunk)");
-            if (!host_inflate_block(file.data(), s.blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
+            if (!host_inflate_block(fdata, s.blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
             ++hb;
           }
         };
@@ -568,11 +742,14 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       }
       const uint32_t nb = (uint32_t) s.blocks.size();
       nblk_all += nb;
-      if (nb == 0) return;
-      for (auto &b : s.blocks) b.in_off -= lo;
+      if (nb == 0)
+      {
+        if (sb) pool.release(*sb, s.st);
+        return;
+      }
       const double ts1 = now_s2();
       t_scan += ts1 - ts0;
-      uint8_t *df = s.dfile.as<uint8_t>(off - lo + 8);
+      uint8_t *df = s.dfile.as<uint8_t>(rel + 8);
       BgzfBlock *db = s.dblk.as<BgzfBlock>((uint64_t) nb + 1);
       uint8_t *dd = s.ddata.as<uint8_t>(total + 64);
       uint32_t *de = s.derr.as<uint32_t>(1);
@@ -581,7 +758,8 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       uint64_t *nr = s.dnr.as<uint64_t>((uint64_t) nb + 1), *nc = s.dnc.as<uint64_t>((uint64_t) nb + 1), *na = s.dna.as<uint64_t>((uint64_t) nb + 1);
       const double ta = now_s2();
       t_alloc += ta - ts1;
-      HIP_CHECK(hipMemcpyAsync(df, file.data() + lo, off - lo, hipMemcpyHostToDevice, s.st));
+      HIP_CHECK(hipMemcpyAsync(df, fdata, rel, hipMemcpyHostToDevice, s.st));
+      if (sb) pool.release(*sb, s.st);
       HIP_CHECK(hipMemcpyAsync(db, s.blocks.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
       t_h2d += now_s2() - ta;
       HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
@@ -624,16 +802,15 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       n_cig = g;
       n_aux = a;
     };
-    // the host runs one chunk ahead of the totals it waits for
-    uint64_t nchunk = 0;
-    while (off < file.size())
+    // the driver thread stages chunk ci, then takes the totals of chunk ci - LAG
+    const uint64_t nchunk = pool.nchunks;
+    for (uint64_t ci = 0; ci < nchunk + LAG; ++ci)
     {
-      const uint64_t ci = nchunk++;
-      stage(slot[ci % NS], ci == 0);
+      if (ci < nchunk) stage(slot[ci % NS], ci);
       if (ci == 0) first_bytes = off;
-      if (ci > 0) finish(slot[(ci - 1) % NS], ci == 1, true);
+      if (ci >= LAG) finish(slot[(ci - LAG) % NS], ci == LAG, ci - LAG + 1 < nchunk);
     }
-    if (nchunk) finish(slot[(nchunk - 1) % NS], nchunk == 1, false);
+    if (off != file.size()) throw bk_error(BK_ERR_IO, "BGZF blocks do not end at the end of the file");
     const double t_end_loop = now_s2();
     reserve(n_rec, n_cig, n_aux);  // (an empty file still gets its end entries)
     sync_all();
@@ -651,9 +828,15 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
     if (n_targets) *n_targets = (int) h->names.size();
     if (names) *names = h->name_ptrs.data();
     if (lens) *lens = h->lens.data();
+    const double td0 = now_s2();
+    pool.shutdown();
+    const double td1 = now_s2();
+    for (auto &sl : slot)
+      for (DevBuf *b : {&sl.dfile, &sl.dblk, &sl.ddata, &sl.dslab, &sl.dcnt, &sl.dnr, &sl.dnc, &sl.dna, &sl.dscan, &sl.derr}) b->release();
+    const double td2 = now_s2();
     if (getenv("BREAKID_FEED_STATS"))
-      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (host side: header hops %.3f s, buffers %.3f s, H2D calls %.3f s, waiting for chunk totals + column growth %.3f s, final sync %.3f s)\n",
-              (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_scan, t_alloc, t_h2d, t_reserve, t3 - t_end_loop);
+      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, waiting for chunk totals + column growth %.3f s, final sync %.3f s, teardown %.3f s)\n",
+              (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_stage_wait, t_scan, t_alloc, t_h2d, t_reserve, t3 - t_end_loop, td2 - td0);
     *out = h;
     return BK_OK;
   }

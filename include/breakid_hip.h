@@ -220,7 +220,8 @@ void bk_bam_close(bk_bam *b);
 /* The same feed on the GPU: the file image goes to HBM, BGZF blocks are inflated one wavefront each (bgzf_gpu.hip) and
  * the records are decoded into device-resident columns (cols holds device pointers: bk_upload_records(ctx, cols,
  * BK_MEM_DEVICE)).  Needs a BAM whose records do not straddle BGZF blocks (every htslib / samtools file); others fail
- * with BK_ERR_IO and take bk_bam_open / bk_bam_decode.  Single batch: file image + inflated stream must fit in HBM. */
+ * with BK_ERR_IO and take bk_bam_open / bk_bam_decode.  The file is mapped and streamed in chunks
+ * (BREAKID_FEED_CHUNK_MB, default 64-128 MiB, up to four in flight): device memory holds the chunks in flight and the columns. */
 typedef struct bk_bam_dev bk_bam_dev;
 int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                          char *err, size_t errlen);
