@@ -18,8 +18,8 @@ inline uint16_t rd16h(const uint8_t *p) { return (uint16_t) (p[0] | (p[1] << 8))
 
 // hops over BGZF block headers (18 bytes each) from file offset `off` until at least max_bytes of the file are covered or
 // the file ends; appends to blocks (in_off = absolute file offset of the deflate stream, out_off = total before the block,
-// total grows by the 256-byte aligned block sizes); false + why on a malformed file
-bool bgzf_scan_range(const uint8_t *file, uint64_t n, uint64_t &off, uint64_t max_bytes, std::vector<BgzfBlock> &blocks, uint64_t &total, std::string &why)
+// total grows by the block sizes rounded up to `align`); false + why on a malformed file
+bool bgzf_scan_range(const uint8_t *file, uint64_t n, uint64_t &off, uint64_t max_bytes, std::vector<BgzfBlock> &blocks, uint64_t &total, std::string &why, uint64_t align = BGZF_OUT_ALIGN)
 {
   const uint64_t start = off;
   while (off < n && off - start < max_bytes)
@@ -63,7 +63,7 @@ bool bgzf_scan_range(const uint8_t *file, uint64_t n, uint64_t &off, uint64_t ma
       return false;
     }
     b.out_off = total;
-    total += (b.isize + BGZF_OUT_ALIGN - 1) / BGZF_OUT_ALIGN * BGZF_OUT_ALIGN;
+    total += (b.isize + align - 1) / align * align;
     blocks.push_back(b);
     off += (uint64_t) bsize + 1;
   }
@@ -238,32 +238,39 @@ __device__ __forceinline__ uint64_t qname_hash_dev(const uint8_t *name, uint32_t
   return h;
 }
 
-// EMIT = false: validate + count; EMIT = true: write the columns (bases from the scans)
+// EMIT = false: validate + count; EMIT = true: write the columns (bases from the scans).
+// Aligned files (entry == nullptr): every block starts with a record and no record leaves its block.  Packed mode
+// (entry != nullptr, the inflated stream is contiguous, `total` bytes): the lane of block b takes the records that START
+// in b, from entry[b] (the block's size = none), wherever they end; next_abs[b] = stream offset where its walk stopped.
 template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk,
                                                                          uint32_t first_off, int32_t n_ref, BlockCount *__restrict__ cnt, const uint64_t *__restrict__ rec_base,
-                                                                         const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, uint64_t rec0, uint64_t cig0, uint64_t aux0, BamCols c)
+                                                                         const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, uint64_t rec0, uint64_t cig0, uint64_t aux0, BamCols c,
+                                                                         const uint32_t *__restrict__ entry = nullptr, uint64_t total = 0, uint64_t *__restrict__ next_abs = nullptr)
 {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
   BlockCount bc = {0, 0, 0, 0};
+  uint64_t stop = 0;
   if (b >= first_blk)
   {
     const BgzfBlock bb = blk[b];
     const uint8_t *d = data + bb.out_off;
-    uint32_t p = b == first_blk ? first_off : 0u;
+    // bytes a record that starts in this block may use
+    const uint64_t room = entry ? total - bb.out_off : (uint64_t) bb.isize;
+    uint64_t p = entry ? entry[b] : (b == first_blk ? first_off : 0u);
     uint64_t ri = EMIT ? rec0 + rec_base[b] : 0, ci = EMIT ? cig0 + cig_base[b] : 0, ai = EMIT ? aux0 + aux_base[b] : 0;  // rec0.. = totals of the chunks before this one
     while (p < bb.isize)
     {
-      if (p + 36 > bb.isize)
+      if (p + 36 > room)
       {
         bc.bad = 1;
         break;
       }
       const uint32_t bs = ld32(d + p);
       const uint8_t *r = d + p + 4;
-      if (bs < 32 || (unsigned long long) p + 4 + bs > bb.isize)
+      if (bs < 32 || p + 4 + bs > room)
       {
-        bc.bad = 1;  // a record that continues in the next block (or garbage)
+        bc.bad = 1;  // a record that continues in the next block (aligned mode), or garbage
         break;
       }
       const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
@@ -311,8 +318,13 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
       bc.n_aux += blob;
       p += 4 + bs;
     }
+    stop = bb.out_off + p;
   }
-  if (!EMIT) cnt[b] = bc;
+  if (!EMIT)
+  {
+    cnt[b] = bc;
+    if (next_abs) next_abs[b] = stop;
+  }
 }
 
 __global__ void k_bam_count_split(const BlockCount *__restrict__ cnt, uint32_t nblk, uint64_t *__restrict__ nr, uint64_t *__restrict__ nc, uint64_t *__restrict__ na, uint32_t *__restrict__ err)
@@ -323,6 +335,69 @@ __global__ void k_bam_count_split(const BlockCount *__restrict__ cnt, uint32_t n
   nc[b] = cnt[b].n_cig;
   na[b] = cnt[b].n_aux;
   if (cnt[b].bad) atomicOr(err, 2u);
+}
+
+// ---- record boundaries of a packed stream (files whose records straddle BGZF blocks: htsjdk / Picard / GATK writers)
+// Is there a well-formed record at stream offset `at`?  (the checks of the count kernel + the ones a random offset fails:
+// mate reference, positions, NUL-terminated name)
+__device__ __forceinline__ bool plausible_record(const uint8_t *d, uint64_t at, uint64_t total, int32_t n_ref, uint64_t &next)
+{
+  if (at + 36 > total) return false;
+  const uint32_t bs = ld32(d + at);
+  if (bs < 32 || at + 4 + bs > total) return false;
+  const uint8_t *r = d + at + 4;
+  const int32_t tid = (int32_t) ld32(r), pos = (int32_t) ld32(r + 4), mtid = (int32_t) ld32(r + 20), mpos = (int32_t) ld32(r + 24);
+  const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
+  if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || l_name < 1) return false;
+  const unsigned long long need = 32ull + l_name + 4ull * n_cig + ((unsigned long long) l_seq + 1) / 2 + l_seq;
+  if (need > bs || r[32 + l_name - 1] != 0) return false;
+  next = at + 4 + bs;
+  return true;
+}
+
+// One wave per block: entry[b] = the first offset in the block from which GUESS_CHAIN records in a row are well formed
+// (or the chain reaches the end of the stream); isize = no record starts here.  A guess, made exact by k_bam_verify.
+constexpr int GUESS_CHAIN = 4;
+__global__ __launch_bounds__(64) void k_bam_guess(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk, uint32_t first_off,
+                                                  int32_t n_ref, uint64_t total, uint32_t *__restrict__ entry)
+{
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  if (b >= nblk) return;
+  const BgzfBlock bb = blk[b];
+  if (b <= first_blk)
+  {
+    if (lane == 0) entry[b] = b == first_blk ? first_off : bb.isize;  // the header's blocks; the first record is known
+    return;
+  }
+  uint32_t found = bb.isize;
+  for (uint32_t base = 0; base < bb.isize; base += 64)
+  {
+    const uint32_t s = base + lane;
+    bool ok = s < bb.isize;
+    uint64_t at = bb.out_off + s;
+    for (int k = 0; ok && k < GUESS_CHAIN && at < total; ++k) ok = plausible_record(data, at, total, n_ref, at);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    if (m)
+    {
+      found = base + (uint32_t) __ffsll((long long) m) - 1u;
+      break;
+    }
+  }
+  if (lane == 0) entry[b] = found;
+}
+
+// The guesses are exact iff the walks chain: the walk of every block that has an entry stops exactly at the entry of the
+// next block that has one (the first entry is the known first record, the last walk stops at the end of the stream).
+// By induction from the first record every entry then IS a record boundary.
+__global__ void k_bam_verify(const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk, const uint32_t *__restrict__ entry, const uint64_t *__restrict__ next_abs, uint64_t total,
+                             uint32_t *__restrict__ err)
+{
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk || b < first_blk || entry[b] >= blk[b].isize) return;
+  uint32_t nb = b + 1;
+  while (nb < nblk && entry[nb] >= blk[nb].isize) ++nb;
+  const uint64_t want = nb < nblk ? blk[nb].out_off + entry[nb] : total;
+  if (next_abs[b] != want) atomicOr(err, 4u);
 }
 }  // namespace
 
@@ -565,6 +640,53 @@ struct StagePool
   }
 };
 
+// BAM header (magic, text, reference list) from the first BGZF blocks, inflated on the host one by one until the
+// list is complete; first_blk / first_off = where the first record starts
+void parse_bam_header(const uint8_t *fdata, const std::vector<BgzfBlock> &blocks, bool more_file, bk_bam_dev *h, uint32_t &n_ref, uint32_t &first_blk, uint32_t &first_off)
+{
+  std::vector<uint8_t> head;
+  size_t hb = 0;
+  auto need = [&](size_t bytes) {
+    while (head.size() < bytes)
+    {
+      if (hb >= blocks.size()) throw bk_error(hb && more_file ? BK_ERR_LIMIT : BK_ERR_IO, "truncated BAM header (or a header larger than one feed chunk)");
+      if (!host_inflate_block(fdata, blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
+      ++hb;
+    }
+  };
+  need(12);
+  if (memcmp(head.data(), "BAM\1", 4) != 0) throw bk_error(BK_ERR_IO, "not a BAM file");
+  size_t p = 4;
+  const uint32_t l_text = rd32h(head.data() + p);
+  p += 4 + (size_t) l_text;
+  need(p + 4);
+  n_ref = rd32h(head.data() + p);
+  p += 4;
+  h->names.clear();
+  h->name_ptrs.clear();
+  h->lens.clear();
+  for (uint32_t i = 0; i < n_ref; ++i)
+  {
+    need(p + 4);
+    const uint32_t l_name = rd32h(head.data() + p);
+    p += 4;
+    need(p + l_name + 4);
+    h->names.emplace_back((const char *) head.data() + p, l_name ? l_name - 1 : 0);
+    p += l_name;
+    h->lens.push_back(rd32h(head.data() + p));
+    p += 4;
+  }
+  for (auto &nm : h->names) h->name_ptrs.push_back(nm.c_str());
+  uint64_t acc = 0;
+  first_blk = 0;
+  while (first_blk < blocks.size() && acc + blocks[first_blk].isize <= p) acc += blocks[first_blk++].isize;
+  first_off = (uint32_t) (p - acc);
+}
+
+struct not_block_aligned
+{
+};
+
 // one chunk of the file in flight: its compressed bytes, inflated bytes, match tokens and per-block counts
 struct FeedSlot
 {
@@ -601,17 +723,10 @@ void grow_keep(DevBuf &b, size_t used, size_t need)
 // fill each other's tails, and device memory holds four chunks plus the columns whatever the size of the file.  The
 // columns are sized from the first chunk (records per compressed byte x file size) and grow by copying when that was
 // too small.
-extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
-                                    char *err, size_t errlen)
+static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols)
 {
-  bk_bam_dev *h = nullptr;
-  try
   {
-    if (!path || !out || !cols) throw bk_error(BK_ERR_ARG, "bk_bam_decode_device: null argument");
-    *out = nullptr;
-    HIP_CHECK(hipSetDevice(device));
     const double t0 = now_s2();
-    MappedFile file(path);  // mapped, not read: the header hop touches 18 bytes per block and the H2D copies stream the rest
     if (file.size() == 0) throw bk_error(BK_ERR_IO, "empty file");
     // a chunk's inflate kernel lasts as long as its slowest block (~3 ms) however few blocks it has, and kernels of
     // neighbouring chunks mostly run one after the other: big files take bigger chunks
@@ -631,7 +746,6 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
       HIP_CHECK(hipHostMalloc((void **) &s.tot, 4 * sizeof(uint64_t), hipHostMallocDefault));
     }
-    h = new bk_bam_dev();
     StagePool pool(file.data(), file.size(), chunk_bytes, copy_threads, device);
     uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
     uint32_t n_ref = 0;
@@ -703,43 +817,7 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       uint64_t total = 0, rel = off - src_lo;
       if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
       off = src_lo + rel;
-      if (first)
-      {
-        // header: inflated on the host, block by block, until the reference list is complete
-        std::vector<uint8_t> head;
-        size_t hb = 0;
-        auto need = [&](size_t bytes) {
-          while (head.size() < bytes)
-          {
-            if (hb >= s.blocks.size()) throw bk_error(hb && off < file.size() ? BK_ERR_LIMIT : BK_ERR_IO, "truncated BAM header (or a header larger than one feed chunk)");
-            if (!host_inflate_block(fdata, s.blocks[hb], head)) throw bk_error(BK_ERR_IO, "inflate failed");
-            ++hb;
-          }
-        };
-        need(12);
-        if (memcmp(head.data(), "BAM\1", 4) != 0) throw bk_error(BK_ERR_IO, "not a BAM file");
-        size_t p = 4;
-        const uint32_t l_text = rd32h(head.data() + p);
-        p += 4 + (size_t) l_text;
-        need(p + 4);
-        n_ref = rd32h(head.data() + p);
-        p += 4;
-        for (uint32_t i = 0; i < n_ref; ++i)
-        {
-          need(p + 4);
-          const uint32_t l_name = rd32h(head.data() + p);
-          p += 4;
-          need(p + l_name + 4);
-          h->names.emplace_back((const char *) head.data() + p, l_name ? l_name - 1 : 0);
-          p += l_name;
-          h->lens.push_back(rd32h(head.data() + p));
-          p += 4;
-        }
-        for (auto &nm : h->names) h->name_ptrs.push_back(nm.c_str());
-        uint64_t acc = 0;
-        while (s.first_blk < s.blocks.size() && acc + s.blocks[s.first_blk].isize <= p) acc += s.blocks[s.first_blk++].isize;
-        s.first_off = (uint32_t) (p - acc);
-      }
+      if (first) parse_bam_header(fdata, s.blocks, off < file.size(), h, n_ref, s.first_blk, s.first_off);
       const uint32_t nb = (uint32_t) s.blocks.size();
       nblk_all += nb;
       if (nb == 0)
@@ -784,7 +862,7 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       const double tw0 = now_s2();
       HIP_CHECK(hipEventSynchronize(s.ev_count));
       if (s.tot[3] & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
-      if (s.tot[3] & 2u) throw bk_error(BK_ERR_IO, "BAM records are not BGZF-block aligned (or a record is corrupt): use the host decoder");
+      if (s.tot[3] & 2u) throw not_block_aligned();
       const uint64_t r = n_rec + s.tot[0], g = n_cig + s.tot[1], a = n_aux + s.tot[2];
       if (r >= 0xFFFFFFF0ull || g >= 0xFFFFFFF0ull || a >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one BAM");
       if (first && more)
@@ -825,18 +903,159 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
     cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
     cols->n_cigar_words = (uint32_t) n_cig;
     cols->n_aux_bytes = (uint32_t) n_aux;
-    if (n_targets) *n_targets = (int) h->names.size();
-    if (names) *names = h->name_ptrs.data();
-    if (lens) *lens = h->lens.data();
     const double td0 = now_s2();
     pool.shutdown();
-    const double td1 = now_s2();
     for (auto &sl : slot)
       for (DevBuf *b : {&sl.dfile, &sl.dblk, &sl.ddata, &sl.dslab, &sl.dcnt, &sl.dnr, &sl.dnc, &sl.dna, &sl.dscan, &sl.derr}) b->release();
     const double td2 = now_s2();
     if (getenv("BREAKID_FEED_STATS"))
       fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, waiting for chunk totals + column growth %.3f s, final sync %.3f s, teardown %.3f s)\n",
               (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_stage_wait, t_scan, t_alloc, t_h2d, t_reserve, t3 - t_end_loop, td2 - td0);
+  }
+}
+
+// Files whose records straddle BGZF blocks (htsjdk / Picard / GATK writers; htslib keeps records inside blocks).  One
+// batch: the whole file image goes to HBM, the blocks are inflated into ONE contiguous stream, every block guesses its
+// first record boundary (k_bam_guess), the walks are verified to chain (k_bam_verify: then the guesses are exact) and the
+// columns are emitted as in the aligned case.
+static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols)
+{
+  (void) device;
+  const double t0 = now_s2();
+  std::vector<BgzfBlock> blocks;
+  uint64_t total = 0, off = 0;
+  std::string why;
+  if (!bgzf_scan_range(file.data(), file.size(), off, ~0ull, blocks, total, why, 1)) throw bk_error(BK_ERR_IO, why);
+  uint32_t n_ref = 0, first_blk = 0, first_off = 0;
+  parse_bam_header(file.data(), blocks, false, h, n_ref, first_blk, first_off);
+  const uint32_t nblk = (uint32_t) blocks.size();
+  size_t free_b = 0, total_b = 0;
+  HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  if ((double) file.size() + (double) total * 1.3 + (double) bgzf_scratch_bytes(nblk) > 0.8 * (double) free_b)
+    throw bk_error(BK_ERR_LIMIT, "BAM with records across BGZF blocks is too large for the one-batch GPU decoder (use bk_bam_open / bk_bam_decode)");
+  DevBuf dfile, dblk, ddata, derr, dcnt, dnr, dnc, dna, dscan, dslab, dentry, dnext;
+  uint8_t *df = dfile.as<uint8_t>(file.size() + 8);
+  BgzfBlock *db = dblk.as<BgzfBlock>((uint64_t) nblk + 1);
+  uint8_t *dd = ddata.as<uint8_t>(total + 64);
+  uint32_t *de = derr.as<uint32_t>(1);
+  uint8_t *slab = dslab.as<uint8_t>(bgzf_scratch_bytes(nblk));
+  uint32_t *entry = dentry.as<uint32_t>((uint64_t) nblk + 1);
+  uint64_t *next_abs = dnext.as<uint64_t>((uint64_t) nblk + 1);
+  BlockCount *dc = dcnt.as<BlockCount>((uint64_t) nblk + 1);
+  uint64_t *nr = dnr.as<uint64_t>((uint64_t) nblk + 1), *nc = dnc.as<uint64_t>((uint64_t) nblk + 1), *na = dna.as<uint64_t>((uint64_t) nblk + 1);
+  hipStream_t st = nullptr;
+  HIP_CHECK(hipMemcpy(df, file.data(), file.size(), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(db, blocks.data(), (size_t) nblk * sizeof(BgzfBlock), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemset(de, 0, 4));
+  HIP_CHECK(hipMemset(dd + total, 0, 64));
+  launch_bgzf_inflate(df, db, nblk, dd, slab, de, st);
+  BamCols none = {};
+  hipLaunchKernelGGL(k_bam_guess, dim3(nblk), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, total, entry);
+  hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, 0ull, 0ull, 0ull, none, entry,
+                     total, next_abs);
+  hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nblk, 256)), dim3(256), 0, st, dc, nblk, nr, nc, na, de);
+  hipLaunchKernelGGL(k_bam_verify, dim3(cdiv(nblk, 256)), dim3(256), 0, st, db, nblk, first_blk, entry, next_abs, total, de);
+  prims::exclusive_scan<unsigned long long>((unsigned long long *) nr, (unsigned long long *) nr, nblk, dscan, st);
+  prims::exclusive_scan<unsigned long long>((unsigned long long *) nc, (unsigned long long *) nc, nblk, dscan, st);
+  prims::exclusive_scan<unsigned long long>((unsigned long long *) na, (unsigned long long *) na, nblk, dscan, st);
+  uint64_t tot[3] = {0, 0, 0};
+  uint32_t he = 0;
+  HIP_CHECK(hipMemcpyAsync(&tot[0], nr + nblk, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&tot[1], nc + nblk, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&tot[2], na + nblk, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&he, de, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (he & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
+  if (he & 2u) throw bk_error(BK_ERR_IO, "corrupt BAM record");
+  if (he & 4u) throw bk_error(BK_ERR_IO, "the record boundaries of this BAM could not be established on the GPU: use the host decoder");
+  const uint64_t n = tot[0];
+  if (n >= 0xFFFFFFF0ull || tot[1] >= 0xFFFFFFF0ull || tot[2] >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one BAM");
+  BamCols c;
+  c.tid = h->tid.as<int32_t>(n + 4);
+  c.pos = h->pos.as<int32_t>(n + 4);
+  c.mtid = h->mtid.as<int32_t>(n + 4);
+  c.mpos = h->mpos.as<int32_t>(n + 4);
+  c.isize = h->isize.as<int32_t>(n + 4);
+  c.flag = h->flag.as<uint16_t>(n + 4);
+  c.mapq = h->mapq.as<uint8_t>(n + 4);
+  c.qhash = h->qhash.as<uint64_t>(n + 4);
+  c.cigar_off = h->cigar_off.as<uint32_t>(n + 4);
+  c.aux_off = h->aux_off.as<uint32_t>(n + 4);
+  c.cigar = h->cigar.as<uint32_t>(tot[1] + 4);
+  c.aux = h->aux.as<uint8_t>(tot[2] + 4);
+  hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nr, nc, na, 0ull, 0ull, 0ull, c, entry, total, nullptr);
+  const uint32_t ends[2] = {(uint32_t) tot[1], (uint32_t) tot[2]};
+  HIP_CHECK(hipMemcpyAsync(c.cigar_off + n, &ends[0], 4, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(c.aux_off + n, &ends[1], 4, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  memset(cols, 0, sizeof *cols);
+  cols->n = n;
+  cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
+  cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
+  cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
+  cols->n_cigar_words = (uint32_t) tot[1];
+  cols->n_aux_bytes = (uint32_t) tot[2];
+  if (getenv("BREAKID_FEED_STATS"))
+    fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %u BGZF blocks, records across blocks (one batch, boundaries guessed and verified): file -> device table %.3f s\n",
+            (unsigned long long) n, file.size() / 1e6, nblk, now_s2() - t0);
+}
+
+// Does the first block of records end with a record?  (htslib never lets a record leave its block, htsjdk does; the
+// chunked decoder checks every block anyway, this only picks the path that is tried first.)
+static bool first_block_is_record_aligned(const MappedFile &file)
+{
+  try
+  {
+    std::vector<BgzfBlock> blocks;
+    uint64_t total = 0, off = 0;
+    std::string why;
+    if (!bgzf_scan_range(file.data(), file.size(), off, 4u << 20, blocks, total, why)) return true;
+    bk_bam_dev tmp;
+    uint32_t n_ref = 0, first_blk = 0, first_off = 0;
+    parse_bam_header(file.data(), blocks, true, &tmp, n_ref, first_blk, first_off);
+    if (first_blk >= blocks.size()) return true;
+    std::vector<uint8_t> d;
+    if (!host_inflate_block(file.data(), blocks[first_blk], d)) return true;
+    size_t p = first_off;
+    while (p + 4 <= d.size()) p += 4 + (size_t) rd32h(d.data() + p);
+    return p == d.size();
+  }
+  catch (const bk_error &)
+  {
+    return true;  // the decoder proper reports what is wrong with the file
+  }
+}
+
+extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
+                                    char *err, size_t errlen)
+{
+  bk_bam_dev *h = nullptr;
+  try
+  {
+    if (!path || !out || !cols) throw bk_error(BK_ERR_ARG, "bk_bam_decode_device: null argument");
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(device));
+    MappedFile file(path);  // mapped, not read: the header hop touches 18 bytes per block and the H2D copies stream the rest
+    h = new bk_bam_dev();
+    bool packed = !first_block_is_record_aligned(file);
+    if (!packed)
+    {
+      try
+      {
+        decode_chunked(file, device, h, cols);
+      }
+      catch (const not_block_aligned &)
+      {
+        HIP_CHECK(hipDeviceSynchronize());
+        delete h;
+        h = new bk_bam_dev();
+        packed = true;
+      }
+    }
+    if (packed) decode_packed(file, device, h, cols);
+    if (n_targets) *n_targets = (int) h->names.size();
+    if (names) *names = h->name_ptrs.data();
+    if (lens) *lens = h->lens.data();
     *out = h;
     return BK_OK;
   }

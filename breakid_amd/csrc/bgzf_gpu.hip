@@ -588,7 +588,17 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_bgzf_resolve(const BgzfBloc
     }
   }
   __syncthreads();
-  // four output bytes per thread and store (output offsets of blocks are multiples of 256)
+  if ((b.out_off & 3u) != 0)
+  {
+    // packed output (blocks at arbitrary offsets): only the copied bytes are written, one at a time
+    for (uint32_t p = t; p < n; p += RESOLVE_THREADS)
+    {
+      const uint32_t s = s_par[p];
+      if (s != p) o[p] = o[s];
+    }
+    return;
+  }
+  // four output bytes per thread and store
   const uint32_t n4 = n & ~3u;
   for (uint32_t p = 4 * t; p < n4; p += 4 * RESOLVE_THREADS)
   {

@@ -44,16 +44,26 @@ class Comm:
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
         self.host_staged = self.on and dist.get_backend(group) == "gloo"
+        self.before = None  # set by ShardedRun: waits for the library's own stream before a buffer of it is sent
 
     def _to_comm(self, t):
+        if self.before is not None:
+            self.before()
         return t.cpu() if self.host_staged else t
+
+    def _done(self, t):
+        """RCCL collectives are queued on the process group's own stream and only the current torch stream waits for
+        them; the library reads the result on ITS stream, so the host waits here (a few per step, microseconds each)."""
+        if not self.host_staged and t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        return t
 
     def all_reduce(self, t, op="sum"):
         if not self.on or self.world == 1:
             return t
         x = self._to_comm(t.contiguous())
         dist.all_reduce(x, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
-        return x.to(t.device)
+        return self._done(x.to(t.device))
 
     def all_gather_scalars(self, vals):
         """list of python ints -> int64 tensor [world, len(vals)] on the host."""
@@ -78,7 +88,7 @@ class Comm:
         x = self._to_comm(pad)
         out = [torch.empty_like(x) for _ in range(self.world)]
         dist.all_gather(out, x, group=self.group)
-        return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(t.device)
+        return self._done(torch.cat([o[:s] for o, s in zip(out, sizes)]).to(t.device))
 
 
     def all_to_all_var(self, t, send_bytes):
@@ -93,7 +103,7 @@ class Comm:
         x = self._to_comm(t[: sum(send_bytes)].contiguous())
         out = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=x.device)
         dist.all_to_all_single(out, x, output_split_sizes=recv_bytes, input_split_sizes=send_bytes, group=self.group)
-        return out.to(t.device)
+        return self._done(out.to(t.device))
 
 
 def lpt_owner(sizes, world):
@@ -116,6 +126,7 @@ class ShardedRun:
         self.ctx, self.comm = ctx, comm
         self.routed = routed  # False: the simpler replicated join (all-gather of every candidate to every rank)
         self._keep = []
+        comm.before = ctx.sync
 
     def _buffer(self, which):
         L, h = self.ctx.L, self.ctx.h

@@ -217,11 +217,13 @@ int bk_bam_header(const bk_bam *b, int *n_targets, const char *const **names, co
 int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen);
 void bk_bam_close(bk_bam *b);
 
-/* The same feed on the GPU: the file image goes to HBM, BGZF blocks are inflated one wavefront each (bgzf_gpu.hip) and
- * the records are decoded into device-resident columns (cols holds device pointers: bk_upload_records(ctx, cols,
- * BK_MEM_DEVICE)).  Needs a BAM whose records do not straddle BGZF blocks (every htslib / samtools file); others fail
- * with BK_ERR_IO and take bk_bam_open / bk_bam_decode.  The file is mapped and streamed in chunks
- * (BREAKID_FEED_CHUNK_MB, default 64-128 MiB, up to four in flight): device memory holds the chunks in flight and the columns. */
+/* The same feed on the GPU: BGZF blocks are inflated on the device (bgzf_gpu.hip) and the records are decoded into
+ * device-resident columns (cols holds device pointers: bk_upload_records(ctx, cols, BK_MEM_DEVICE)).
+ * Files whose records stay inside their BGZF blocks (htslib / samtools writers) are mapped and streamed in chunks
+ * (BREAKID_FEED_CHUNK_MB, default 64-128 MiB, up to four in flight): device memory holds the chunks in flight and the
+ * columns.  Files whose records run across blocks (htsjdk / Picard / GATK writers, long reads) are decoded in one batch:
+ * file image + inflated stream in HBM, record boundaries guessed per block and verified to chain; BK_ERR_LIMIT when that
+ * does not fit, BK_ERR_IO when the boundaries cannot be established - take bk_bam_open / bk_bam_decode then. */
 typedef struct bk_bam_dev bk_bam_dev;
 int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                          char *err, size_t errlen);

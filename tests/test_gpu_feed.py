@@ -67,14 +67,23 @@ def test_device_decode_matches_generator_and_pipeline():
     table.close()
 
 
-def test_device_decode_rejects_unaligned_blocks_and_takes_the_golden_shapes_when_aligned():
+def test_device_decode_of_records_across_blocks_and_of_the_golden_shapes():
     contigs, ds = _dataset()
+    ref = ds.to_soa()
     with tempfile.TemporaryDirectory() as t:
         p = os.path.join(t, "u.bam")
-        ds.write_bam(p)                 # fixed-size blocks: records straddle them
-        with pytest.raises(capi.BreakIDError) as e:
+        ds.write_bam(p)                 # fixed-size blocks: records straddle them (htsjdk / Picard style)
+        table = capi.decode_bam_device(p)   # one batch: record boundaries guessed per block, verified to chain
+        got = _device_cols(table)
+        assert table.contigs == contigs
+        for k, _ in abi.SOA_COLS:
+            assert np.array_equal(got[k], ref[k]), k
+        table.close()
+        # a cut in the middle of the stream / a file that is no BAM: an error, not a table
+        data = open(p, "rb").read()
+        open(p, "wb").write(data[: len(data) // 2])
+        with pytest.raises(capi.BreakIDError):
             capi.decode_bam_device(p)
-        assert e.value.code == abi.BK_ERR_IO and "aligned" in str(e.value)
         open(p, "wb").write(b"not a bam")
         with pytest.raises(capi.BreakIDError):
             capi.decode_bam_device(p)
@@ -85,6 +94,11 @@ def test_device_decode_rejects_unaligned_blocks_and_takes_the_golden_shapes_when
         with tempfile.TemporaryDirectory() as t:
             up = os.path.join(t, "u.bam")
             g.write_bam(up)
+            ut = capi.decode_bam_device(up)     # records across blocks
+            ugot = _device_cols(ut)
+            for k, _ in abi.SOA_COLS:
+                assert np.array_equal(ugot[k], ref[k]), (make.__name__, "across blocks", k)
+            ut.close()
             raw = b"".join(_inflate_blocks(open(up, "rb").read()))
             ap = os.path.join(t, "a.bam")
             _rewrite_aligned(raw, ap)
@@ -251,3 +265,30 @@ def test_device_decode_in_chunks_equals_one_chunk():
             for k, _ in abi.SOA_COLS:
                 assert np.array_equal(got[k], ref[k]), (mb, k)
             table.close()
+
+
+def test_device_decode_of_records_longer_than_a_block():
+    """long reads: a record spans several BGZF blocks, some blocks hold no record start at all"""
+    from breakid_amd import bamio
+    contigs = [("chr1", 3_000_000), ("chr2", 2_000_000)]
+    ds = synth.make_cfg(21, contigs, 600, 3, 6, 4, jitter=100, read_len=100)
+    ref = ds.to_soa()
+
+    def gen():
+        for i, r in enumerate(ds.recs):
+            aux = ([("SA", r.sa)] if r.sa else []) + ([("OC", r.oc)] if r.oc else [])
+            # every 7th record carries 150-300 kb of sequence + qualities (2 to 7 blocks), the others 0 to 400 bases
+            seq_len = 100_000 + 13_007 * (i % 11) if i % 7 == 3 else (i * 37) % 400
+            yield bamio.encode_record(r.qname, r.flag, r.tid, r.pos, r.mapq, bamio.parse_cigar(r.cigar), r.mtid, r.mpos, r.isize, aux, seq_len=seq_len)
+
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "long.bam")
+        bamio.write_bam(p, contigs, gen())
+        host_contigs, host_cols = capi.decode_bam(p)
+        table = capi.decode_bam_device(p)
+        got = _device_cols(table)
+        assert table.contigs == contigs == host_contigs
+        for k, _ in abi.SOA_COLS:
+            assert np.array_equal(got[k], ref[k]), k
+            assert np.array_equal(got[k], host_cols[k]), k
+        table.close()

@@ -102,3 +102,13 @@ if __name__ == "__main__":
         print("GPU decoder: file -> device table %.3f s = %.1f M records/s, %.0f MB/s of BAM; run %.1f ms" % (t1 - t0, n / (t1 - t0) / 1e6, comp / (t1 - t0) / 1e6, (t2 - t1) * 1e3), flush=True)
         ctx.close()
         table.close()
+    # the same records in fixed-size blocks (records across BGZF blocks, as htsjdk / Picard write them): one-batch variant
+    path2 = "/tmp/feed_%d_across.bam" % n_pairs
+    n2, raw2, comp2 = write_bam(path2, n_pairs, aligned=False)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        table = capi.decode_bam_device(path2)
+        t1 = time.perf_counter()
+        print("GPU decoder, records across blocks: file -> device table %.3f s = %.1f M records/s, %.0f MB/s of BAM" % (t1 - t0, n2 / (t1 - t0) / 1e6, comp2 / (t1 - t0) / 1e6), flush=True)
+        table.close()
