@@ -683,6 +683,31 @@ void parse_bam_header(const uint8_t *fdata, const std::vector<BgzfBlock> &blocks
   first_off = (uint32_t) (p - acc);
 }
 
+// The header of a mapped file, however many blocks it takes: reference list into h, and where the first record starts
+// (in_off of its block = absolute file offset of the block's deflate stream, offset inside the inflated block).
+void parse_bam_header_of_file(const uint8_t *file, uint64_t size, bk_bam_dev *h, uint32_t &n_ref, uint64_t &first_in_off, uint32_t &first_off)
+{
+  std::vector<BgzfBlock> blocks;
+  uint64_t total = 0, off = 0;
+  std::string why;
+  while (true)
+  {
+    if (!bgzf_scan_range(file, size, off, 1u << 20, blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+    uint32_t first_blk = 0;
+    try
+    {
+      parse_bam_header(file, blocks, off < size, h, n_ref, first_blk, first_off);
+    }
+    catch (const bk_error &e)
+    {
+      if (e.code == BK_ERR_LIMIT && off < size) continue;  // the header goes on in blocks not hopped over yet
+      throw;
+    }
+    first_in_off = first_blk < blocks.size() ? blocks[first_blk].in_off : ~0ull;  // ~0: no record at all
+    return;
+  }
+}
+
 struct not_block_aligned
 {
 };
@@ -746,9 +771,11 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
       HIP_CHECK(hipHostMalloc((void **) &s.tot, 4 * sizeof(uint64_t), hipHostMallocDefault));
     }
+    uint64_t first_in_off = 0;
+    uint32_t hdr_first_off = 0, n_ref = 0;
+    parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, hdr_first_off);
     StagePool pool(file.data(), file.size(), chunk_bytes, copy_threads, device);
     uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
-    uint32_t n_ref = 0;
     double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0;
     std::string why;
     BamCols c = {};
@@ -801,7 +828,6 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     };
     // chunk k -> slot: hop over the block headers in the staged bytes, copy, inflate, count
     auto stage = [&](FeedSlot &s, uint64_t k) {
-      const bool first = k == 0;
       if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
       s.used = true;
       s.blocks.clear();
@@ -817,7 +843,9 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       uint64_t total = 0, rel = off - src_lo;
       if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
       off = src_lo + rel;
-      if (first) parse_bam_header(fdata, s.blocks, off < file.size(), h, n_ref, s.first_blk, s.first_off);
+      // blocks of the header hold no records; the first record's block starts at first_off
+      while (s.first_blk < s.blocks.size() && src_lo + s.blocks[s.first_blk].in_off < first_in_off) ++s.first_blk;
+      if (s.first_blk < s.blocks.size() && src_lo + s.blocks[s.first_blk].in_off == first_in_off) s.first_off = hdr_first_off;
       const uint32_t nb = (uint32_t) s.blocks.size();
       nblk_all += nb;
       if (nb == 0)
@@ -927,8 +955,10 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
   std::string why;
   if (!bgzf_scan_range(file.data(), file.size(), off, ~0ull, blocks, total, why, 1)) throw bk_error(BK_ERR_IO, why);
   uint32_t n_ref = 0, first_blk = 0, first_off = 0;
-  parse_bam_header(file.data(), blocks, false, h, n_ref, first_blk, first_off);
+  uint64_t first_in_off = 0;
+  parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, first_off);
   const uint32_t nblk = (uint32_t) blocks.size();
+  while (first_blk < nblk && blocks[first_blk].in_off < first_in_off) ++first_blk;
   size_t free_b = 0, total_b = 0;
   HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
   if ((double) file.size() + (double) total * 1.3 + (double) bgzf_scratch_bytes(nblk) > 0.8 * (double) free_b)
@@ -1006,16 +1036,18 @@ static bool first_block_is_record_aligned(const MappedFile &file)
 {
   try
   {
-    std::vector<BgzfBlock> blocks;
-    uint64_t total = 0, off = 0;
-    std::string why;
-    if (!bgzf_scan_range(file.data(), file.size(), off, 4u << 20, blocks, total, why)) return true;
     bk_bam_dev tmp;
-    uint32_t n_ref = 0, first_blk = 0, first_off = 0;
-    parse_bam_header(file.data(), blocks, true, &tmp, n_ref, first_blk, first_off);
-    if (first_blk >= blocks.size()) return true;
+    uint32_t n_ref = 0, first_off = 0;
+    uint64_t first_in_off = 0;
+    parse_bam_header_of_file(file.data(), file.size(), &tmp, n_ref, first_in_off, first_off);
+    if (first_in_off == ~0ull) return true;
+    // the BGZF block whose deflate stream starts at first_in_off: its header ends there (12 + XLEN bytes: 18 for BGZF)
+    std::vector<BgzfBlock> blocks;
+    uint64_t total = 0, off = first_in_off - 18;
+    std::string why;
+    if (first_in_off < 18 || !bgzf_scan_range(file.data(), file.size(), off, 1, blocks, total, why) || blocks.empty() || blocks[0].in_off != first_in_off) return true;
     std::vector<uint8_t> d;
-    if (!host_inflate_block(file.data(), blocks[first_blk], d)) return true;
+    if (!host_inflate_block(file.data(), blocks[0], d)) return true;
     size_t p = first_off;
     while (p + 4 <= d.size()) p += 4 + (size_t) rd32h(d.data() + p);
     return p == d.size();

@@ -21,6 +21,8 @@
 #include "bk_common.h"
 #include "prims.h"
 #include "sortemu.h"
+#include <vector>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
@@ -1318,6 +1320,39 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     if (nh)
     {
       const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
+      if (getenv("BK_DEBUG_SORT_TIES"))
+      {
+        // how many equal keys do the big heap segments hold?  (debugging aid)
+        std::vector<HeapSeg> hh(nh);
+        HIP_CHECK(hipMemcpy(hh.data(), hl, (size_t) nh * sizeof(HeapSeg), hipMemcpyDeviceToHost));
+        for (const HeapSeg &g : hh)
+        {
+          const uint32_t m = g.last - g.first;
+          if (m < 16384) continue;
+          std::vector<uint32_t> kk(m);
+          HIP_CHECK(hipMemcpy(kk.data(), key + g.first, (size_t) m * 4, hipMemcpyDeviceToHost));
+          uint32_t inv = 0;
+          for (uint32_t i = 1; i < m; ++i) inv += kk[i] < kk[i - 1];
+          std::sort(kk.begin(), kk.end());
+          uint32_t distinct = 1, in_ties = 0, maxrun = 1, run = 1;
+          for (uint32_t i = 1; i < m; ++i)
+          {
+            if (kk[i] == kk[i - 1])
+            {
+              ++run;
+              if (run == 2) in_ties += 2; else ++in_ties;
+              if (run > maxrun) maxrun = run;
+            }
+            else
+            {
+              ++distinct;
+              run = 1;
+            }
+          }
+          fprintf(stderr, "[sortemu]   heap segment of %u: %u distinct keys, %u elements in tie groups (largest %u), key range %u..%u, %u descents in arrival order\n", m, distinct, in_ties, maxrun,
+                  kk.front(), kk.back(), inv);
+        }
+      }
       hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
       static const bool use_asm = getenv("BK_HEAP_CXX") == nullptr;  // BK_HEAP_CXX=1: the C++ statement of the pop loop (debugging)
       static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
