@@ -1229,6 +1229,33 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   if (n64 > 0x7FFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: more than 2^31 pairs");
   const uint32_t n = (uint32_t) n64;
   unsigned long long *cnt = b.cnt.as<unsigned long long>((uint64_t) (n / 8 + ng) + 32);
+  if (const char *dump = getenv("BK_DEBUG_SORT_DUMP"))
+  {
+    // keys and group offsets as they arrive at this sort (debugging aid): <dump>.<call>.keys.u32 / .goff.u64, first 5 calls
+    static int call = 0;
+    if (call < 5)
+    {
+      std::vector<uint64_t> go((size_t) ng + 1);
+      std::vector<uint32_t> kk(n);
+      HIP_CHECK(hipStreamSynchronize(st));
+      HIP_CHECK(hipMemcpy(go.data(), goff, ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(kk.data(), key, (size_t) n * 4, hipMemcpyDeviceToHost));
+      char name[512];
+      snprintf(name, sizeof name, "%s.%d.keys.u32", dump, call);
+      if (FILE *f = fopen(name, "wb"))
+      {
+        fwrite(kk.data(), 4, kk.size(), f);
+        fclose(f);
+      }
+      snprintf(name, sizeof name, "%s.%d.goff.u64", dump, call);
+      if (FILE *f = fopen(name, "wb"))
+      {
+        fwrite(go.data(), 8, go.size(), f);
+        fclose(f);
+      }
+    }
+    ++call;
+  }
   uint32_t *err = b.err.as<uint32_t>(4);
   HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
   // level 0 segments = groups larger than 16
