@@ -1,5 +1,8 @@
+"""Run time of the hot path when the discordant pairs fall into few, large chr-pair groups (GPU box).
+usage: gpu_biggroup.py <records> <number of hg19 contigs>; BK_DEBUG_SORT=1 prints the sort emulation's per-sort statistics,
+BK_DEBUG_SORT_DUMP=<prefix> writes the keys and group offsets of the first five sorts."""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from breakid_amd import abi, capi, synth_gpu
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]); nc = int(sys.argv[2])
