@@ -242,10 +242,11 @@ __device__ __forceinline__ uint64_t qname_hash_dev(const uint8_t *name, uint32_t
 // Aligned files (entry == nullptr): every block starts with a record and no record leaves its block.  Packed mode
 // (entry != nullptr, the inflated stream is contiguous, `total` bytes): the lane of block b takes the records that START
 // in b, from entry[b] (the block's size = none), wherever they end; next_abs[b] = stream offset where its walk stopped.
+// allow_tail: a record that does not fit the stream is not an error but the end of the walk (the next chunk starts with it).
 template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk,
                                                                          uint32_t first_off, int32_t n_ref, BlockCount *__restrict__ cnt, const uint64_t *__restrict__ rec_base,
                                                                          const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, uint64_t rec0, uint64_t cig0, uint64_t aux0, BamCols c,
-                                                                         const uint32_t *__restrict__ entry = nullptr, uint64_t total = 0, uint64_t *__restrict__ next_abs = nullptr)
+                                                                         const uint32_t *__restrict__ entry = nullptr, uint64_t total = 0, uint64_t *__restrict__ next_abs = nullptr, int allow_tail = 0)
 {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
@@ -263,14 +264,14 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
     {
       if (p + 36 > room)
       {
-        bc.bad = 1;
+        bc.bad = allow_tail ? 0 : 1;  // allow_tail: the stream goes on in the next chunk, this record is its first
         break;
       }
       const uint32_t bs = ld32(d + p);
       const uint8_t *r = d + p + 4;
       if (bs < 32 || p + 4 + bs > room)
       {
-        bc.bad = 1;  // a record that continues in the next block (aligned mode), or garbage
+        bc.bad = (allow_tail && bs >= 32) ? 0 : 1;  // a record that continues in the next block (aligned mode), or garbage
         break;
       }
       const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
@@ -390,14 +391,27 @@ __global__ __launch_bounds__(64) void k_bam_guess(const uint8_t *__restrict__ da
 // next block that has one (the first entry is the known first record, the last walk stops at the end of the stream).
 // By induction from the first record every entry then IS a record boundary.
 __global__ void k_bam_verify(const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk, const uint32_t *__restrict__ entry, const uint64_t *__restrict__ next_abs, uint64_t total,
-                             uint32_t *__restrict__ err)
+                             uint32_t *__restrict__ err, int allow_tail = 0, unsigned long long *__restrict__ tail_out = nullptr)
 {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk || b < first_blk || entry[b] >= blk[b].isize) return;
   uint32_t nb = b + 1;
   while (nb < nblk && entry[nb] >= blk[nb].isize) ++nb;
-  const uint64_t want = nb < nblk ? blk[nb].out_off + entry[nb] : total;
-  if (next_abs[b] != want) atomicOr(err, 4u);
+  if (nb < nblk)
+  {
+    if (next_abs[b] != blk[nb].out_off + entry[nb]) atomicOr(err, 4u);
+  }
+  else if (allow_tail)
+  {
+    // the last walk of a chunk stops at the record that continues in the next chunk (or at the end of the stream)
+    if (next_abs[b] > total) atomicOr(err, 4u);
+    if (tail_out) *tail_out = next_abs[b];
+  }
+  else
+  {
+    if (next_abs[b] != total) atomicOr(err, 4u);
+    if (tail_out) *tail_out = next_abs[b];
+  }
 }
 }  // namespace
 
@@ -1030,6 +1044,250 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
             (unsigned long long) n, file.size() / 1e6, nblk, now_s2() - t0);
 }
 
+// Growing device columns of the record table.
+struct ColumnSink
+{
+  bk_bam_dev *h;
+  BamCols c = {};
+  uint64_t n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0;
+  // room for (r, g, a) records / CIGAR words / aux bytes; `quiesce` must wait for every kernel that writes the columns
+  template <class F> void reserve(uint64_t r, uint64_t g, uint64_t a, F quiesce)
+  {
+    if (r <= cap_rec && g <= cap_cig && a <= cap_aux) return;
+    quiesce();
+    if (r > cap_rec)
+    {
+      const uint64_t nc = std::max(r, cap_rec + cap_rec / 2) + 1024;
+      for (DevBuf *b : {&h->tid, &h->pos, &h->mtid, &h->mpos, &h->isize, &h->cigar_off, &h->aux_off}) grow_keep(*b, n_rec * 4, (nc + 4) * 4);
+      grow_keep(h->flag, n_rec * 2, (nc + 4) * 2);
+      grow_keep(h->mapq, n_rec, nc + 4);
+      grow_keep(h->qhash, n_rec * 8, (nc + 4) * 8);
+      cap_rec = nc;
+    }
+    if (g > cap_cig)
+    {
+      const uint64_t nc = std::max(g, cap_cig + cap_cig / 2) + 1024;
+      grow_keep(h->cigar, n_cig * 4, (nc + 4) * 4);
+      cap_cig = nc;
+    }
+    if (a > cap_aux)
+    {
+      const uint64_t nc = std::max(a, cap_aux + cap_aux / 2) + 1024;
+      grow_keep(h->aux, n_aux, nc + 4);
+      cap_aux = nc;
+    }
+    c.tid = h->tid.get<int32_t>();
+    c.pos = h->pos.get<int32_t>();
+    c.mtid = h->mtid.get<int32_t>();
+    c.mpos = h->mpos.get<int32_t>();
+    c.isize = h->isize.get<int32_t>();
+    c.flag = h->flag.get<uint16_t>();
+    c.mapq = h->mapq.get<uint8_t>();
+    c.qhash = h->qhash.get<uint64_t>();
+    c.cigar_off = h->cigar_off.get<uint32_t>();
+    c.aux_off = h->aux_off.get<uint32_t>();
+    c.cigar = h->cigar.get<uint32_t>();
+    c.aux = h->aux.get<uint8_t>();
+  }
+  void finish(bk_soa *cols)
+  {
+    const uint32_t ends[2] = {(uint32_t) n_cig, (uint32_t) n_aux};
+    HIP_CHECK(hipMemcpy(c.cigar_off + n_rec, &ends[0], 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c.aux_off + n_rec, &ends[1], 4, hipMemcpyHostToDevice));
+    memset(cols, 0, sizeof *cols);
+    cols->n = n_rec;
+    cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
+    cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
+    cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
+    cols->n_cigar_words = (uint32_t) n_cig;
+    cols->n_aux_bytes = (uint32_t) n_aux;
+  }
+};
+
+// Records across BGZF blocks, file too large for one batch: the file is taken in chunks like the aligned case, every
+// chunk is inflated into a contiguous stream behind PACKED_RESERVE free bytes.  The walk of a chunk ends at the record
+// that does not fit any more; its bytes (the "carry") are copied in front of the next chunk's stream, whose first block is
+// extended backwards over them - so every chunk starts at a KNOWN record boundary, the other blocks guess theirs and
+// the chain is verified per chunk exactly as in the one-batch variant.  The record phase of chunk c + 1 therefore waits
+// for the totals of chunk c; its H2D copy and inflate do not.
+constexpr uint64_t PACKED_RESERVE = 8u << 20;  // longest record that may cross a chunk boundary
+
+struct PackedSlot
+{
+  DevBuf dfile, dblk, dblk2, ddata, dslab, dcnt, dnr, dnc, dna, dscan, derr, dentry, dnext, dtail;
+  hipStream_t st = nullptr;
+  hipEvent_t ev_emit = nullptr;
+  uint64_t *tot = nullptr;  // pinned: records, CIGAR words, aux bytes, error flags, tail
+  std::vector<BgzfBlock> blocks, blocks2;  // as inflated; as walked (first block extended over the carry)
+  uint64_t total = 0;       // bytes of the chunk's inflated stream
+  uint64_t file_hi = 0;     // file offset behind the chunk
+  uint32_t first_blk = 0, first_off = 0;
+  bool used = false;
+  ~PackedSlot()
+  {
+    if (st) (void) hipStreamDestroy(st);
+    if (ev_emit) (void) hipEventDestroy(ev_emit);
+    if (tot) (void) hipHostFree(tot);
+  }
+};
+
+static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols)
+{
+  (void) device;
+  const double t0 = now_s2();
+  uint64_t chunk_bytes = 64ull << 20;
+  if (const char *e = getenv("BREAKID_FEED_CHUNK_MB"))
+    if (atof(e) > 0) chunk_bytes = (uint64_t) (atof(e) * 1048576.0);
+  chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000);
+  constexpr int NS = 3;
+  PackedSlot slot[NS];
+  for (auto &s : slot)
+  {
+    HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc((void **) &s.tot, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  }
+  hipEvent_t ev_carry;
+  HIP_CHECK(hipEventCreateWithFlags(&ev_carry, hipEventDisableTiming));
+  struct EvGuard
+  {
+    hipEvent_t e;
+    ~EvGuard() { (void) hipEventDestroy(e); }
+  } evg{ev_carry};
+  DevBuf dcarry;
+  uint8_t *carry = dcarry.as<uint8_t>(PACKED_RESERVE);
+  uint64_t carry_len = 0, first_in_off = 0, off = 0, nblk_all = 0, nchunk = 0;
+  uint32_t hdr_first_off = 0, n_ref = 0;
+  parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, hdr_first_off);
+  ColumnSink sink{h};
+  std::string why;
+  auto quiesce = [&]() {
+    for (auto &s : slot) HIP_CHECK(hipStreamSynchronize(s.st));
+  };
+  // chunk -> slot: hop over its block headers, copy, inflate behind the reserve
+  auto stage = [&](PackedSlot &s) {
+    if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
+    s.used = true;
+    s.blocks.clear();
+    s.total = 0;
+    s.first_blk = 0;
+    s.first_off = 0;
+    const uint64_t lo = off;
+    if (!bgzf_scan_range(file.data(), file.size(), off, chunk_bytes, s.blocks, s.total, why, 1)) throw bk_error(BK_ERR_IO, why);
+    const uint32_t nb = (uint32_t) s.blocks.size();
+    nblk_all += nb;
+    while (s.first_blk < nb && s.blocks[s.first_blk].in_off < first_in_off) ++s.first_blk;
+    if (s.first_blk < nb && s.blocks[s.first_blk].in_off == first_in_off) s.first_off = hdr_first_off;
+    for (auto &b : s.blocks)
+    {
+      b.in_off -= lo;
+      b.out_off += PACKED_RESERVE;
+    }
+    uint8_t *df = s.dfile.as<uint8_t>(off - lo + 8);
+    BgzfBlock *db = s.dblk.as<BgzfBlock>((uint64_t) nb + 1);
+    uint8_t *dd = s.ddata.as<uint8_t>(PACKED_RESERVE + s.total + 64);
+    uint32_t *de = s.derr.as<uint32_t>(1);
+    uint8_t *slab = s.dslab.as<uint8_t>(bgzf_scratch_bytes(nb));
+    HIP_CHECK(hipMemcpyAsync(df, file.data() + lo, off - lo, hipMemcpyHostToDevice, s.st));
+    HIP_CHECK(hipMemcpyAsync(db, s.blocks.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
+    HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
+    HIP_CHECK(hipMemsetAsync(dd + PACKED_RESERVE + s.total, 0, 64, s.st));
+    launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st);
+    s.file_hi = off;
+  };
+  // the carry of the chunk before is known: boundaries, counts and totals of this chunk
+  auto records = [&](PackedSlot &s, bool last) {
+    const uint32_t nb = (uint32_t) s.blocks.size();
+    if (nb == 0) return;
+    uint8_t *dd = s.ddata.get<uint8_t>();
+    std::vector<BgzfBlock> &b2 = s.blocks2;
+    b2 = s.blocks;
+    // the block that holds the first record is extended backwards over the carried bytes
+    if (carry_len)
+    {
+      if (s.first_blk >= nb) throw bk_error(BK_ERR_IO, "corrupt BAM record");
+      HIP_CHECK(hipStreamWaitEvent(s.st, ev_carry, 0));
+      HIP_CHECK(hipMemcpyAsync(dd + PACKED_RESERVE - carry_len, carry, carry_len, hipMemcpyDeviceToDevice, s.st));
+      // blocks before it hold no record starts (they are empty: isize 0)
+      b2[s.first_blk].out_off -= carry_len;
+      b2[s.first_blk].isize += (uint32_t) carry_len;
+    }
+    BgzfBlock *db2 = s.dblk2.as<BgzfBlock>((uint64_t) nb + 1);
+    HIP_CHECK(hipMemcpyAsync(db2, b2.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
+    const uint64_t total = PACKED_RESERVE + s.total;
+    uint32_t *de = s.derr.get<uint32_t>();
+    uint32_t *entry = s.dentry.as<uint32_t>((uint64_t) nb + 1);
+    uint64_t *next_abs = s.dnext.as<uint64_t>((uint64_t) nb + 1);
+    unsigned long long *tail = s.dtail.as<unsigned long long>(1);
+    BlockCount *dc = s.dcnt.as<BlockCount>((uint64_t) nb + 1);
+    uint64_t *nr = s.dnr.as<uint64_t>((uint64_t) nb + 1), *nc = s.dnc.as<uint64_t>((uint64_t) nb + 1), *na = s.dna.as<uint64_t>((uint64_t) nb + 1);
+    s.tot[5] = total;  // (no record starts in the chunk: nothing to carry)
+    HIP_CHECK(hipMemcpyAsync(tail, &s.tot[5], 8, hipMemcpyHostToDevice, s.st));
+    BamCols none = {};
+    hipLaunchKernelGGL(k_bam_guess, dim3(nb), dim3(64), 0, s.st, dd, db2, nb, s.first_blk, s.first_off, (int32_t) n_ref, total, entry);
+    hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, dd, db2, nb, s.first_blk, s.first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, 0ull, 0ull, 0ull, none,
+                       entry, total, next_abs, last ? 0 : 1);
+    hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nb, 256)), dim3(256), 0, s.st, dc, nb, nr, nc, na, de);
+    hipLaunchKernelGGL(k_bam_verify, dim3(cdiv(nb, 256)), dim3(256), 0, s.st, db2, nb, s.first_blk, entry, next_abs, total, de, last ? 0 : 1, tail);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) nr, (unsigned long long *) nr, nb, s.dscan, s.st);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) nc, (unsigned long long *) nc, nb, s.dscan, s.st);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) na, (unsigned long long *) na, nb, s.dscan, s.st);
+    s.tot[3] = 0;
+    HIP_CHECK(hipMemcpyAsync(&s.tot[0], nr + nb, 8, hipMemcpyDeviceToHost, s.st));
+    HIP_CHECK(hipMemcpyAsync(&s.tot[1], nc + nb, 8, hipMemcpyDeviceToHost, s.st));
+    HIP_CHECK(hipMemcpyAsync(&s.tot[2], na + nb, 8, hipMemcpyDeviceToHost, s.st));
+    HIP_CHECK(hipMemcpyAsync(&s.tot[3], de, 4, hipMemcpyDeviceToHost, s.st));
+    HIP_CHECK(hipMemcpyAsync(&s.tot[4], tail, 8, hipMemcpyDeviceToHost, s.st));
+    HIP_CHECK(hipStreamSynchronize(s.st));
+    if (s.tot[3] & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
+    if (s.tot[3] & 2u) throw bk_error(BK_ERR_IO, "corrupt BAM record");
+    if (s.tot[3] & 4u) throw bk_error(BK_ERR_IO, "the record boundaries of this BAM could not be established on the GPU: use the host decoder");
+    // what is left of the stream behind the last complete record travels to the next chunk
+    const uint64_t new_carry = total - s.tot[4];
+    if (new_carry > PACKED_RESERVE) throw bk_error(BK_ERR_LIMIT, "a BAM record longer than 8 MiB crosses a feed chunk: use the host decoder");
+    if (last && new_carry) throw bk_error(BK_ERR_IO, "truncated BAM record at the end of the file");
+    if (new_carry)
+    {
+      HIP_CHECK(hipMemcpyAsync(carry, dd + s.tot[4], new_carry, hipMemcpyDeviceToDevice, s.st));
+      HIP_CHECK(hipEventRecord(ev_carry, s.st));
+    }
+    carry_len = new_carry;
+    const uint64_t r = sink.n_rec + s.tot[0], g = sink.n_cig + s.tot[1], a = sink.n_aux + s.tot[2];
+    if (r >= 0xFFFFFFF0ull || g >= 0xFFFFFFF0ull || a >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one BAM");
+    if (sink.cap_rec == 0 && !last)
+    {
+      const double scale = 1.05 * (double) file.size() / (double) std::max<uint64_t>(s.file_hi, 1);
+      sink.reserve((uint64_t) (r * scale), (uint64_t) (g * scale), (uint64_t) (a * scale), quiesce);
+    }
+    sink.reserve(r, g, a, quiesce);
+    hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, dd, db2, nb, s.first_blk, s.first_off, (int32_t) n_ref, dc, nr, nc, na, sink.n_rec, sink.n_cig, sink.n_aux, sink.c,
+                       entry, total, nullptr, last ? 0 : 1);
+    HIP_CHECK(hipEventRecord(s.ev_emit, s.st));
+    sink.n_rec = r;
+    sink.n_cig = g;
+    sink.n_aux = a;
+  };
+  // the inflate of chunk c + 1 is queued before the host waits for the totals of chunk c
+  bool have = false;
+  int cur = 0;
+  while (off < file.size())
+  {
+    const int nxt = (int) (nchunk % NS);
+    stage(slot[nxt]);
+    ++nchunk;
+    if (have) records(slot[cur], false);
+    cur = nxt;
+    have = true;
+  }
+  if (have) records(slot[cur], true);
+  sink.reserve(sink.n_rec, sink.n_cig, sink.n_aux, quiesce);
+  quiesce();
+  sink.finish(cols);
+  if (getenv("BREAKID_FEED_STATS"))
+    fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks, records across blocks (boundaries guessed and verified per chunk): file -> device table %.3f s\n",
+            (unsigned long long) sink.n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, now_s2() - t0);
+}
+
 // Does the first block of records end with a record?  (htslib never lets a record leave its block, htsjdk does; the
 // chunked decoder checks every block anyway, this only picks the path that is tried first.)
 static bool first_block_is_record_aligned(const MappedFile &file)
@@ -1084,7 +1342,27 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
         packed = true;
       }
     }
-    if (packed) decode_packed(file, device, h, cols);
+    if (packed)
+    {
+      // one batch when file image + inflated stream fit in HBM (BREAKID_FEED_PACKED_CHUNKS=1: always in chunks)
+      bool in_chunks = getenv("BREAKID_FEED_PACKED_CHUNKS") != nullptr;
+      if (!in_chunks)
+      {
+        try
+        {
+          decode_packed(file, device, h, cols);
+        }
+        catch (const bk_error &e)
+        {
+          if (e.code != BK_ERR_LIMIT) throw;
+          HIP_CHECK(hipDeviceSynchronize());
+          delete h;
+          h = new bk_bam_dev();
+          in_chunks = true;
+        }
+      }
+      if (in_chunks) decode_packed_chunked(file, device, h, cols);
+    }
     if (n_targets) *n_targets = (int) h->names.size();
     if (names) *names = h->name_ptrs.data();
     if (lens) *lens = h->lens.data();

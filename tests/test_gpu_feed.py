@@ -292,3 +292,42 @@ def test_device_decode_of_records_longer_than_a_block():
             assert np.array_equal(got[k], ref[k]), k
             assert np.array_equal(got[k], host_cols[k]), k
         table.close()
+
+
+def test_device_decode_of_records_across_blocks_in_chunks():
+    """the variant for files too large for one batch: chunks start at the record carried over from the chunk before;
+    short records, records of 100-230 kB (2-7 blocks) and chunks of a few blocks"""
+    from breakid_amd import bamio
+    contigs = [("chr1", 3_000_000), ("chr2", 2_000_000)]
+    ds = synth.make_cfg(23, contigs, 3000, 4, 8, 6, jitter=100, read_len=100)
+    for i in range(0, len(ds.recs), 97):
+        ds.recs[i].sa = "chr2,%d,+,40S60M,60,0;" % (100 + i)
+    ref = ds.to_soa()
+    rng = np.random.default_rng(4)
+
+    def gen(long_every):
+        for i, r in enumerate(ds.recs):
+            aux = ([("SA", r.sa)] if r.sa else []) + ([("OC", r.oc)] if r.oc else [])
+            seq_len = 100_000 + 13_007 * (i % 11) if long_every and i % long_every == 3 else (i * 37) % 400
+            rec = bytearray(bamio.encode_record(r.qname, r.flag, r.tid, r.pos, r.mapq, bamio.parse_cigar(r.cigar), r.mtid, r.mpos, r.isize, aux, seq_len=seq_len))
+            if seq_len:   # incompressible bases / qualities: chunks of a few blocks really are a few blocks
+                at = len(rec) - sum(3 + len(v) + 1 for _, v in aux) - ((seq_len + 1) // 2 + seq_len)
+                rec[at:at + (seq_len + 1) // 2 + seq_len] = rng.integers(0, 256, (seq_len + 1) // 2 + seq_len, dtype=np.uint8).tobytes()
+            yield bytes(rec)
+
+    os.environ["BREAKID_FEED_PACKED_CHUNKS"] = "1"
+    try:
+        for long_every, mb in ((0, 0.07), (0, 0.3), (29, 0.07), (29, 0.5), (7, 1.0)):
+            with tempfile.TemporaryDirectory() as t:
+                p = os.path.join(t, "x.bam")
+                bamio.write_bam(p, contigs, gen(long_every))
+                os.environ["BREAKID_FEED_CHUNK_MB"] = repr(mb)
+                table = capi.decode_bam_device(p)
+                got = _device_cols(table)
+                assert table.contigs == contigs
+                for k, _ in abi.SOA_COLS:
+                    assert np.array_equal(got[k], ref[k]), (long_every, mb, k)
+                table.close()
+    finally:
+        os.environ.pop("BREAKID_FEED_PACKED_CHUNKS", None)
+        os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
