@@ -1273,7 +1273,6 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   size_t max_segs = (size_t) n / 8 + ng + 16;
   Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
   uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
-  const uint32_t ns_initial = ns;
   if (ns)
   {
     hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs);
@@ -1316,172 +1315,183 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
-  // segments of at most FIN_MAX elements: the rest of their introsort loop in LDS, one workgroup each
+  // What is left: (1) segments of at most FIN_MAX elements - the rest of their introsort loop runs in LDS, one workgroup
+  // each (the finisher; it may add small segments to the heap list) - and (2) the segments that exhausted introsort's
+  // depth limit in the level loop, which are heapsorted (they are final: no children).  The longest heap segment is the
+  // critical path of the whole sort, so the big heaps are started first, on side streams, and the finisher runs beside them.
   uint32_t nfin2[2] = {0, 0};
+  uint32_t e[4] = {0, 0, 0, 0};
   HIP_CHECK(hipMemcpyAsync(nfin2, fin, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   const uint32_t nfin = nfin2[0] + nfin2[1];
-  static const bool dbg_fin = getenv("BK_DEBUG_SORT") != nullptr;
-  double t_fin0 = 0;
-  if (dbg_fin) t_fin0 = now_ms();
-  if (nfin2[1]) hipLaunchKernelGGL((k_se_finish<FIN_MAX, 256>), dim3(nfin2[1]), dim3(256), 0, st, fin_list + (fin_cap - 1), nfin2[1], -1, key, idx, err, heap_list);
-  if (dbg_fin)
+  const uint32_t nh1 = e[3], max1 = e[1];  // heap segments of the level loop
+  const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
+  static const bool use_asm = getenv("BK_HEAP_CXX") == nullptr;  // BK_HEAP_CXX=1: the C++ statement of the pop loop (debugging)
+  static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
+  const size_t dyn = (HEAP_LARGE + HEAP_PAD) * 8;
+  hent *hscratch = nullptr;
+  const uint32_t *rank32 = nullptr;
+  uint32_t *scratch32 = nullptr;
+  int used = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (dbg)
   {
-    HIP_CHECK(hipStreamSynchronize(st));
-    fprintf(stderr, "[sortemu] finisher: %u segments of 257..%u elements %.3f ms", nfin2[1], FIN_MAX, now_ms() - t_fin0);
-    t_fin0 = now_ms();
+    HIP_CHECK(hipEventCreate(&ev0));
+    HIP_CHECK(hipEventCreate(&ev1));
+    HIP_CHECK(hipEventRecord(ev0, st));
   }
-  if (nfin2[0]) hipLaunchKernelGGL((k_se_finish<FIN_SMALL, 64>), dim3(nfin2[0]), dim3(64), 0, st, fin_list, nfin2[0], 1, key, idx, err, heap_list);
-  if (dbg_fin)
+  if (nh1 || nfin)
   {
-    HIP_CHECK(hipStreamSynchronize(st));
-    fprintf(stderr, ", %u segments of 17..%u elements %.3f ms\n", nfin2[0], FIN_SMALL, now_ms() - t_fin0);
-  }
-  if (ns_initial || nfin)
-  {
-    // segments that exhausted introsort's depth limit are heapsorted now (they are final: no children)
-    uint32_t e[4] = {0, 0, 0, 0};
-    HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    const uint32_t nh = e[3];
-    if (nh)
+    hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
+    if (!b.fork)
     {
-      const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
-      if (getenv("BK_DEBUG_SORT_TIES"))
+      HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
+      for (int i = 0; i < SortEmuBufs::N_AUX; ++i)
       {
-        // how many equal keys do the big heap segments hold?  (debugging aid)
-        std::vector<HeapSeg> hh(nh);
-        HIP_CHECK(hipMemcpy(hh.data(), hl, (size_t) nh * sizeof(HeapSeg), hipMemcpyDeviceToHost));
-        for (const HeapSeg &g : hh)
-        {
-          const uint32_t m = g.last - g.first;
-          if (m < 16384) continue;
-          std::vector<uint32_t> kk(m);
-          HIP_CHECK(hipMemcpy(kk.data(), key + g.first, (size_t) m * 4, hipMemcpyDeviceToHost));
-          uint32_t inv = 0;
-          for (uint32_t i = 1; i < m; ++i) inv += kk[i] < kk[i - 1];
-          std::sort(kk.begin(), kk.end());
-          uint32_t distinct = 1, in_ties = 0, maxrun = 1, run = 1;
-          for (uint32_t i = 1; i < m; ++i)
-          {
-            if (kk[i] == kk[i - 1])
-            {
-              ++run;
-              if (run == 2) in_ties += 2; else ++in_ties;
-              if (run > maxrun) maxrun = run;
-            }
-            else
-            {
-              ++distinct;
-              run = 1;
-            }
-          }
-          fprintf(stderr, "[sortemu]   heap segment of %u: %u distinct keys, %u elements in tie groups (largest %u), key range %u..%u, %u descents in arrival order\n", m, distinct, in_ties, maxrun,
-                  kk.front(), kk.back(), inv);
-        }
-      }
-      hent *hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
-      static const bool use_asm = getenv("BK_HEAP_CXX") == nullptr;  // BK_HEAP_CXX=1: the C++ statement of the pop loop (debugging)
-      static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
-      hipEvent_t ev0 = nullptr, ev1 = nullptr;
-      if (dbg)
-      {
-        HIP_CHECK(hipEventCreate(&ev0));
-        HIP_CHECK(hipEventCreate(&ev1));
-        HIP_CHECK(hipEventRecord(ev0, st));
-      }
-      const size_t dyn = (HEAP_LARGE + HEAP_PAD) * 8;
-      if (!b.fork)
-      {
-        HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
-        for (int i = 0; i < SortEmuBufs::N_AUX; ++i)
-        {
-          HIP_CHECK(hipStreamCreateWithFlags(&b.aux[i], hipStreamNonBlocking));
-          HIP_CHECK(hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming));
-        }
-      }
-      // heaps of HEAP_LARGE+1 .. HEAP_RANKED_MAX elements run on ranked 4-byte entries: rank their keys first
-      const uint32_t *rank32 = nullptr;
-      uint32_t *scratch32 = nullptr;
-      static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
-      if (e[1] > HEAP_LARGE && use_asm && !no_ranked)
-      {
-        unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
-        hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
-        prims::exclusive_scan<unsigned long long>(hc, hc, nh, b.scan_tmp, st);
-        unsigned long long tot2 = 0;
-        HIP_CHECK(hipMemcpyAsync(&tot2, hc + nh, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        const uint32_t n_ord = (uint32_t) tot2, e2 = (uint32_t) (tot2 >> 32);
-        if (e2)
-        {
-          uint64_t *hck = b.hr_ck.as<uint64_t>(e2);
-          uint32_t *hval = b.hr_val.as<uint32_t>(e2), *hf = b.hr_f.as<uint32_t>((uint64_t) e2 + 1), *hord = b.hr_ord.as<uint32_t>(n_ord);
-          uint32_t *r32 = b.rank32.as<uint32_t>(n);
-          scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
-          hipLaunchKernelGGL(k_hr_gather, dim3(nh), dim3(256), 0, st, hl, nh, hc, key, hck, hval, hord);
-          int obits = 1;
-          while ((1u << obits) < n_ord && obits < 31) ++obits;
-          uint64_t *sk;
-          uint32_t *sv;
-          prims::radix_sort_pairs(hck, hval, e2, 0, 32 + obits, b.radix, st, &sk, &sv);
-          hipLaunchKernelGGL(k_hr_flags, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, e2, hf);
-          prims::exclusive_scan<uint32_t>(hf, hf, e2, b.scan_tmp, st);
-          hipLaunchKernelGGL(k_hr_scatter, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, sv, hf, hord, e2, r32);
-          rank32 = r32;
-        }
-      }
-      auto launch = [&](auto k0, auto k1, auto k2) {
-        // largest class first: its longest segment is the critical path of the whole sort
-        HIP_CHECK(hipEventRecord(b.fork, st));
-        int used = 0;
-        auto side = [&](auto k, size_t lds, uint32_t lo, uint32_t hi) {
-          HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-          hipLaunchKernelGGL(k, dim3(nh), dim3(64), lds, b.aux[used], hl, nh, key, idx, hscratch, lo, hi, rank32, scratch32);
-          HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
-          ++used;
-        };
-        if (e[1] > HEAP_LARGE)
-        {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          side(k2, dyn, HEAP_LARGE, 0xFFFFFFFFu);
-        }
-        if (e[1] > HEAP_SMALL)
-        {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
-          // one launch per LDS footprint (BK_HEAP_CLASSES=1) packs more mid-size heaps per CU but measured slower
-          // end to end (197 vs 187 ms per step): the extra activity slows the lone wave on the critical path
-          static const bool split = getenv("BK_HEAP_CLASSES") != nullptr;
-          if (!split)
-            side(k1, dyn, HEAP_SMALL, HEAP_LARGE);
-          else
-            for (int c = 0; c < 4; ++c)
-              if (e[1] > bounds[c + 1]) side(k1, ((size_t) bounds[c] + HEAP_PAD) * 8, bounds[c + 1], bounds[c]);
-        }
-        hipLaunchKernelGGL(k0, dim3(nh), dim3(64), 0, st, hl, nh, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32);
-        for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
-      };
-      if (use_asm)
-        launch(k_se_heapsort<0, true>, k_se_heapsort<1, true>, k_se_heapsort<2, true>);
-      else
-        launch(k_se_heapsort<0, false>, k_se_heapsort<1, false>, k_se_heapsort<2, false>);
-      if (dbg)
-      {
-        float ms = 0;
-        HIP_CHECK(hipEventRecord(ev1, st));
-        HIP_CHECK(hipEventSynchronize(ev1));
-        HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        unsigned long long it[2] = {0, 0}, zero[2] = {0, 0};
-        HIP_CHECK(hipMemcpyFromSymbol(it, HIP_SYMBOL(g_heap_iters), 16));
-        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_iters), zero, 16));
-        fprintf(stderr, "[sortemu] heapsort kernels %.3f ms (%.3f us per element of the largest segment); %llu iterations for %llu pops\n", ms, ms * 1e3 / e[1], it[0], it[1]);
-        (void) hipEventDestroy(ev0);
-        (void) hipEventDestroy(ev1);
+        HIP_CHECK(hipStreamCreateWithFlags(&b.aux[i], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming));
       }
     }
-    if (getenv("BK_DEBUG_SORT")) fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u elements=%u max=%u\n", n, ng, e[3], e[2], e[1]);
   }
+  auto side = [&](auto k, size_t lds, const HeapSeg *list, uint32_t count, uint32_t lo, uint32_t hi) {
+    HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
+    hipLaunchKernelGGL(k, dim3(count), dim3(64), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32);
+    HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
+    ++used;
+  };
+  if (nh1 && max1 > HEAP_SMALL)
+  {
+    const uint32_t nh = nh1;
+    if (getenv("BK_DEBUG_SORT_TIES"))
+    {
+      // how many equal keys do the big heap segments hold?  (debugging aid)
+      std::vector<HeapSeg> hh(nh);
+      HIP_CHECK(hipMemcpy(hh.data(), hl, (size_t) nh * sizeof(HeapSeg), hipMemcpyDeviceToHost));
+      for (const HeapSeg &g : hh)
+      {
+        const uint32_t m = g.last - g.first;
+        if (m < 16384) continue;
+        std::vector<uint32_t> kk(m);
+        HIP_CHECK(hipMemcpy(kk.data(), key + g.first, (size_t) m * 4, hipMemcpyDeviceToHost));
+        uint32_t inv = 0;
+        for (uint32_t i = 1; i < m; ++i) inv += kk[i] < kk[i - 1];
+        std::sort(kk.begin(), kk.end());
+        uint32_t distinct = 1, in_ties = 0, maxrun = 1, run = 1;
+        for (uint32_t i = 1; i < m; ++i)
+        {
+          if (kk[i] == kk[i - 1])
+          {
+            ++run;
+            if (run == 2) in_ties += 2; else ++in_ties;
+            if (run > maxrun) maxrun = run;
+          }
+          else
+          {
+            ++distinct;
+            run = 1;
+          }
+        }
+        fprintf(stderr, "[sortemu]   heap segment of %u: %u distinct keys, %u elements in tie groups (largest %u), key range %u..%u, %u descents in arrival order\n", m, distinct, in_ties, maxrun,
+                kk.front(), kk.back(), inv);
+      }
+    }
+    // heaps of HEAP_LARGE+1 .. HEAP_RANKED_MAX elements run on ranked 4-byte entries: rank their keys first
+    static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
+    if (max1 > HEAP_LARGE && use_asm && !no_ranked)
+    {
+      unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
+      hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
+      prims::exclusive_scan<unsigned long long>(hc, hc, nh, b.scan_tmp, st);
+      unsigned long long tot2 = 0;
+      HIP_CHECK(hipMemcpyAsync(&tot2, hc + nh, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      const uint32_t n_ord = (uint32_t) tot2, e2 = (uint32_t) (tot2 >> 32);
+      if (e2)
+      {
+        uint64_t *hck = b.hr_ck.as<uint64_t>(e2);
+        uint32_t *hval = b.hr_val.as<uint32_t>(e2), *hf = b.hr_f.as<uint32_t>((uint64_t) e2 + 1), *hord = b.hr_ord.as<uint32_t>(n_ord);
+        uint32_t *r32 = b.rank32.as<uint32_t>(n);
+        scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
+        hipLaunchKernelGGL(k_hr_gather, dim3(nh), dim3(256), 0, st, hl, nh, hc, key, hck, hval, hord);
+        int obits = 1;
+        while ((1u << obits) < n_ord && obits < 31) ++obits;
+        uint64_t *sk;
+        uint32_t *sv;
+        prims::radix_sort_pairs(hck, hval, e2, 0, 32 + obits, b.radix, st, &sk, &sv);
+        hipLaunchKernelGGL(k_hr_flags, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, e2, hf);
+        prims::exclusive_scan<uint32_t>(hf, hf, e2, b.scan_tmp, st);
+        hipLaunchKernelGGL(k_hr_scatter, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, sv, hf, hord, e2, r32);
+        rank32 = r32;
+      }
+    }
+    auto big = [&](auto k1, auto k2) {
+      // largest class first
+      HIP_CHECK(hipEventRecord(b.fork, st));
+      if (max1 > HEAP_LARGE)
+      {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+        side(k2, dyn, hl, nh1, HEAP_LARGE, 0xFFFFFFFFu);
+      }
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+      const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
+      // one launch per LDS footprint (BK_HEAP_CLASSES=1) packs more mid-size heaps per CU but measured slower
+      // end to end (197 vs 187 ms per step): the extra activity slows the lone wave on the critical path
+      static const bool split = getenv("BK_HEAP_CLASSES") != nullptr;
+      if (!split)
+        side(k1, dyn, hl, nh1, HEAP_SMALL, HEAP_LARGE);
+      else
+        for (int c = 0; c < 4; ++c)
+          if (max1 > bounds[c + 1]) side(k1, ((size_t) bounds[c] + HEAP_PAD) * 8, hl, nh1, bounds[c + 1], bounds[c]);
+    };
+    if (use_asm)
+      big(k_se_heapsort<1, true>, k_se_heapsort<2, true>);
+    else
+      big(k_se_heapsort<1, false>, k_se_heapsort<2, false>);
+  }
+  if (nfin2[1]) hipLaunchKernelGGL((k_se_finish<FIN_MAX, 256>), dim3(nfin2[1]), dim3(256), 0, st, fin_list + (fin_cap - 1), nfin2[1], -1, key, idx, err, heap_list);
+  if (nfin2[0]) hipLaunchKernelGGL((k_se_finish<FIN_SMALL, 64>), dim3(nfin2[0]), dim3(64), 0, st, fin_list, nfin2[0], 1, key, idx, err, heap_list);
+  if (nh1 || nfin)
+  {
+    // small heaps (level loop and finisher) and the finisher's own segments above HEAP_SMALL (at most FIN_MAX elements)
+    if (nfin)
+    {
+      HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    const uint32_t nh2 = e[3];
+    if (nh2)
+    {
+      auto small = [&](auto k0, auto k1) {
+        if (nh2 > nh1 && e[1] > HEAP_SMALL)
+        {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, HEAP_SMALL, HEAP_LARGE, rank32, scratch32);
+        }
+        hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32);
+      };
+      if (use_asm)
+        small(k_se_heapsort<0, true>, k_se_heapsort<1, true>);
+      else
+        small(k_se_heapsort<0, false>, k_se_heapsort<1, false>);
+    }
+    for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
+    if (dbg)
+    {
+      float ms = 0;
+      HIP_CHECK(hipEventRecord(ev1, st));
+      HIP_CHECK(hipEventSynchronize(ev1));
+      HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+      unsigned long long it[2] = {0, 0}, zero[2] = {0, 0};
+      HIP_CHECK(hipMemcpyFromSymbol(it, HIP_SYMBOL(g_heap_iters), 16));
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_iters), zero, 16));
+      fprintf(stderr, "[sortemu] finisher (%u + %u segments) beside the heapsort kernels: %.3f ms (%.3f us per element of the largest heap segment); %llu iterations for %llu pops\n", nfin2[1], nfin2[0], ms,
+              e[1] ? ms * 1e3 / e[1] : 0.0, it[0], it[1]);
+      fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u (%u from the level loop) elements=%u max=%u\n", n, ng, e[3], nh1, e[2], e[1]);
+    }
+  }
+  if (ev0) (void) hipEventDestroy(ev0);
+  if (ev1) (void) hipEventDestroy(ev1);
   // __final_insertion_sort == stable sort by key of what the introsort loop left: two tilings of 32-element windows
   static const bool radix_final = getenv("BK_FINAL_RADIX") != nullptr;  // the general stable radix sort (debugging)
   if (!radix_final)
