@@ -4,8 +4,10 @@
 A step = one pass of the whole hot path (insert-size statistics, discordant-pair scan + mate join,
 isolated-pair masking, -fast clustering, per-read split evidence, cluster summary, split-read
 breakpoints) over one synthetic WGS-shape record table that is already resident in HBM when the timed
-region starts.  Workload at N=1 = BASELINE.json configs[1] (30x WGS shape, hg19, 2x150 bp); for N>1
-every rank processes its own table of the same size (weak scaling).
+region starts.  Workload at N=1 = BASELINE.json configs[1] (30x WGS shape, hg19, 2x150 bp); for N>1 ONE
+sample of N x that size (capped below 2^32 records) is sharded over the ranks - every rank holds a contiguous range of
+its coordinate-sorted records, candidates and pairs travel to their owners by RCCL all-to-all (breakid_amd/sharded.py) -
+so the per-GPU work stays fixed (weak scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--records R]
 
