@@ -46,9 +46,11 @@ template <class T> __device__ __forceinline__ T block_exclusive_scan(T v, T *lds
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
 
-template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const T *__restrict__ in, T *__restrict__ sums, uint64_t n)
+// (n_dev != nullptr: the element count is read from device memory, n is only the bound the grid was sized for)
+template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const T *__restrict__ in, T *__restrict__ sums, uint64_t n, const uint32_t *__restrict__ n_dev = nullptr)
 {
   __shared__ T lds[WAVES];
+  if (n_dev) n = *n_dev;
   uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
   T acc = 0;
 #pragma unroll
@@ -63,9 +65,10 @@ template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const 
 }
 
 // single block: exclusive scan of sums[0..nb) in place, total -> *total_out
-template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_sums(T *sums, uint32_t nb, T *total_out)
+template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_sums(T *sums, uint32_t nb, T *total_out, const uint32_t *__restrict__ n_dev = nullptr)
 {
   __shared__ T lds[WAVES];
+  if (n_dev) total_out += *n_dev;  // total_out = the output array then
   T carry = 0;
   for (uint32_t base = 0; base < nb; base += BLOCK)
   {
@@ -79,9 +82,10 @@ template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_sums(T *sums,
   if (threadIdx.x == 0) *total_out = carry;
 }
 
-template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_apply(const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ sums, uint64_t n)
+template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_apply(const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ sums, uint64_t n, const uint32_t *__restrict__ n_dev = nullptr)
 {
   __shared__ T lds[WAVES];
+  if (n_dev) n = *n_dev;
   uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
   T carry = sums[blockIdx.x];
 #pragma unroll
@@ -106,9 +110,19 @@ template <class T> inline void exclusive_scan(const T *in, T *out, uint64_t n, D
   }
   uint32_t nb = cdiv(n, SCAN_TILE);
   T *sums = tmp.as<T>(nb + 1);
-  hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(BLOCK), 0, st, in, sums, n);
-  hipLaunchKernelGGL(k_scan_sums<T>, dim3(1), dim3(BLOCK), 0, st, sums, nb, out + n);
-  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(BLOCK), 0, st, in, out, sums, n);
+  hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(BLOCK), 0, st, in, sums, n, (const uint32_t *) nullptr);
+  hipLaunchKernelGGL(k_scan_sums<T>, dim3(1), dim3(BLOCK), 0, st, sums, nb, out + n, (const uint32_t *) nullptr);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(BLOCK), 0, st, in, out, sums, n, (const uint32_t *) nullptr);
+}
+
+// the same with the element count in device memory (*n_dev <= n_bound); out[*n_dev] = total
+template <class T> inline void exclusive_scan_devn(const T *in, T *out, uint64_t n_bound, const uint32_t *n_dev, DevBuf &tmp, hipStream_t st)
+{
+  uint32_t nb = cdiv(n_bound ? n_bound : 1, SCAN_TILE);
+  T *sums = tmp.as<T>(nb + 1);
+  hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(BLOCK), 0, st, in, sums, n_bound, n_dev);
+  hipLaunchKernelGGL(k_scan_sums<T>, dim3(1), dim3(BLOCK), 0, st, sums, nb, out, n_dev);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3(nb), dim3(BLOCK), 0, st, in, out, sums, n_bound, n_dev);
 }
 
 // ---- stable LSD radix sort, u64 keys + u32 values, 8-bit digits -----------------------------------

@@ -96,16 +96,14 @@ __global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, 
   }
 }
 
-// __move_median_to_first(first, first+1, mid, last-1)
-__global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
+// __move_median_to_first(first, first+1, mid, last-1) of one live segment; a segment whose depth budget is used up goes
+// to the heap list instead (depth = -1)
+__device__ __forceinline__ void pivot_one(Seg &sg, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
 {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ns) return;
-  Seg sg = segs[s];
   if (sg.depth == 0)
   {
     // std::sort switches to heapsort here (__partial_sort(first,last,last)); k_se_heapsort finishes the segment
-    segs[s].depth = -1;
+    sg.depth = -1;
     uint32_t slot = atomicAdd(err + 3, 1u);
     heap_list[slot] = make_uint2(sg.first, sg.last);
     atomicAdd(err + 2, sg.last - sg.first);
@@ -131,8 +129,17 @@ __global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__rest
   key[pick] = kf;
   idx[first] = xp;
   idx[pick] = xf;
-  segs[s].pivot = kp;
-  segs[s].depth = sg.depth - 1;
+  sg.pivot = kp;
+  sg.depth = sg.depth - 1;
+}
+__global__ void k_se_pivot(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Seg sg = segs[s];
+  pivot_one(sg, key, idx, err, heap_list);
+  segs[s].pivot = sg.pivot;
+  segs[s].depth = sg.depth;
 }
 
 // ---- heapsort branch of std::sort (__partial_sort(first,last,last) = make_heap + sort_heap) ----------------
@@ -746,10 +753,18 @@ __device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint3
 // lr[c] = (#L-stopper at c) | (#R-stopper at c) << 32 ; segof[c] = segment index
 // Live segments hold more than 16 elements, so the 256 consecutive compact indices of a block span at most 16
 // segments: one full binary search per block, then a 4-step search inside that window per lane.
+// (lvl != nullptr in all level kernels: live segment / element counts {ns, na} are read from device memory, the arguments
+// are only the bounds the grid was sized for)
 __global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
-                                                  unsigned long long *__restrict__ lr, uint32_t *__restrict__ segof)
+                                                  unsigned long long *__restrict__ lr, uint32_t *__restrict__ segof, const uint32_t *__restrict__ lvl = nullptr)
 {
   __shared__ uint32_t s_first;
+  if (lvl)
+  {
+    ns = lvl[0];
+    na = lvl[1];
+  }
+  if (blockIdx.x * blockDim.x >= na) return;
   if (threadIdx.x == 0) s_first = find_seg(segs, ns, blockIdx.x * blockDim.x);
   __syncthreads();
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -774,8 +789,9 @@ __global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, 
 }
 
 __global__ __launch_bounds__(256) void k_se_lists(const Seg *__restrict__ segs, const uint32_t *__restrict__ segof, const uint32_t *__restrict__ key, uint32_t na,
-                                                  const unsigned long long *__restrict__ LR, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR)
+                                                  const unsigned long long *__restrict__ LR, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR, const uint32_t *__restrict__ lvl = nullptr)
 {
+  if (lvl) na = lvl[1];
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= na) return;
   const Seg sg = segs[segof[c]];
@@ -797,8 +813,9 @@ __global__ __launch_bounds__(256) void k_se_lists(const Seg *__restrict__ segs, 
 }
 
 __global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const uint32_t *__restrict__ segof, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
-                                                 const unsigned long long *__restrict__ LR, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR)
+                                                 const unsigned long long *__restrict__ LR, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR, const uint32_t *__restrict__ lvl = nullptr)
 {
+  if (lvl) na = lvl[1];
   uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= na) return;
   const uint32_t s = segof[c];
@@ -878,6 +895,82 @@ __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, cons
     Seg c = sg;
     c.first = sg.cut;
     c.cbase = cb;
+    out[o++] = c;
+  }
+  else if (b > 16)
+    fin_append(fl, fin, sg.cut, sg.last, sg.depth);
+}
+
+// Late levels hold a few dozen to a few hundred live segments and are bound by launches and by the host round trip
+// that sizes the next level.  For up to CHILD_FUSED segments one workgroup counts the children, scans the counts, writes
+// the children, picks their pivots (k_se_child_count + exclusive_scan + k_se_child_write + the next level's k_se_pivot: six
+// launches in one) and leaves the next level's {segments, elements} in lvl, so that the host can queue several levels
+// before it looks (the level kernels read lvl; their grids are sized for bounds).
+constexpr uint32_t CHILD_FUSED = 1024;
+__global__ __launch_bounds__(CHILD_FUSED) void k_se_children_small(const Seg *__restrict__ segs, uint32_t *__restrict__ lvl, Seg *__restrict__ out, FinSeg *__restrict__ fl,
+                                                                   uint32_t *__restrict__ fin, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
+                                                                   uint2 *__restrict__ heap_list)
+{
+  __shared__ unsigned long long wsum[CHILD_FUSED / 64];
+  const uint32_t ns = lvl[0];
+  const uint32_t s = threadIdx.x, lane = s & 63, w = s >> 6;
+  Seg sg = {};
+  unsigned long long v = 0;
+  uint32_t a = 0, b = 0;
+  bool live = false;
+  if (s < ns)
+  {
+    sg = segs[s];
+    live = sg.depth >= 0;
+    if (live)
+    {
+      a = sg.cut - sg.first;
+      b = sg.last - sg.cut;
+      if (a > FIN_MAX) v += 1ull | ((unsigned long long) a << 32);
+      if (b > FIN_MAX) v += 1ull | ((unsigned long long) b << 32);
+    }
+  }
+  // exclusive scan of (count | elements << 32) over the workgroup
+  unsigned long long inc = v;
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const unsigned long long o = __shfl_up(inc, d, 64);
+    if ((int) lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();  // (every thread has read lvl[0] by now)
+  unsigned long long base = 0, tot = 0;
+  for (uint32_t i = 0; i < CHILD_FUSED / 64; ++i)
+  {
+    const unsigned long long t = wsum[i];
+    if (i < w) base += t;
+    tot += t;
+  }
+  if (s == 0)
+  {
+    lvl[0] = (uint32_t) tot;
+    lvl[1] = (uint32_t) (tot >> 32);
+  }
+  if (!live) return;
+  const unsigned long long off = base + inc - v;
+  uint32_t o = (uint32_t) off, cb = (uint32_t) (off >> 32);
+  if (a > FIN_MAX)
+  {
+    Seg c = sg;
+    c.last = sg.cut;
+    c.cbase = cb;
+    cb += a;
+    pivot_one(c, key, idx, err, heap_list);
+    out[o++] = c;
+  }
+  else if (a > 16)
+    fin_append(fl, fin, sg.first, sg.cut, sg.depth);
+  if (b > FIN_MAX)
+  {
+    Seg c = sg;
+    c.first = sg.cut;
+    c.cbase = cb;
+    pivot_one(c, key, idx, err, heap_list);
     out[o++] = c;
   }
   else if (b > 16)
@@ -1287,32 +1380,79 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       HIP_CHECK(hipStreamSynchronize(st));
       t_loop0 = now_ms();
     }
+    uint32_t *lvl = b.lvl.as<uint32_t>(4);
+    bool pivoted = false;  // the live segments already carry their pivots (the fused child kernel picked them)
     while (ns)
     {
       if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-      hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-      const unsigned nbk = cdiv(na, 256);
-      hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, na, lr, segof);
-      prims::exclusive_scan<unsigned long long>(lr, lr, na, b.scan_tmp, st);
-      hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR);
-      hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR);
-      hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
-      prims::exclusive_scan<unsigned long long>(cnt, cnt, ns, b.scan_tmp, st);
-      // the children are written while the host waits for their count (at most 2 per segment: 2 * ns <= capacity)
-      if (2ull * ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-      hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin);
-      HIP_CHECK(hipMemcpyAsync(&tot, cnt + ns, 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+      // how many levels may be queued before the host has to look: the segment count at most doubles per level and
+      // the fused child kernel takes CHILD_FUSED segments
+      int batch = 0;
+      static const bool no_batch = getenv("BK_SORT_NO_BATCH") != nullptr;
+      static const int max_batch = getenv("BK_SORT_BATCH") ? atoi(getenv("BK_SORT_BATCH")) : 6;
+      if (!no_batch)
+      {
+        // a live segment holds more than FIN_MAX elements and the live elements never grow: na / FIN_MAX bounds the
+        // segment count of every later level
+        if (ns <= CHILD_FUSED && na / FIN_MAX <= CHILD_FUSED)
+          batch = max_batch;
+        else
+          for (uint32_t cap = ns; cap <= CHILD_FUSED && batch < max_batch; cap *= 2) ++batch;
+      }
+      if (batch == 0)
+      {
+        if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
+        pivoted = false;
+        const unsigned nbk = cdiv(na, 256);
+        hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, na, lr, segof, (const uint32_t *) nullptr);
+        prims::exclusive_scan<unsigned long long>(lr, lr, na, b.scan_tmp, st);
+        hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) nullptr);
+        hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) nullptr);
+        hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
+        prims::exclusive_scan<unsigned long long>(cnt, cnt, ns, b.scan_tmp, st);
+        // the children are written while the host waits for their count (at most 2 per segment: 2 * ns <= capacity)
+        if (2ull * ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
+        hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin);
+        HIP_CHECK(hipMemcpyAsync(&tot, cnt + ns, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::swap(segs, segs2);
+        ++level;
+      }
+      else
+      {
+        // `batch` levels without a host round trip: counts live in lvl, grids are sized for the counts at the start
+        if (std::min<uint64_t>((uint64_t) ns << batch, (uint64_t) na / FIN_MAX + 1) > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
+        const uint32_t cur[2] = {ns, na};
+        HIP_CHECK(hipMemcpyAsync(lvl, cur, 8, hipMemcpyHostToDevice, st));
+        if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
+        const unsigned nbk = cdiv(na, 256);
+        uint32_t ns_bound = ns;
+        for (int l = 0; l < batch; ++l)
+        {
+          hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns_bound, key, na, lr, segof, (const uint32_t *) lvl);
+          prims::exclusive_scan_devn<unsigned long long>(lr, lr, na, lvl + 1, b.scan_tmp, st);
+          hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) lvl);
+          hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) lvl);
+          hipLaunchKernelGGL(k_se_children_small, dim3(1), dim3(CHILD_FUSED), 0, st, segs, lvl, segs2, fin_list, fin, key, idx, err, heap_list);
+          std::swap(segs, segs2);
+          ns_bound = ns_bound * 2 < CHILD_FUSED ? ns_bound * 2 : CHILD_FUSED;
+          ++level;
+        }
+        pivoted = true;
+        uint32_t now[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(now, lvl, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        tot = (unsigned long long) now[0] | ((unsigned long long) now[1] << 32);
+      }
       const uint32_t ns2 = (uint32_t) tot;
-      std::swap(segs, segs2);
-      ns = ns2;
-      na = (uint32_t) (tot >> 32);
       if (dbg_levels && (level % 4 == 0 || ns2 == 0))
       {
         HIP_CHECK(hipStreamSynchronize(st));
         fprintf(stderr, "[sortemu]   level %d: %u segments -> %u (%u live elements), %.3f ms so far\n", level, ns, ns2, (uint32_t) (tot >> 32), now_ms() - t_loop0);
       }
-      if (++level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
+      ns = ns2;
+      na = (uint32_t) (tot >> 32);
+      if (level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
   // What is left: (1) segments of at most FIN_MAX elements - the rest of their introsort loop runs in LDS, one workgroup
