@@ -902,33 +902,30 @@ __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, cons
 }
 
 // Late levels hold a few dozen to a few hundred live segments and are bound by launches and by the host round trip
-// that sizes the next level.  For up to CHILD_FUSED segments one workgroup counts the children, scans the counts, writes
+// that sizes the next level.  For up to CHILD_FUSED segments (a few per thread) one workgroup counts the children, scans the counts, writes
 // the children, picks their pivots (k_se_child_count + exclusive_scan + k_se_child_write + the next level's k_se_pivot: six
 // launches in one) and leaves the next level's {segments, elements} in lvl, so that the host can queue several levels
 // before it looks (the level kernels read lvl; their grids are sized for bounds).
-constexpr uint32_t CHILD_FUSED = 1024;
-__global__ __launch_bounds__(CHILD_FUSED) void k_se_children_small(const Seg *__restrict__ segs, uint32_t *__restrict__ lvl, Seg *__restrict__ out, FinSeg *__restrict__ fl,
-                                                                   uint32_t *__restrict__ fin, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
-                                                                   uint2 *__restrict__ heap_list)
+constexpr uint32_t CHILD_THREADS = 1024, CHILD_PER = 8, CHILD_FUSED = CHILD_THREADS * CHILD_PER;
+__global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *__restrict__ segs, uint32_t *__restrict__ lvl, Seg *__restrict__ out, FinSeg *__restrict__ fl,
+                                                                     uint32_t *__restrict__ fin, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
+                                                                     uint2 *__restrict__ heap_list)
 {
-  __shared__ unsigned long long wsum[CHILD_FUSED / 64];
+  __shared__ unsigned long long wsum[CHILD_THREADS / 64];
   const uint32_t ns = lvl[0];
-  const uint32_t s = threadIdx.x, lane = s & 63, w = s >> 6;
-  Seg sg = {};
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // thread t takes segments [t * per, (t + 1) * per): one each while they are few
+  const uint32_t per = (ns + CHILD_THREADS - 1) / CHILD_THREADS;
   unsigned long long v = 0;
-  uint32_t a = 0, b = 0;
-  bool live = false;
-  if (s < ns)
+  for (uint32_t k = 0; k < per; ++k)
   {
-    sg = segs[s];
-    live = sg.depth >= 0;
-    if (live)
-    {
-      a = sg.cut - sg.first;
-      b = sg.last - sg.cut;
-      if (a > FIN_MAX) v += 1ull | ((unsigned long long) a << 32);
-      if (b > FIN_MAX) v += 1ull | ((unsigned long long) b << 32);
-    }
+    const uint32_t s = t * per + k;
+    if (s >= ns) break;
+    const Seg sg = segs[s];
+    if (sg.depth < 0) continue;
+    const uint32_t a = sg.cut - sg.first, b = sg.last - sg.cut;
+    if (a > FIN_MAX) v += 1ull | ((unsigned long long) a << 32);
+    if (b > FIN_MAX) v += 1ull | ((unsigned long long) b << 32);
   }
   // exclusive scan of (count | elements << 32) over the workgroup
   unsigned long long inc = v;
@@ -940,41 +937,49 @@ __global__ __launch_bounds__(CHILD_FUSED) void k_se_children_small(const Seg *__
   if (lane == 63) wsum[w] = inc;
   __syncthreads();  // (every thread has read lvl[0] by now)
   unsigned long long base = 0, tot = 0;
-  for (uint32_t i = 0; i < CHILD_FUSED / 64; ++i)
+  for (uint32_t i = 0; i < CHILD_THREADS / 64; ++i)
   {
-    const unsigned long long t = wsum[i];
-    if (i < w) base += t;
-    tot += t;
+    const unsigned long long x = wsum[i];
+    if (i < w) base += x;
+    tot += x;
   }
-  if (s == 0)
+  if (t == 0)
   {
     lvl[0] = (uint32_t) tot;
     lvl[1] = (uint32_t) (tot >> 32);
   }
-  if (!live) return;
   const unsigned long long off = base + inc - v;
   uint32_t o = (uint32_t) off, cb = (uint32_t) (off >> 32);
-  if (a > FIN_MAX)
+  for (uint32_t k = 0; k < per; ++k)
   {
-    Seg c = sg;
-    c.last = sg.cut;
-    c.cbase = cb;
-    cb += a;
-    pivot_one(c, key, idx, err, heap_list);
-    out[o++] = c;
+    const uint32_t s = t * per + k;
+    if (s >= ns) break;
+    const Seg sg = segs[s];
+    if (sg.depth < 0) continue;
+    const uint32_t a = sg.cut - sg.first, b = sg.last - sg.cut;
+    if (a > FIN_MAX)
+    {
+      Seg c = sg;
+      c.last = sg.cut;
+      c.cbase = cb;
+      cb += a;
+      pivot_one(c, key, idx, err, heap_list);
+      out[o++] = c;
+    }
+    else if (a > 16)
+      fin_append(fl, fin, sg.first, sg.cut, sg.depth);
+    if (b > FIN_MAX)
+    {
+      Seg c = sg;
+      c.first = sg.cut;
+      c.cbase = cb;
+      cb += b;
+      pivot_one(c, key, idx, err, heap_list);
+      out[o++] = c;
+    }
+    else if (b > 16)
+      fin_append(fl, fin, sg.cut, sg.last, sg.depth);
   }
-  else if (a > 16)
-    fin_append(fl, fin, sg.first, sg.cut, sg.depth);
-  if (b > FIN_MAX)
-  {
-    Seg c = sg;
-    c.first = sg.cut;
-    c.cbase = cb;
-    pivot_one(c, key, idx, err, heap_list);
-    out[o++] = c;
-  }
-  else if (b > 16)
-    fin_append(fl, fin, sg.cut, sg.last, sg.depth);
 }
 
 // ---- the same introsort loop for one segment of at most FIN_MAX elements, entirely in LDS ---------------------
@@ -1433,7 +1438,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
           prims::exclusive_scan_devn<unsigned long long>(lr, lr, na, lvl + 1, b.scan_tmp, st);
           hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) lvl);
           hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) lvl);
-          hipLaunchKernelGGL(k_se_children_small, dim3(1), dim3(CHILD_FUSED), 0, st, segs, lvl, segs2, fin_list, fin, key, idx, err, heap_list);
+          hipLaunchKernelGGL(k_se_children_small, dim3(1), dim3(CHILD_THREADS), 0, st, segs, lvl, segs2, fin_list, fin, key, idx, err, heap_list);
           std::swap(segs, segs2);
           ns_bound = ns_bound * 2 < CHILD_FUSED ? ns_bound * 2 : CHILD_FUSED;
           ++level;
