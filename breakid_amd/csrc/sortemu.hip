@@ -248,7 +248,8 @@ template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint3
 }
 
 constexpr uint32_t HEAP_PAD = 32;
-__device__ unsigned long long g_heap_iters[2];  // debug: loop iterations / pops of sort_heap (BK_DEBUG_SORT)
+__device__ unsigned long long g_heap_iters[2];
+__device__ unsigned long long g_heap_phase[8];  // debug: 10 ns ticks of the phases of the largest ranked heap (BK_DEBUG_SORT)  // debug: loop iterations / pops of sort_heap (BK_DEBUG_SORT)
 
 // the routines below are executed by one full wavefront (64 lanes, all active)
 // make_heap, bottom level first (nodes of one depth own disjoint subtrees)
@@ -634,16 +635,20 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
   if (CLS == 2 && ASM && rank32 != nullptr && m <= HEAP_RANKED_MAX)
   {
     // ranked 4-byte entries (see E32): up to HEAP_LARGE32 of them fit LDS.  buf keeps the packed originals.
+    const unsigned long long tp0 = wall_clock64();
     uint32_t *l32 = reinterpret_cast<uint32_t *>(dyn);
     uint32_t *g32 = scratch32 + sg.first;
     const bool fits = m <= HEAP_LARGE32;
     uint32_t *e32 = fits ? l32 : g32;
     for (uint32_t i = threadIdx.x; i < m; i += 64) e32[i] = (rank32[sg.first + i] << 16) | i;
     __syncthreads();
+    const unsigned long long tp1 = wall_clock64();
+    unsigned long long tp2 = tp1, tp3 = tp1;
     if (fits)
     {
       LdsMemT<E32> mem{l32};
       make_heap_wave(mem, m);
+      tp2 = tp3 = wall_clock64();
       sort_heap_asm32<false>(l32, m, 1);
     }
     else
@@ -651,7 +656,9 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
       GlbMemT<E32> gmem{g32};
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       make_heap_wave(gmem, m);
+      tp2 = wall_clock64();
       sort_heap_asm32<true>(g32, m, HEAP_LARGE32);
+      tp3 = wall_clock64();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) l32[i] = g32[i];
       __syncthreads();
@@ -661,6 +668,15 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    const unsigned long long tp4 = wall_clock64();
+    if (threadIdx.x == 0 && m > 36000)
+    {
+      g_heap_phase[0] = m;
+      g_heap_phase[1] = tp1 - tp0;
+      g_heap_phase[2] = tp2 - tp1;
+      g_heap_phase[3] = tp3 - tp2;
+      g_heap_phase[4] = tp4 - tp3;
+    }
     for (uint32_t i = threadIdx.x; i < m; i += 64)
     {
       const hent e = buf[e32[i] & 0xFFFFu];
@@ -1633,6 +1649,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       fprintf(stderr, "[sortemu] finisher (%u + %u segments) beside the heapsort kernels: %.3f ms (%.3f us per element of the largest heap segment); %llu iterations for %llu pops\n", nfin2[1], nfin2[0], ms,
               e[1] ? ms * 1e3 / e[1] : 0.0, it[0], it[1]);
       fprintf(stderr, "[sortemu] n=%u groups=%u heap segments=%u (%u from the level loop) elements=%u max=%u\n", n, ng, e[3], nh1, e[2], e[1]);
+      unsigned long long ph[8] = {0}, zz[8] = {0};
+      HIP_CHECK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_heap_phase), 64));
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_phase), zz, 64));
+      if (ph[0]) fprintf(stderr, "[sortemu]   a ranked heap of %llu: load + rank %.2f ms, make_heap %.2f ms, pops in global memory %.2f ms, pops in LDS %.2f ms\n", ph[0], ph[1] * 1e-5, ph[2] * 1e-5, ph[3] * 1e-5, ph[4] * 1e-5);
     }
   }
   if (ev0) (void) hipEventDestroy(ev0);
