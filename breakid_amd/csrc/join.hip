@@ -26,13 +26,11 @@ __device__ __forceinline__ uint32_t gpos(const uint32_t *__restrict__ tprefix, i
   return base + (uint32_t) pos;
 }
 
-// one lane per sorted position; only run starts work.  Runs are a handful of records.
-__global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ cand, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, double w,
-                                                    const uint32_t *__restrict__ tprefix, int32_t nt, bk_pair *__restrict__ out, uint64_t *__restrict__ okey,
-                                                    uint32_t *__restrict__ oval, unsigned long long cap, unsigned long long *__restrict__ counter,
-                                                    uint32_t *__restrict__ err)
+// the mate join of the run of equal read-name hashes that starts at sorted position i (nothing when i is not a run
+// start); append(pair) takes every discordant pair, in the reference's arrival order
+template <class F> __device__ __forceinline__ void join_run(const Cand *__restrict__ cand, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, double w,
+                                                            const uint32_t *__restrict__ tprefix, int32_t nt, uint32_t *__restrict__ err, uint64_t i, F &&append)
 {
-  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t h = key[i];
   if (i > 0 && key[i - 1] == h) return;  // not a run start
@@ -114,9 +112,55 @@ __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ can
     p.id = 0;
     p.cluster = -1;
     p.group = 0;
+    append(p);
+  }
+}
+
+
+// one lane per sorted position; only run starts work.  Runs are a handful of records.
+__global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ cand, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, double w,
+                                                    const uint32_t *__restrict__ tprefix, int32_t nt, bk_pair *__restrict__ out, uint64_t *__restrict__ okey,
+                                                    uint32_t *__restrict__ oval, unsigned long long cap, unsigned long long *__restrict__ counter,
+                                                    uint32_t *__restrict__ err)
+{
+  // Pairs are appended through ONE counter: a returning atomic per wave tops out near 90 per microsecond on this part
+  // (15 M pairs from 480 K waves: 5.3 ms, the whole kernel).  The first pair of every lane is therefore counted in LDS
+  // and the workgroup takes its slots with a single global atomic; further pairs of a long run (rare) append directly.
+  __shared__ unsigned int s_cnt;
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  bool have = false;
+  bk_pair first_pair;
+  auto append = [&](const bk_pair &p) {
+    if (!have)
+    {
+      have = true;
+      first_pair = p;
+      return;
+    }
     unsigned long long slot = atomicAdd(counter, 1ull);
     if (slot < cap)
     {
+      out[slot] = p;
+      uint64_t gk = (uint64_t) (uint32_t) (p.p1_tid + 1) * (uint64_t) (nt + 1) + (uint64_t) (uint32_t) (p.p2_tid + 1);
+      okey[slot] = (gk << 32) | p.rec;
+      oval[slot] = (uint32_t) slot;
+    }
+  };
+  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  join_run(cand, key, val, n, w, tprefix, nt, err, i, append);
+  unsigned int my = 0;
+  if (have) my = atomicAdd(&s_cnt, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(counter, (unsigned long long) s_cnt);
+  __syncthreads();
+  if (have)
+  {
+    const unsigned long long slot = s_base + my;
+    if (slot < cap)
+    {
+      const bk_pair &p = first_pair;
       out[slot] = p;
       uint64_t gk = (uint64_t) (uint32_t) (p.p1_tid + 1) * (uint64_t) (nt + 1) + (uint64_t) (uint32_t) (p.p2_tid + 1);
       okey[slot] = (gk << 32) | p.rec;
