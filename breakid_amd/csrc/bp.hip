@@ -389,11 +389,16 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
   const int32_t p1_chr = hdr_id[k.p1_tid + 1];
   int2 *E = emit + moff[c];
   const uint32_t K = moff[c + 1] - moff[c];
-  for (uint64_t i = wk.t1lo + lane; i < wk.t1hi; i += 64)
+  if (K == 0) return;  // k_bp_regions counted no match: nothing to emit, nothing to vote on (and no fence to pay)
+  // all (a, b) combinations of the two tuple ranges, spread over the lanes (a lane per `a` left most of the wave idle:
+  // a cluster has a handful of tuples on either side)
+  const uint64_t n1 = wk.t1hi - wk.t1lo, n2 = wk.t2hi - wk.t2lo, total = n1 * n2;
+  for (uint64_t q = lane; q < total; q += 64)
   {
+    const uint64_t qi = total <= 0xFFFFFFFFull ? (uint64_t) ((uint32_t) q / (uint32_t) n2) : q / n2;
+    const uint64_t i = wk.t1lo + qi, j = wk.t2lo + (q - qi * n2);
     const bk_split a = sp[i];
     if (!in_region(r1, a.tid, a.pos, a.endpos)) continue;
-    for (uint64_t j = wk.t2lo; j < wk.t2hi; ++j)
     {
       const bk_split b = sp[j];
       if (in_region(r2, b.tid, b.pos, b.endpos) && tuples_match(a, b))
