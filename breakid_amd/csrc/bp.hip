@@ -7,6 +7,8 @@
 #include "bk_common.h"
 #include "prims.h"
 #include "bp.h"
+#include <algorithm>
+#include <vector>
 
 namespace
 {
@@ -289,6 +291,16 @@ __device__ bool side_verdict(const bk_split *__restrict__ sp, uint64_t nsp, cons
   return !(cov < 5 || ev < 2);
 }
 
+// the same over tuples in memory: the read-name hash decides nearly every comparison, so it is looked at first and the
+// other 72 bytes of a tuple are only loaded for the pairs that share it
+__device__ __forceinline__ bool tuples_match_at(const bk_split *__restrict__ pa, const bk_split *__restrict__ pb)
+{
+  if (pa->qhash != pb->qhash) return false;
+  const bk_split a = *pa, b = *pb;
+  return ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.prim_start == b.prim_start && a.sec_start == b.sec_start &&
+         a.prim_end == b.prim_end && a.sec_end == b.sec_end && a.prim_cigar == b.prim_cigar && a.sec_cigar == b.sec_cigar && a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;
+}
+
 __device__ __forceinline__ bool tuples_match(const bk_split &a, const bk_split &b)
 {
   return a.qhash == b.qhash && ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.prim_start == b.prim_start &&
@@ -317,15 +329,14 @@ __global__ __launch_bounds__(256) void k_bp_regions(const bk_split *__restrict__
   if (ok1 && ok2)
   {
     wk.ok = 1;
-    for (uint64_t i = wk.t1lo + lane; i < wk.t1hi; i += 64)
+    // all (a, b) combinations of the two tuple ranges, spread over the lanes
+    const uint64_t n2 = wk.t2hi - wk.t2lo, total = (wk.t1hi - wk.t1lo) * n2;
+    for (uint64_t q = lane; q < total; q += 64)
     {
-      const bk_split a = sp[i];
-      if (!in_region(r1, a.tid, a.pos, a.endpos)) continue;
-      for (uint64_t j = wk.t2lo; j < wk.t2hi; ++j)
-      {
-        const bk_split b = sp[j];
-        if (in_region(r2, b.tid, b.pos, b.endpos) && tuples_match(a, b)) ++m;
-      }
+      const uint64_t qi = total <= 0xFFFFFFFFull ? (uint64_t) ((uint32_t) q / (uint32_t) n2) : q / n2;
+      const bk_split *pa = sp + wk.t1lo + qi, *pb = sp + wk.t2lo + (q - qi * n2);
+      if (!tuples_match_at(pa, pb)) continue;
+      if (in_region(r1, pa->tid, pa->pos, pa->endpos) && in_region(r2, pb->tid, pb->pos, pb->endpos)) ++m;
     }
     m = wave_sum(m);
   }
@@ -373,6 +384,7 @@ __device__ bool key_less(int32_t a1, int32_t a2, int32_t b1, int32_t b2)
   return la < lb;
 }
 
+constexpr uint32_t VOTE_LDS = 256;
 // phase 3: emit (p1_bp, p2_bp) for every match and vote (find_bp_pair); voted[c] = 1 when encompass_num >= 2 (:446)
 __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp, bk_cluster *__restrict__ cl, uint32_t ncl, int wi, const BpWork *__restrict__ work,
                                                  const uint32_t *__restrict__ moff, int2 *__restrict__ emit, uint32_t *__restrict__ ecount,
@@ -380,16 +392,27 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
 {
   const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  // the emitted list of a cluster with up to VOTE_LDS matches lives in LDS (no global atomics, no fence before it is
+  // read back); longer lists use the global buffer
+  __shared__ int2 s_emit[4][VOTE_LDS];
+  __shared__ unsigned int s_ecount[4];
   if (c >= ncl) return;
   if (lane == 0) voted[c] = 0;
+  // (one round trip for everything the wave needs to know about its cluster: this kernel is a chain of dependent loads
+  // per wave - a cluster has ~100 tuple combinations and ~8 matches - so the chain's length is its run time)
   const BpWork wk = work[c];
-  if (!wk.ok) return;
   bk_cluster k = cl[c];
+  const uint32_t m0 = moff[c], m1 = moff[c + 1];
+  if (!wk.ok) return;
+  const uint32_t K = m1 - m0;
+  if (K == 0) return;  // k_bp_regions counted no match: nothing to emit, nothing to vote on
   Region r1 = make_region(k.p1_tid, k.p1_mean, wi), r2 = make_region(k.p2_tid, k.p2_mean, wi);
   const int32_t p1_chr = hdr_id[k.p1_tid + 1];
-  int2 *E = emit + moff[c];
-  const uint32_t K = moff[c + 1] - moff[c];
-  if (K == 0) return;  // k_bp_regions counted no match: nothing to emit, nothing to vote on (and no fence to pay)
+  const bool in_lds = K <= VOTE_LDS;
+  const int wv = threadIdx.x >> 6;
+  int2 *E = in_lds ? s_emit[wv] : emit + m0;
+  if (in_lds && lane == 0) s_ecount[wv] = 0;
+  __builtin_amdgcn_wave_barrier();
   // all (a, b) combinations of the two tuple ranges, spread over the lanes (a lane per `a` left most of the wave idle:
   // a cluster has a handful of tuples on either side)
   const uint64_t n1 = wk.t1hi - wk.t1lo, n2 = wk.t2hi - wk.t2lo, total = n1 * n2;
@@ -397,13 +420,13 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
   {
     const uint64_t qi = total <= 0xFFFFFFFFull ? (uint64_t) ((uint32_t) q / (uint32_t) n2) : q / n2;
     const uint64_t i = wk.t1lo + qi, j = wk.t2lo + (q - qi * n2);
-    const bk_split a = sp[i];
-    if (!in_region(r1, a.tid, a.pos, a.endpos)) continue;
+    const bk_split *pa = sp + i, *pb = sp + j;
+    if (!tuples_match_at(pa, pb)) continue;
     {
-      const bk_split b = sp[j];
-      if (in_region(r2, b.tid, b.pos, b.endpos) && tuples_match(a, b))
+      const bk_split a = *pa, b = *pb;
+      if (in_region(r1, a.tid, a.pos, a.endpos) && in_region(r2, b.tid, b.pos, b.endpos))
       {
-        uint32_t slot = atomicAdd(&ecount[c], 1u);
+        uint32_t slot = in_lds ? atomicAdd(&s_ecount[wv], 1u) : atomicAdd(&ecount[c], 1u);
         int2 e;
         if (a.prim_chr == p1_chr)  // :647
         {
@@ -420,7 +443,11 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
     }
   }
   // the list was written by other lanes of this wave: make it visible before it is read back
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  if (in_lds)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  else
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_wave_barrier();
   // vote (:804-855): for each distinct key, count emitted pairs within +-2 on both coordinates (unsigned
   // arithmetic, :820-821); first strict maximum in std::map<string> order wins
   int best_cnt = 0;
@@ -614,6 +641,27 @@ void bp_vote(const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, dou
   HIP_CHECK(hipMemcpyAsync(&host[1], err, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   if (host[1]) throw bk_error(BK_ERR_CIGAR, "error cigar: ");  // the reference's exit(-1), BreakID.cc:954-968
+  if (getenv("BK_DEBUG_BP"))
+  {
+    std::vector<uint32_t> nm(ncl);
+    std::vector<BpWork> wk(ncl);
+    HIP_CHECK(hipMemcpy(nm.data(), nmatch, ncl * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(wk.data(), work, ncl * sizeof(BpWork), hipMemcpyDeviceToHost));
+    uint64_t okc = 0, kmax = 0, ksum = 0, pmax = 0, psum = 0, k0 = 0;
+    for (uint64_t i = 0; i < ncl; ++i)
+    {
+      if (!wk[i].ok) continue;
+      ++okc;
+      const uint64_t pr = (wk[i].t1hi - wk[i].t1lo) * (wk[i].t2hi - wk[i].t2lo);
+      kmax = std::max<uint64_t>(kmax, nm[i]);
+      ksum += nm[i];
+      pmax = std::max(pmax, pr);
+      psum += pr;
+      k0 += nm[i] == 0;
+    }
+    fprintf(stderr, "[bp] %llu clusters, %llu with both regions ok (%llu of them without a match): matches total %llu max %llu; tuple combinations total %llu max %llu\n",
+            (unsigned long long) ncl, (unsigned long long) okc, (unsigned long long) k0, (unsigned long long) ksum, (unsigned long long) kmax, (unsigned long long) psum, (unsigned long long) pmax);
+  }
   int2 *emit = b.emit.as<int2>((uint64_t) host[0] + 1);
   uint32_t *ecount = b.ecount.as<uint32_t>(ncl + 1);
   HIP_CHECK(hipMemsetAsync(ecount, 0, (ncl + 1) * 4, st));
