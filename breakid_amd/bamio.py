@@ -155,3 +155,38 @@ def write_nib(path: str, seq: str) -> None:
         out.append((vals[i] << 4) | vals[i + 1])
     with open(path, "wb") as f:
         f.write(bytes(out))
+
+
+def write_bam_from_soa(path: str, contigs: Sequence[Tuple[str, int]], cols, qnames: Sequence[bytes], aligned: bool = True) -> None:
+    """Columnar table (numpy dict, abi.SOA_COLS layout) -> coordinate-sorted BAM; qnames[i] is record i's read name.
+    The aux blob becomes SA:Z (and OC:Z when the blob is 'OC \\t SA').  Tooling for fixtures: this is how tables made by
+    breakid_amd.synth_gpu reach the reference binary."""
+    tid, pos, mtid, mpos, isize = (cols[k].tolist() for k in ("tid", "pos", "mtid", "mpos", "isize"))
+    flag, mapq = cols["flag"].tolist(), cols["mapq"].tolist()
+    coff, aoff = cols["cigar_off"].tolist(), cols["aux_off"].tolist()
+    cig = cols["cigar"].tolist()
+    aux = cols["aux"].tobytes()
+    pack_core = struct.Struct("<iiiBBHHHIiii").pack
+
+    def gen():
+        for i in range(len(tid)):
+            c = cig[coff[i]:coff[i + 1]]
+            p = pos[i]
+            if flag[i] & 4 or not c:
+                end = p + 1
+            else:
+                end = p + cigar_reflen(c)
+            b = reg2bin(p, max(end, p + 1)) if p >= 0 else 4680
+            name = qnames[i] + b"\0"
+            body = name
+            if c:
+                body += struct.pack("<%dI" % len(c), *c)
+            a = aux[aoff[i]:aoff[i + 1]]
+            if a:
+                if b"\t" in a:
+                    oc, a = a.split(b"\t", 1)
+                    body += b"SAZ" + a + b"\0OCZ" + oc + b"\0"
+                else:
+                    body += b"SAZ" + a + b"\0"
+            yield pack_core(32 + len(body), tid[i], p, len(name), mapq[i], b, len(c), flag[i], 0, mtid[i], mpos[i], isize[i]) + body
+    write_bam(path, contigs, gen(), aligned=aligned)

@@ -66,6 +66,7 @@ struct bk_ctx
   SdState hsd{};
   bool stream_done = false, splits_sorted = false;
   int mapq_min = 20;
+  int stream_mapq = -1;  // threshold the candidate list in d_cand was filtered with
   uint64_t cand_cap = 0, split_cap = 0, sa_cap = 0;
   // sharded sample: this table is records [rec_base, rec_base + n) of the sample; gathered tables replace the local ones
   uint64_t rec_base = 0;
@@ -283,6 +284,7 @@ void run_stream(bk_ctx *c)
   HIP_CHECK(hipStreamSynchronize(c->st));
   if (c->timing && !c->timers.empty()) c->timers.back().bytes += 48ull * c->hc.n_split;
   c->stream_done = true;
+  c->stream_mapq = c->mapq_min;
   c->splits_sorted = false;
   c->stats_done = false;
 }
@@ -383,6 +385,13 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
     ctx->rec_base = 0;
     if (mem_space == BK_MEM_DEVICE)
     {
+      // the columns are used in place: they must live on this context's GPU (a table decoded on another device would be
+      // read across xGMI, or fault without peer access)
+      hipPointerAttribute_t at;
+      if (s->n && s->tid && hipPointerGetAttributes(&at, s->tid) == hipSuccess && at.type == hipMemoryTypeDevice && at.device != ctx->device)
+        throw bk_error(BK_ERR_ARG, "bk_upload_records: BK_MEM_DEVICE table lives on device " + std::to_string(at.device) + ", context on device " +
+                                       std::to_string(ctx->device));
+      (void) hipGetLastError();
       ctx->rec = *s;
     }
     else
@@ -489,7 +498,7 @@ static void finish_groups(bk_ctx *ctx, const std::vector<uint32_t> *all_keys)
 int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, uint32_t *n_groups)
 {
   return guarded(ctx, [&] {
-    if (!ctx->stream_done || mapq_min != ctx->mapq_min)
+    if (!ctx->stream_done || mapq_min != ctx->stream_mapq)
     {
       ctx->mapq_min = mapq_min;
       run_stream(ctx);
@@ -581,6 +590,7 @@ int bk_split_breakpoints(bk_ctx *ctx, double w, uint64_t *n_valid)
 int bk_run(bk_ctx *ctx, int mapq_min, int fast, double *w_out, uint64_t *n_valid)
 {
   if (!ctx) return BK_ERR_ARG;
+  if (ctx->stream_done && mapq_min != ctx->stream_mapq) ctx->stream_done = false;  // candidates were filtered with another threshold
   ctx->mapq_min = mapq_min;
   double mean, sd;
   int rc = bk_isize_stats(ctx, &mean, &sd);

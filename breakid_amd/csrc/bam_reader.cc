@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <memory>
 #include <ctime>
 #include <cstdio>
 #include <cstdlib>
@@ -187,6 +188,11 @@ bool inflate_all(const std::vector<uint8_t> &file, std::vector<uint8_t> &out, st
     b.in_off = off + 12 + xlen;
     b.clen = (size_t) bsize + 1 - (12 + (size_t) xlen) - 8;
     b.isize = rd32(h + bsize + 1 - 4);
+    if (b.isize > 65536u)  // BGZF: a block inflates to at most 64 KiB (bgzf.h BGZF_MAX_BLOCK_SIZE); same check as the GPU scanner
+    {
+      why = "BGZF block claims more than 64 KiB of data";
+      return false;
+    }
     b.out_off = total;
     total += b.isize;
     blocks.push_back(b);
@@ -229,7 +235,7 @@ double now_s()
 }
 }  // namespace
 
-extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t errlen)
+static int bam_open_impl(const char *path, bk_bam **out, char *err, size_t errlen)
 {
   if (!path || !out) return BK_ERR_ARG;
   *out = nullptr;
@@ -251,14 +257,14 @@ extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t err
     return BK_ERR_IO;
   }
   fclose(f);
-  bk_bam *b = new bk_bam();
+  std::unique_ptr<bk_bam> guard(new bk_bam());  // freed on every error return and on an exception
+  bk_bam *b = guard.get();
   b->path = path;
   std::string why;
   const double t0 = now_s();
   if (!inflate_all(file, b->data, why))
   {
     set_err(err, errlen, why);
-    delete b;
     return BK_ERR_IO;
   }
   b->t_inflate_s = now_s() - t0;
@@ -267,7 +273,6 @@ extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t err
   if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0)
   {
     set_err(err, errlen, "not a BAM file");
-    delete b;
     return BK_ERR_IO;
   }
   size_t p = 4;
@@ -276,17 +281,16 @@ extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t err
   if (p + 4 > d.size())
   {
     set_err(err, errlen, "truncated BAM header");
-    delete b;
     return BK_ERR_IO;
   }
   uint32_t n_ref = rd32(d.data() + p);
   p += 4;
   for (uint32_t i = 0; i < n_ref; ++i)
   {
-    if (p + 4 > d.size()) { set_err(err, errlen, "truncated BAM header"); delete b; return BK_ERR_IO; }
+    if (p + 4 > d.size()) { set_err(err, errlen, "truncated BAM header"); return BK_ERR_IO; }
     uint32_t l_name = rd32(d.data() + p);
     p += 4;
-    if (p + l_name + 4 > d.size()) { set_err(err, errlen, "truncated BAM header"); delete b; return BK_ERR_IO; }
+    if (p + l_name + 4 > d.size()) { set_err(err, errlen, "truncated BAM header"); return BK_ERR_IO; }
     b->names.emplace_back((const char *) d.data() + p, l_name ? l_name - 1 : 0);
     p += l_name;
     b->lens.push_back(rd32(d.data() + p));
@@ -294,7 +298,7 @@ extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t err
   }
   for (auto &s : b->names) b->name_ptrs.push_back(s.c_str());
   b->rec_begin = p;
-  *out = b;
+  *out = guard.release();
   return BK_OK;
 }
 
@@ -416,7 +420,7 @@ void decode_chunk(const uint8_t *d, size_t dsize, size_t p, size_t r0, size_t r1
 }
 }  // namespace
 
-extern "C" int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen)
+static int bam_decode_impl(bk_bam *b, bk_soa *out, char *err, size_t errlen)
 {
   if (!b || !out) return BK_ERR_ARG;
   const double t0 = now_s();
@@ -521,4 +525,31 @@ extern "C" int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen)
   return BK_OK;
 }
 
+// no C++ exception crosses the C boundary: a corrupt file (attacker-chosen ISIZE sums, record counts) must come back as an
+// error code, not std::terminate
+template <class F> static int no_throw(char *err, size_t errlen, F &&f)
+{
+  try
+  {
+    return f();
+  }
+  catch (const std::bad_alloc &)
+  {
+    set_err(err, errlen, "out of host memory while decoding the BAM");
+    return BK_ERR_LIMIT;
+  }
+  catch (const std::exception &e)
+  {
+    set_err(err, errlen, e.what());
+    return BK_ERR_IO;
+  }
+}
+extern "C" int bk_bam_open(const char *path, bk_bam **out, char *err, size_t errlen)
+{
+  return no_throw(err, errlen, [&] { return bam_open_impl(path, out, err, errlen); });
+}
+extern "C" int bk_bam_decode(bk_bam *b, bk_soa *out, char *err, size_t errlen)
+{
+  return no_throw(err, errlen, [&] { return bam_decode_impl(b, out, err, errlen); });
+}
 extern "C" void bk_bam_close(bk_bam *b) { delete b; }

@@ -330,7 +330,7 @@ int main(int argc, char *argv[])
     }
     fclose(probe);
   }
-  if (!getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device(inp_file.c_str(), 0, &dbam, &soa, &nt, &names, &lens, err, sizeof err) == BK_OK)
+  if (!getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device(inp_file.c_str(), device, &dbam, &soa, &nt, &names, &lens, err, sizeof err) == BK_OK)
     soa_where = BK_MEM_DEVICE;
   else
   {

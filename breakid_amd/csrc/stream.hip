@@ -520,6 +520,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     __syncthreads();
     const unsigned int nc = min(s_ncand, (unsigned int) ST_CAND_CAP), ns = min(s_nsa, (unsigned int) ST_SA_CAP);
     const bool flush_c = nc && (nc >= ST_CAND_CAP / 2 || last_iter), flush_s = ns && (ns >= ST_SA_CAP / 2 || last_iter);
+    // every wave must take the flush decision from the same counts: nobody adds to the bins before all have read them
+    __syncthreads();
     if (flush_c || flush_s)
     {
       if (threadIdx.x == 0)

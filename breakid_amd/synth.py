@@ -109,6 +109,34 @@ class Dataset:
         return soa
 
 
+def fnv1a64_fixed(names) -> "np.ndarray":
+    """fnv1a64() of many equal-length byte strings at once: `names` is a (n, L) uint8 array."""
+    with np.errstate(over="ignore"):
+        h = np.full(names.shape[0], 0xCBF29CE484222325, np.uint64)
+        for j in range(names.shape[1]):
+            h = (h ^ names[:, j].astype(np.uint64)) * np.uint64(0x100000001B3)
+        h ^= h >> np.uint64(30)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(27)
+        h *= np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(31)
+    return h
+
+
+def name_records(cols):
+    """Give every record of a generated table (whose qhash column is only a pair id hash) a real read name, the 16 hex
+    digits of that hash, and re-derive qhash from the name the way the BAM decoders do.  Returns (cols', names) with names
+    an (n, 16) uint8 array; mates keep equal names.  This is how synth_gpu tables are written as BAM for the reference."""
+    q = np.ascontiguousarray(cols["qhash"]).view(np.uint64)
+    digits = np.frombuffer(b"0123456789abcdef", np.uint8)
+    names = np.empty((len(q), 16), np.uint8)
+    for j in range(16):
+        names[:, j] = digits[((q >> np.uint64(60 - 4 * j)) & np.uint64(15)).astype(np.int64)]
+    out = dict(cols)
+    out["qhash"] = fnv1a64_fixed(names)
+    return out, names
+
+
 def encode_aux(sa: str, oc: str) -> bytes:
     """Per-record aux blob of the SoA: '' (no SA), SA text, or OC text + '\\t' + SA text.
     Records without an SA tag carry nothing (the path never looks at OC then)."""
@@ -120,21 +148,28 @@ def encode_aux(sa: str, oc: str) -> bytes:
 
 
 # ----------------------------------------------------------------------------------------------
-def write_side_files(ds: Dataset, root: str, seed: int = 7, refgene_lines: Sequence[str] = ()) -> Dict[str, str]:
-    """nib dir (+ref_names.txt) and INSTALLDIR/ref_files/refGene.txt for the reference / CLI."""
+def write_side_files(ds, root: str, seed: int = 7, refgene_lines: Sequence[str] = (), max_nib_len: int = 5_000_000) -> Dict[str, str]:
+    """nib dir (+ref_names.txt) and INSTALLDIR/ref_files/refGene.txt for the reference / CLI.  `ds` is a Dataset or a
+    contig list; contigs longer than `max_nib_len` get no sequence file."""
+    contigs = ds.contigs if hasattr(ds, "contigs") else list(ds)
     nib = os.path.join(root, "nib")
     inst = os.path.join(root, "install")
     os.makedirs(nib, exist_ok=True)
     os.makedirs(os.path.join(inst, "ref_files"), exist_ok=True)
     rng = np.random.default_rng(seed)
     with open(os.path.join(nib, "ref_names.txt"), "w") as f:
-        for name, _ in ds.contigs:
+        for name, _ in contigs:
             f.write(name + "\n")
-    for name, ln in ds.contigs:
+    code_of = np.asarray([2, 1, 3, 0], np.uint8)  # "ACGT"[i] -> nib code (T=0 C=1 A=2 G=3, nibtools.cc:18-26)
+    for name, ln in contigs:
         p = os.path.join(nib, "hg19_%s.nib" % name)
-        if ln <= 5_000_000:
-            seq = "".join(np.array(list("ACGT"))[rng.integers(0, 4, ln)])
-            bamio.write_nib(p, seq)
+        if ln <= max_nib_len:
+            vals = code_of[rng.integers(0, 4, ln)]
+            if ln & 1:
+                vals = np.concatenate([vals, np.zeros(1, np.uint8)])
+            with open(p, "wb") as f:
+                f.write(np.asarray([0x6BE93D3A, ln], "<u4").tobytes())
+                f.write(((vals[0::2] << 4) | vals[1::2]).astype(np.uint8).tobytes())
     with open(os.path.join(inst, "ref_files", "refGene.txt"), "w") as f:
         for l in refgene_lines:
             f.write(l + "\n")
@@ -191,6 +226,27 @@ def make_g1(partner_flag: int = 0x100, seed: int = 12345) -> Dataset:
         ds.recs += _split_pair("s%d" % i, names, 0, 50_099, 1, 80_200, partner_flag=partner_flag)
     ds.sort()
     return ds
+
+
+def random_refgene(contigs, n_genes: int, seed: int) -> List[str]:
+    """Synthetic refGene.txt rows (UCSC table layout read by RefSeqTranscript.cc:203-260): genes with 2-6 exons spread over
+    the contigs, both strands, a few NR_ (skipped by the reference) among them."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for g in range(n_genes):
+        t = int(rng.integers(0, len(contigs)))
+        name, ln = contigs[t]
+        span = int(rng.integers(20_000, max(20_001, min(ln // 4, 2_000_000))))
+        s = int(rng.integers(1000, ln - span - 1000))
+        ne = int(rng.integers(2, 7))
+        cuts = np.sort(rng.choice(np.arange(s + 100, s + span - 100), 2 * ne - 2, replace=False))
+        starts = [s] + [int(v) for v in cuts[1::2]]
+        ends = [int(v) for v in cuts[0::2]] + [s + span]
+        acc = ("NR_%06d" if g % 11 == 10 else "NM_%06d") % (300000 + g)
+        rows.append("0\t%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%s\t%s\t0\tSG%d\tcmpl\tcmpl\t%s" % (
+            acc, name, "+-"[int(rng.integers(0, 2))], s, s + span, s + 50, s + span - 50, ne,
+            "".join("%d," % v for v in starts), "".join("%d," % v for v in ends), g, "0," * ne))
+    return rows
 
 
 G1_REFGENE = [
@@ -330,3 +386,72 @@ def make_poison() -> Dataset:
     ds.recs.append(bad)
     ds.sort()
     return ds
+
+
+# ----------------------------------------------------------------------------------------------
+def median3_killer(n: int, div: int = 1) -> np.ndarray:
+    """Musser's median-of-3 killer shifted by one element (libstdc++ samples first+1, mid, last-1): drives
+    introsort into its depth limit, so std::sort heapsorts segments of up to ~n elements.  `div` adds ties."""
+    k = n // 2
+    a = np.zeros(n, np.int64)
+    i = np.arange(k)
+    a[:k] = np.where(i % 2 == 0, i + 1, k + i + (1 if k % 2 == 0 else 0))
+    a[k:2 * k] = 2 * (i + 1)
+    return (np.concatenate([[0], a]) // div).astype(np.uint32)
+
+
+DEEP_GROUPS = [(0, 0, 1000, 1), (0, 1, 12000, 2), (1, 1, 20000, 3), (0, 2, 30000, 1), (1, 2, 39000, 3), (2, 2, 50000, 1),
+               (0, 3, 64000, 5), (1, 3, 65596, 1), (2, 3, 100000, 2), (3, 3, 300000, 2)]
+
+
+def make_deep(seed: int = 31337, groups=DEEP_GROUPS, n_proper: int = 20000, read_len: int = 100):
+    """Chromosome-pair groups whose pairs are DISCOVERED in median-of-3-killer order of the p1 coordinate, so that the
+    reference's first std::sort of every group (remove_isolated_pairs, BreakID.cc:1274) runs into introsort's depth limit
+    and heapsorts segments of ~n/2 elements: every heap size class of the sort emulation, pinned by the reference binary.
+    Discovery order = file order of the later mate (p2), so p2 positions ascend (ties keep generation order) while the p1
+    positions follow the killer sequence; everything stays within the mask distance, so the later sorts see all pairs.
+    Returns (contigs, cols, names): numpy SoA + (n, 16) uint8 read names (see name_records)."""
+    rng = np.random.default_rng(seed)
+    contigs = [("chr%d" % (i + 1), 5_000_000) for i in range(6)]
+    parts = {k: [] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "pid")}
+    pid0 = 1 << 40
+    for gi, (ta, tb, n, div) in enumerate(groups):
+        kv = median3_killer(n, div).astype(np.int64)
+        n = len(kv)
+        T = max(1, (n + 799) // 800)
+        xa = 100_000 + 400_000 * (gi % 3)
+        yb = 2_500_000 + 600_000 * (gi % 4)
+        x = xa + kv
+        y = yb + np.arange(n) // T
+        ra, rb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        fa = 0x1 | 0x40 | (0x10 if ra else 0) | (0x20 if rb else 0)
+        fb = 0x1 | 0x80 | (0x10 if rb else 0) | (0x20 if ra else 0)
+        isz = (y - x + read_len) if ta == tb else np.zeros(n, np.int64)
+        pid = pid0 + np.arange(n)
+        pid0 += n
+        for tid, pos, mtid, mpos, iz, fl in ((ta, x, tb, y, isz, fa), (tb, y, ta, x, -isz, fb)):
+            parts["tid"].append(np.full(n, tid)); parts["pos"].append(pos); parts["mtid"].append(np.full(n, mtid))
+            parts["mpos"].append(mpos); parts["isize"].append(iz); parts["flag"].append(np.full(n, fl)); parts["pid"].append(pid)
+    t = rng.integers(4, 6, n_proper)
+    ins = np.maximum(read_len + 1, np.rint(rng.normal(350, 40, n_proper)).astype(np.int64))
+    s = rng.integers(1000, 4_900_000, n_proper)
+    e = s + ins - read_len
+    pid = np.arange(n_proper)
+    for tid, pos, mpos, iz, fl in ((t, s, e, ins, 0x63), (t, e, s, -ins, 0x93)):
+        parts["tid"].append(tid); parts["pos"].append(pos); parts["mtid"].append(tid); parts["mpos"].append(mpos)
+        parts["isize"].append(iz); parts["flag"].append(np.full(n_proper, fl)); parts["pid"].append(pid)
+    c = {k: np.concatenate(v) for k, v in parts.items()}
+    order = np.argsort((c["tid"].astype(np.int64) << 32) | c["pos"].astype(np.int64), kind="stable")
+    n = len(order)
+    with np.errstate(over="ignore"):
+        q = (c["pid"][order].astype(np.uint64) ^ np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        q ^= q >> np.uint64(29)
+        q *= np.uint64(0xBF58476D1CE4E5B9)
+        q ^= q >> np.uint64(32)
+    cols = {"tid": c["tid"][order].astype(np.int32), "pos": c["pos"][order].astype(np.int32), "mtid": c["mtid"][order].astype(np.int32),
+            "mpos": c["mpos"][order].astype(np.int32), "isize": c["isize"][order].astype(np.int32), "flag": c["flag"][order].astype(np.uint16),
+            "mapq": np.full(n, 60, np.uint8), "qhash": q, "cigar_off": np.arange(n + 1, dtype=np.uint32),
+            "cigar": np.full(n, (read_len << 4), np.uint32), "aux_off": np.zeros(n + 1, np.uint32), "aux": np.zeros(0, np.uint8),
+            "target_len": np.asarray([l for _, l in contigs], np.uint32)}
+    cols, names = name_records(cols)
+    return contigs, cols, names

@@ -4,7 +4,7 @@
 // C-ABI stages must reproduce.  Output of this tool is committed as golden vectors (tests/golden/),
 // the tool itself and the reference never travel to the GPU box.
 //
-//   ref_harness stages <bam> <nib_dir> <qual> <fast 0|1> <out.txt>
+//   ref_harness stages <bam> <nib_dir> <qual> <fast 0|1> <out.txt> [nocall]   (nocall: stop after clustering, no region queries)
 //   ref_harness sa     <bam> <chr> <start> <end>            (find_sa_reads dump, BreakID.cc:868)
 //   ref_harness depth  <bam> <chr> <pos>                    (cal_single_base_depth, util_bed.cc:154)
 //   ref_harness mask   <distance>        stdin: n, then "x y" lines  (mask_pairs_chr_pos, :1813)
@@ -45,6 +45,7 @@ static int run_stages(int argc, char **argv)
   bool fast = atoi(argv[5]) != 0;
   FILE *f = fopen(argv[6], "w");
   if (!f) return 2;
+  const bool nocall = argc > 7 && string(argv[7]) == "nocall";
   stringstream sink;
   streambuf *old = cout.rdbuf(sink.rdbuf());
 
@@ -71,6 +72,7 @@ static int run_stages(int argc, char **argv)
         roots = find_cluster_pairs_enspan_ahc(chr_it.second, w, 1, 2);
       fprintf(f, "roots %d\n", roots);
       dump_pairs(f, "clustered", chr_it.first, chr_it.second, true);
+      if (nocall) continue;
       sort(chr_it.second.begin(), chr_it.second.end(), cmp_enspan_id);
       vector<bam1_t *> split_reads;
       findClusterBreakPointInfoSaTag(bam, chr_it.second, w, tmp_cluster_vec, split_reads, nib);
@@ -183,7 +185,7 @@ static int run_vote()
 int main(int argc, char **argv)
 {
   string cmd = argc > 1 ? argv[1] : "";
-  if (cmd == "stages" && argc == 7) return run_stages(argc, argv);
+  if (cmd == "stages" && (argc == 7 || argc == 8)) return run_stages(argc, argv);
   if (cmd == "sa" && argc == 6) return run_sa(argv);
   if (cmd == "depth" && argc == 5) return run_depth(argv);
   if (cmd == "mask" && argc == 3)

@@ -226,16 +226,54 @@ template <class T> void mask_pairs(std::vector<T> &v, long distance)
 template <class T> bool cmp_x(T a, T b) { return a.x < b.x; }  // BreakID.h:170-173
 template <class T> bool cmp_y(T a, T b) { return a.y < b.y; }  // BreakID.h:175-178
 
+// Diagnostic only (ora_sort_stats): which segments would libstdc++'s introsort hand to its heapsort branch
+// (depth limit 2*floor(log2 n), bits/stl_algo.h __introsort_loop)?  Replayed on a COPY with the library's own
+// partition step; the result the oracle uses always comes from the real std::sort below.
+struct SortStats
+{
+  uint64_t sorts = 0, heap_segments = 0, heap_elems = 0, max_heap = 0;
+};
+SortStats g_sort_stats;
+bool g_sort_probe = false;
+template <class It, class Cmp> void probe_loop(It first, It last, long depth, Cmp c)
+{
+  while (last - first > 16)
+  {
+    if (depth == 0)
+    {
+      uint64_t m = (uint64_t) (last - first);
+      g_sort_stats.heap_segments++;
+      g_sort_stats.heap_elems += m;
+      if (m > g_sort_stats.max_heap) g_sort_stats.max_heap = m;
+      return;
+    }
+    --depth;
+    It cut = std::__unguarded_partition_pivot(first, last, __gnu_cxx::__ops::__iter_comp_iter(c));
+    probe_loop(cut, last, depth, c);
+    last = cut;
+  }
+}
+template <class T, class Cmp> void ref_sort(std::vector<T> &v, Cmp c)
+{
+  if (g_sort_probe && v.size() > 16)
+  {
+    std::vector<T> copy(v);
+    g_sort_stats.sorts++;
+    probe_loop(copy.begin(), copy.end(), 2 * (long) std::__lg((long) copy.size()), c);
+  }
+  std::sort(v.begin(), v.end(), c);
+}
+
 // BreakID.cc:1271-1285 remove_isolated_pairs (distance is truncated to long at :1275)
 template <class T> void remove_isolated(std::vector<T> &v, double w)
 {
-  std::sort(v.begin(), v.end(), cmp_x<T>);
+  ref_sort(v, cmp_x<T>);
   mask_pairs(v, (long) w);
   if (!v.empty())
   {
-    std::sort(v.begin(), v.end(), cmp_y<T>);
+    ref_sort(v, cmp_y<T>);
     mask_pairs(v, (long) w);
-    if (!v.empty()) std::sort(v.begin(), v.end(), cmp_x<T>);
+    if (!v.empty()) ref_sort(v, cmp_x<T>);
   }
 }
 
@@ -271,7 +309,7 @@ template <class T> int fast_cluster(std::vector<T> &v, double w, int min_reads)
   v = tmp;
   tmp.clear();
   cl.clear();
-  std::sort(v.begin(), v.end(), cmp_y<T>);
+  ref_sort(v, cmp_y<T>);
   k = 1;
   n = (int) v.size();
   if (n == 0) return 0;  // reference: UB read of enspan[0]; nothing survives either way
@@ -299,7 +337,7 @@ template <class T> int fast_cluster(std::vector<T> &v, double w, int min_reads)
   }
   v = tmp;
   tmp.clear();
-  std::sort(v.begin(), v.end(), cmp_x<T>);
+  ref_sort(v, cmp_x<T>);
   std::map<std::pair<int, int>, int> key, key_cl;  // string ids "k1:k2" compare equal iff (k1,k2) equal
   for (auto &p : v) key[{p.k1, p.k2}]++;
   k = 0;
@@ -1210,6 +1248,13 @@ int ora_unit_region(ora *o, int tid, uint32_t start, uint32_t end, bk_split *out
   return (int) v.size();
 }
 uint32_t ora_unit_depth(ora *o, int tid, uint64_t pos) { return base_depth(*o, tid, pos); }
+
+// diagnostic: enable the heapsort-branch probe / read and reset its counters {sorts, heap segments, elements in them, largest}
+void ora_sort_probe(int on) { g_sort_probe = on != 0; g_sort_stats = SortStats(); }
+void ora_sort_stats(uint64_t out[4])
+{
+  out[0] = g_sort_stats.sorts; out[1] = g_sort_stats.heap_segments; out[2] = g_sort_stats.heap_elems; out[3] = g_sort_stats.max_heap;
+}
 
 uint64_t ora_text_hash(const char *s, size_t len) { return text_hash(s, len); }
 int ora_name_id(ora *o, const char *name) { return o->intern(name); }

@@ -184,3 +184,14 @@ def unit_std_sort(key, group_off):
     perm = np.zeros(len(key), np.uint32)
     L.ora_unit_std_sort(key.ctypes.data, group_off.ctypes.data, len(group_off) - 1, perm.ctypes.data)
     return perm
+
+
+def sort_probe(on=True):
+    """Diagnostic: count the segments libstdc++'s introsort hands to its heapsort branch in the oracle's sorts."""
+    lib().ora_sort_probe(int(on))
+
+
+def sort_stats():
+    out = (C.c_uint64 * 4)()
+    lib().ora_sort_stats(out)
+    return {"sorts": int(out[0]), "heap_segments": int(out[1]), "heap_elems": int(out[2]), "max_heap": int(out[3])}

@@ -18,8 +18,13 @@ def fusion_type(mask):
 def parse_stages(path):
     out = {"groups": {}, "order": []}
     cur = None
-    with open(path) as f:
-        lines = f.read().split("\n")
+    if path.endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rt") as f:
+            lines = f.read().split("\n")
+    else:
+        with open(path) as f:
+            lines = f.read().split("\n")
     i = 0
     while i < len(lines):
         t = lines[i].split()
@@ -119,3 +124,66 @@ def load_soa(golden_dir, name):
     names = [str(s) for s in z["names"]]
     contigs = list(zip(names, [int(v) for v in cols["target_len"]]))
     return contigs, cols
+
+
+# ---- digests of large stage dumps (tests/golden/*.digest.json, made by tools/make_golden_big.py) ----------------
+def _sha(rows):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(rows, dtype=np.int64)).tobytes()).hexdigest()
+
+
+SCAN_FIELDS = ("p1_flag", "p2_flag", "p1_pos", "p2_pos", "p1_mapq", "p2_mapq", "x", "y")
+
+
+def digest_from_dump(dump):
+    """Canonical per-group digests of a parsed reference stage dump (what a *.digest.json holds)."""
+    out = {"mean": float(dump["mean"]).hex(), "sd": float(dump["sd"]).hex(), "w": float(dump["w"]).hex(), "order": list(dump["order"]), "groups": {}}
+    for key in dump["order"]:
+        g = dump["groups"][key]
+        scan = [[r[k] for k in SCAN_FIELDS] + [int(r["s1"] == "-"), int(r["s2"] == "-")] for r in g["scan"]]
+        d = {"n_scan": len(scan), "scan": _sha(scan), "n_iso": len(g.get("iso", [])), "iso": _sha(g.get("iso", [])),
+             "n_clustered": len(g.get("clustered", [])), "clustered": _sha(g.get("clustered", []))}
+        if "clusters" in g:
+            d["clusters"] = [[r["id"], r["p1_mean"], r["p2_mean"], r["p1_min"], r["p1_max"], r["p2_min"], r["p2_max"], r["p1_exact"], r["p2_exact"],
+                              r["n_drp"], r["n_sr"], r["type"], int(r["depth1"]), int(r["depth2"])] for r in g["clusters"]]
+        out["groups"][key] = d
+    return out
+
+
+def digest_from_fetch(names, fetch, mean, sd, w, with_clusters=False):
+    """The same digests from product / oracle stage arrays (fetch(stage) -> (array, group_off))."""
+    from breakid_amd import abi
+    keys, _ = fetch(abi.STAGE_GROUP_KEYS)
+    gnames = [tid_name(names, int(k["p1_tid"])) + "_" + tid_name(names, int(k["p2_tid"])) for k in keys]
+    out = {"mean": float(mean).hex(), "sd": float(sd).hex(), "w": float(w).hex(), "order": gnames, "groups": {}}
+    scan, soff = fetch(abi.STAGE_SCAN)
+    iso, ioff = fetch(abi.STAGE_ISO)
+    clu, coff = fetch(abi.STAGE_CLUSTERED)
+    cl = None
+    if with_clusters:
+        cl, _ = fetch(abi.STAGE_CLUSTERS)
+        cl = cl[(cl["flags"] & 2) != 0]
+    for g, key in enumerate(gnames):
+        a = scan[soff[g]:soff[g + 1]]
+        rows = np.stack([a[k].astype(np.int64) for k in SCAN_FIELDS] + [a["p1_rev"].astype(np.int64), a["p2_rev"].astype(np.int64)], axis=1) if len(a) else []
+        i = iso[ioff[g]:ioff[g + 1]]
+        c = clu[coff[g]:coff[g + 1]]
+        d = {"n_scan": len(a), "scan": _sha(rows), "n_iso": len(i), "iso": _sha(i["id"].astype(np.int64)),
+             "n_clustered": len(c), "clustered": _sha(np.stack([c["id"].astype(np.int64), c["cluster"].astype(np.int64)], axis=1) if len(c) else [])}
+        if with_clusters:
+            rows = cl[cl["group"] == g]
+            if len(i) >= 2:
+                d["clusters"] = [[int(r["id"]), int(r["p1_mean"]), int(r["p2_mean"]), int(r["p1_min"]), int(r["p1_max"]), int(r["p2_min"]), int(r["p2_max"]),
+                                  int(r["p1_exact"]), int(r["p2_exact"]), int(r["n_drp"]), int(r["n_sr"]), fusion_type(int(r["type_mask"])),
+                                  int(r["depth1"]), int(r["depth2"])] for r in rows]
+        out["groups"][key] = d
+    return out
+
+
+def soa_sha(cols):
+    """Digest of the input table itself: the regenerated input must be the one the reference saw."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "qhash", "cigar_off", "cigar", "aux_off", "aux"):
+        h.update(np.ascontiguousarray(cols[k]).tobytes())
+    return h.hexdigest()
