@@ -36,7 +36,7 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
            "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
@@ -75,6 +75,11 @@ def lib():
         L.bk_timing_enable.argtypes = [vp, C.c_int]
         L.bk_debug_std_sort.argtypes = [vp, vp, vp, C.c_uint32, vp]
         L.bk_debug_ahc.argtypes = [vp, vp, vp, C.c_uint32, C.c_double, vp, vp, C.POINTER(C.c_uint32)]
+        L.bk_debug_points.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_double, vp, vp, C.POINTER(C.c_uint32)]
+        L.bk_debug_cigar.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+        L.bk_debug_vote.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_int32, C.c_int32, vp]
+        L.bk_debug_region.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32)]
         L.bk_shard_begin.argtypes = [vp, C.c_uint64, C.c_int]
         L.bk_shard_get_stats.argtypes = [vp, C.POINTER(abi.ShardStats)]
         L.bk_shard_set_stats.argtypes = [vp, C.POINTER(abi.ShardStats)]
@@ -240,6 +245,57 @@ class Context:
         m = C.c_uint32()
         self._check(self.L.bk_debug_ahc(self.h, x.ctypes.data, y.ctypes.data, n, float(w), idx.ctypes.data, cl.ctypes.data, C.byref(m)))
         return idx[:m.value].copy(), cl[:m.value].copy()
+
+    def debug_points(self, mode, x, y, w):
+        """mode: 'mask' | 'iso' | 'fast' (see include/breakid_hip.h: bk_debug_points)."""
+        x = np.ascontiguousarray(x, np.uint32)
+        y = np.ascontiguousarray(y, np.uint32)
+        n = len(x)
+        idx = np.zeros(max(n, 1), np.uint32)
+        cl = np.zeros(max(n, 1), np.int32)
+        m = C.c_uint32()
+        self._check(self.L.bk_debug_points(self.h, {"mask": 0, "iso": 1, "fast": 2}[mode], x.ctypes.data, y.ctypes.data, n, float(w), idx.ctypes.data,
+                                           cl.ctypes.data, C.byref(m)))
+        return idx[:m.value].copy(), cl[:m.value].copy()
+
+    def debug_cigar(self, rows):
+        """rows: (kind 't'|'b', c1 text or list of BAM words, c2 text, e) -> int32 array (n, 6)."""
+        kind = np.asarray([1 if r[0] == "b" else 0 for r in rows], np.uint8)
+        c1 = bytearray()
+        o1 = [0]
+        for r in rows:
+            while r[0] == "b" and len(c1) % 4:
+                c1 += b"\0"            # word rows start 4-byte aligned (the padding belongs to no row)
+                o1[-1] = len(c1)
+            c1 += np.asarray(r[1], np.uint32).tobytes() if r[0] == "b" else r[1].encode()
+            o1.append(len(c1))
+        c2 = bytearray()
+        o2 = [0]
+        for r in rows:
+            c2 += r[2].encode()
+            o2.append(len(c2))
+        # rows keep their own start: offsets are (start_i, end_i) pairs flattened as start of i = o[i], end of i = o[i+1] (padding shifted the start)
+        o1a, o2a = np.asarray(o1, np.uint32), np.asarray(o2, np.uint32)
+        b1 = np.frombuffer(bytes(c1) + b"\0" * 16, np.uint8)
+        b2 = np.frombuffer(bytes(c2) + b"\0" * 16, np.uint8)
+        e = np.asarray([r[3] for r in rows], np.int32)
+        out = np.zeros((len(rows), 6), np.int32)
+        self._check(self.L.bk_debug_cigar(self.h, len(rows), kind.ctypes.data, o1a.ctypes.data, b1.ctypes.data, o2a.ctypes.data, b2.ctypes.data, e.ctypes.data,
+                                          out.ctypes.data))
+        return out
+
+    def debug_vote(self, s1, s2, p1_tid, p2_tid):
+        s1 = np.ascontiguousarray(s1, abi.SPLIT)
+        s2 = np.ascontiguousarray(s2, abi.SPLIT)
+        out = np.zeros(3, np.int32)
+        self._check(self.L.bk_debug_vote(self.h, s1.ctypes.data, len(s1), s2.ctypes.data, len(s2), p1_tid, p2_tid, out.ctypes.data))
+        return tuple(int(v) for v in out)
+
+    def debug_region(self, tid, start, end, depth_pos, cap=4096):
+        out = np.zeros(cap, abi.SPLIT)
+        n, cov, depth = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.bk_debug_region(self.h, tid, start, end, depth_pos, out.ctypes.data, cap, C.byref(n), C.byref(cov), C.byref(depth)))
+        return out[:min(n.value, cap)].copy(), n.value, cov.value, depth.value
 
     def timing_enable(self, on=True):
         self._check(self.L.bk_timing_enable(self.h, int(on)))

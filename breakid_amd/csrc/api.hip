@@ -134,6 +134,15 @@ struct bk_ctx
   }
 };
 
+static RecView rec_view(const bk_ctx *ctx)
+{
+  RecView r;
+  r.n = ctx->rec.n;
+  r.tid = ctx->rec.tid; r.pos = ctx->rec.pos; r.flag = ctx->rec.flag; r.mapq = ctx->rec.mapq;
+  r.cigar_off = ctx->rec.cigar_off; r.cigar = ctx->rec.cigar;
+  return r;
+}
+
 namespace
 {
 struct Scope
@@ -871,15 +880,6 @@ int bk_shard_group_pairs(bk_ctx *ctx, const void *pairs_dev, uint64_t n, const u
   });
 }
 
-static RecView rec_view(const bk_ctx *ctx)
-{
-  RecView r;
-  r.n = ctx->rec.n;
-  r.tid = ctx->rec.tid; r.pos = ctx->rec.pos; r.flag = ctx->rec.flag; r.mapq = ctx->rec.mapq;
-  r.cigar_off = ctx->rec.cigar_off; r.cigar = ctx->rec.cigar;
-  return r;
-}
-
 int bk_shard_bp_cov(bk_ctx *ctx, double w, void **cov_dev, uint64_t *n)
 {
   return guarded(ctx, [&] {
@@ -991,6 +991,149 @@ int bk_debug_ahc(bk_ctx *ctx, const uint32_t *x, const uint32_t *y, uint32_t n, 
       HIP_CHECK(hipMemcpyAsync(cluster_out, dcl.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToHost, ctx->st));
     }
     HIP_CHECK(hipStreamSynchronize(ctx->st));
+  });
+}
+
+int bk_debug_points(bk_ctx *ctx, int mode, const uint32_t *x, const uint32_t *y, uint32_t n, double w, uint32_t *idx_out, int32_t *cluster_out, uint32_t *n_out)
+{
+  return guarded(ctx, [&] {
+    if ((n && (!x || !y)) || !idx_out || !n_out || mode < 0 || mode > 2) throw bk_error(BK_ERR_ARG, "bk_debug_points: bad argument");
+    std::vector<bk_pair> hp(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      memset(&hp[i], 0, sizeof(bk_pair));
+      hp[i].x = x[i];
+      hp[i].y = y[i];
+    }
+    DevBuf dp, dcl, dgof, dgoff;
+    PairList L;
+    std::vector<uint32_t> gof(n, 0);
+    uint64_t goff[2] = {0, n};
+    if (n) HIP_CHECK(hipMemcpy(dp.as<bk_pair>(n + 1), hp.data(), n * sizeof(bk_pair), hipMemcpyHostToDevice));
+    if (n) HIP_CHECK(hipMemcpy(dgof.as<uint32_t>(n + 1), gof.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dgoff.as<uint64_t>(2), goff, 16, hipMemcpyHostToDevice));
+    const bk_pair *pairs = dp.as<bk_pair>(n + 1);
+    // one group holding the points in the given order
+    remove_isolated_all(pairs, dgof.get<uint32_t>(), dgoff.get<uint64_t>(), 1, mode == 1 ? n : 0, w, L, ctx->cb, ctx->st);
+    if (mode != 1)
+    {
+      // the list as given (remove_isolated_all sized the buffers; fill identity order)
+      L.n = n;
+      L.ng = 1;
+      std::vector<uint32_t> iota(n);
+      std::iota(iota.begin(), iota.end(), 0u);
+      if (n) HIP_CHECK(hipMemcpy(L.idx.as<uint32_t>(n + 1), iota.data(), n * 4, hipMemcpyHostToDevice));
+      if (n) HIP_CHECK(hipMemcpy(L.gof.as<uint32_t>(n + 1), gof.data(), n * 4, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(L.goff.as<uint64_t>(2), goff, 16, hipMemcpyHostToDevice));
+      if (mode == 0)
+        debug_mask_list(pairs, L, (long) w, ctx->cb, ctx->st);
+      else
+        fast_cluster_all(pairs, L, w, dcl, ctx->cb, ctx->st);
+    }
+    *n_out = (uint32_t) L.n;
+    if (L.n)
+    {
+      HIP_CHECK(hipMemcpyAsync(idx_out, L.idx.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToHost, ctx->st));
+      if (mode == 2 && cluster_out) HIP_CHECK(hipMemcpyAsync(cluster_out, dcl.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToHost, ctx->st));
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+  });
+}
+
+int bk_debug_cigar(bk_ctx *ctx, uint32_t n, const uint8_t *kind, const uint32_t *c1_off, const uint8_t *c1, const uint32_t *c2_off, const uint8_t *c2, const int32_t *e,
+                   int32_t *out6)
+{
+  return guarded(ctx, [&] {
+    if (!n) return;
+    if (!kind || !c1_off || !c1 || !c2_off || !c2 || !e || !out6) throw bk_error(BK_ERR_ARG, "bk_debug_cigar: null argument");
+    DevBuf dk, d1o, d1, d2o, d2, de, dout;
+    HIP_CHECK(hipMemcpy(dk.as<uint8_t>(n), kind, n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d1o.as<uint32_t>(n + 1), c1_off, (n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d1.as<uint8_t>(c1_off[n] + 16), c1, c1_off[n], hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d2o.as<uint32_t>(n + 1), c2_off, (n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d2.as<uint8_t>(c2_off[n] + 16), c2, c2_off[n], hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(de.as<int32_t>(n), e, n * 4, hipMemcpyHostToDevice));
+    int32_t *o = dout.as<int32_t>(6ull * n);
+    debug_cigar(dk.get<uint8_t>(), d1o.get<uint32_t>(), d1.get<uint8_t>(), d2o.get<uint32_t>(), d2.get<uint8_t>(), de.get<int32_t>(), n, o, ctx->st);
+    HIP_CHECK(hipMemcpyAsync(out6, o, 24ull * n, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+  });
+}
+
+int bk_debug_vote(bk_ctx *ctx, const bk_split *side1, uint32_t n1, const bk_split *side2, uint32_t n2, int32_t p1_tid, int32_t p2_tid, int32_t *out3)
+{
+  return guarded(ctx, [&] {
+    if ((n1 && !side1) || (n2 && !side2) || !out3) throw bk_error(BK_ERR_ARG, "bk_debug_vote: null argument");
+    // one cluster; side-1 tuples lie in its first region, side-2 tuples in its second one; two extra tuples per side that
+    // match nothing keep find_sa_reads' "at least 2 evidence alignments" verdict out of the way (the vectors were taken
+    // from find_bp_pair directly, BreakID.cc:577-857)
+    const uint32_t pos1 = 100000, pos2 = 300000;
+    std::vector<bk_split> t;
+    auto put = [&](const bk_split *src, uint32_t n, int32_t tid, uint32_t pos, uint64_t salt) {
+      for (uint32_t i = 0; i < n + 2; ++i)
+      {
+        bk_split s;
+        if (i < n)
+          s = src[i];
+        else
+        {
+          memset(&s, 0, sizeof s);
+          s.qhash = 0xD00D000000000000ull + salt + i;
+          s.prim_chr = s.sec_chr = -7;
+        }
+        s.tid = tid;
+        s.pos = (int32_t) pos;
+        s.endpos = (int32_t) pos + 50;
+        t.push_back(s);
+      }
+    };
+    put(side1, n1, p1_tid, pos1, 0);
+    put(side2, n2, p2_tid, pos2, 1000);
+    // tuples must be in coordinate order
+    std::stable_sort(t.begin(), t.end(), [](const bk_split &a, const bk_split &b) { return (uint32_t) a.tid != (uint32_t) b.tid ? (uint32_t) a.tid < (uint32_t) b.tid : a.pos < b.pos; });
+    for (size_t i = 0; i < t.size(); ++i) t[i].rec = (uint32_t) i;
+    bk_cluster c;
+    memset(&c, 0, sizeof c);
+    c.p1_tid = p1_tid;
+    c.p2_tid = p2_tid;
+    c.p1_mean = pos1 + 10;
+    c.p2_mean = pos2 + 10;
+    c.p1_exact = 0xFFFFFFFFu;
+    c.p2_exact = -1;
+    DevBuf dt, dc, dcov;
+    HIP_CHECK(hipMemcpy(dt.as<bk_split>(t.size() + 1), t.data(), t.size() * sizeof(bk_split), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dc.as<bk_cluster>(2), &c, sizeof c, hipMemcpyHostToDevice));
+    const uint32_t cov[2] = {5, 5};
+    HIP_CHECK(hipMemcpy(dcov.as<uint32_t>(4), cov, 8, hipMemcpyHostToDevice));
+    bp_vote(dt.get<bk_split>(), t.size(), dc.get<bk_cluster>(), 1, 1000.0, 200, dcov.get<uint32_t>(), ctx->d_hdr.get<int32_t>(), ctx->bb, ctx->st);
+    uint32_t voted = 0;
+    HIP_CHECK(hipMemcpyAsync(&voted, ctx->bb.voted.get<uint32_t>(), 4, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipMemcpyAsync(&c, dc.get<bk_cluster>(), sizeof c, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    out3[0] = voted ? (int32_t) c.p1_exact : -1;
+    out3[1] = voted ? c.p2_exact : -1;
+    out3[2] = voted ? (int32_t) c.n_sr : 0;
+  });
+}
+
+int bk_debug_region(bk_ctx *ctx, int32_t tid, uint32_t start, uint32_t end, uint64_t depth_pos, bk_split *out, uint32_t cap, uint32_t *n_out, uint32_t *cov_out,
+                    uint32_t *depth_out)
+{
+  return guarded(ctx, [&] {
+    if (!ctx->stream_done) run_stream(ctx);
+    ensure_splits_sorted(ctx);
+    DevBuf dout, dres;
+    bk_split *o = dout.as<bk_split>((uint64_t) cap + 1);
+    uint32_t *res = dres.as<uint32_t>(4);
+    debug_region(rec_view(ctx), ctx->d_split.get<bk_split>(), ctx->hc.n_split, tid, start, end, (int) ctx->hc.max_span, depth_pos, o, cap, res, ctx->st);
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(h, res, 16, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    const uint32_t n = h[0] < cap ? h[0] : cap;
+    if (n && out) HIP_CHECK(hipMemcpy(out, o, n * sizeof(bk_split), hipMemcpyDeviceToHost));
+    if (n_out) *n_out = h[0];
+    if (cov_out) *cov_out = h[1];
+    if (depth_out) *depth_out = h[2];
   });
 }
 

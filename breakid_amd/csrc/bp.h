@@ -45,3 +45,6 @@ uint32_t *bp_depth_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl,
 void bp_finish(bk_cluster *cl, uint64_t ncl, const uint32_t *depth, BpBufs &b, hipStream_t st);
 void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, double w, int maxspan, const int32_t *hdr_id, BpBufs &b,
                        hipStream_t st);
+// test hook: one raw region through the product's region / verdict / depth device code (res: n tuples, coverage capped at 5, depth, poison)
+void debug_region(const RecView &r, const bk_split *sp, uint64_t nsp, int32_t tid, uint32_t start, uint32_t end, int maxspan, unsigned long long depth_pos, bk_split *out,
+                  uint32_t cap, uint32_t *res, hipStream_t st);

@@ -491,6 +491,30 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
 }
 
 // phase 4 (per shard): cal_single_base_depth partial counts for the voted clusters
+// cal_single_base_depth (util_bed.cc:154-192): records overlapping [pos-1, pos) with mapq > 0 && !DUP && PAIRED, counted by one wave;
+// bam_iter_query(idx, tid, pos - 1, pos) with the reference's uint64 -> int conversions
+__device__ uint32_t base_depth_wave(const RecView &r, int32_t tid, unsigned long long pos, int maxspan)
+{
+  int beg = (int) (pos - 1ull), end = (int) pos;
+  if (beg < 0) beg = 0;
+  if (end < beg || tid < 0) return 0;
+  Region rg;
+  rg.tid = tid;
+  rg.beg = beg;
+  rg.end = end;
+  rg.valid = true;
+  const int lane = threadIdx.x & 63;
+  uint64_t lo = rec_lower(r, tid, (long long) beg - maxspan), hi = rec_lower(r, tid, (long long) end);
+  long long acc = 0;
+  for (uint64_t i = lo + lane; i < hi; i += 64)
+  {
+    if (!in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) continue;
+    uint16_t f = r.flag[i];
+    if (r.mapq[i] > 0 && !(f & 0x400) && (f & 1)) ++acc;  // util_bed.cc:183
+  }
+  return (uint32_t) wave_sum(acc);
+}
+
 __global__ __launch_bounds__(256) void k_bp_depth(RecView r, const bk_cluster *__restrict__ cl, uint32_t ncl, int maxspan, const uint32_t *__restrict__ voted,
                                                   uint32_t *__restrict__ depth)
 {
@@ -500,39 +524,47 @@ __global__ __launch_bounds__(256) void k_bp_depth(RecView r, const bk_cluster *_
   if (voted[c])
   {
     const bk_cluster k = cl[c];
-    for (int side = 0; side < 2; ++side)
-    {
-      // bam_iter_query(idx, tid, pos - 1, pos) with uint64 -> int conversions (util_bed.cc:154-181)
-      const unsigned long long pos = side ? (unsigned long long) (long long) k.p2_exact : (unsigned long long) k.p1_exact;
-      const int32_t tid = side ? k.p2_tid : k.p1_tid;
-      int beg = (int) (pos - 1ull), end = (int) pos;
-      if (beg < 0) beg = 0;
-      uint32_t d = 0;
-      if (!(end < beg || tid < 0))
-      {
-        Region rg;
-        rg.tid = tid;
-        rg.beg = beg;
-        rg.end = end;
-        rg.valid = true;
-        const int lane = threadIdx.x & 63;
-        uint64_t lo = rec_lower(r, tid, (long long) beg - maxspan), hi = rec_lower(r, tid, (long long) end);
-        long long acc = 0;
-        for (uint64_t i = lo + lane; i < hi; i += 64)
-        {
-          if (!in_region(rg, r.tid[i], r.pos[i], rec_endpos(r, i))) continue;
-          uint16_t f = r.flag[i];
-          if (r.mapq[i] > 0 && !(f & 0x400) && (f & 1)) ++acc;  // util_bed.cc:183
-        }
-        d = (uint32_t) wave_sum(acc);
-      }
-      if (side) d2 = d; else d1 = d;
-    }
+    d1 = base_depth_wave(r, k.p1_tid, (unsigned long long) k.p1_exact, maxspan);
+    d2 = base_depth_wave(r, k.p2_tid, (unsigned long long) (long long) k.p2_exact, maxspan);
   }
   if ((threadIdx.x & 63) == 0)
   {
     depth[2 * c] = d1;
     depth[2 * c + 1] = d2;
+  }
+}
+
+// test hook (bk_debug_region): find_sa_reads (BreakID.cc:868-1037) on one raw region with the product's own device code:
+// coverage (capped at 5), the region verdict, and the evidence tuples that survive it; out[0] = n, out[1] = cov, out[2] = depth
+__global__ __launch_bounds__(64) void k_debug_region(RecView r, const bk_split *__restrict__ sp, uint64_t nsp, int32_t tid, uint32_t start, uint32_t end, int maxspan,
+                                                     unsigned long long depth_pos, bk_split *__restrict__ out, uint32_t cap, uint32_t *__restrict__ res)
+{
+  Region rg;
+  rg.tid = tid;
+  rg.beg = (int) start;  // uint32 -> int at bam_iter_query (:881)
+  rg.end = (int) end;
+  if (rg.beg < 0) rg.beg = 0;
+  rg.valid = !(rg.end < rg.beg || tid < 0);
+  const int lane = threadIdx.x & 63;
+  const uint32_t cov = region_cov(r, rg, maxspan);
+  uint64_t tlo, thi;
+  bool poison = false;
+  const bool ok = side_verdict(sp, nsp, rg, maxspan, cov, tlo, thi, poison);
+  const uint32_t depth = base_depth_wave(r, tid, depth_pos, maxspan);
+  if (lane == 0)
+  {
+    uint32_t n = 0;
+    if (ok)
+      for (uint64_t t = tlo; t < thi; ++t)
+        if (in_region(rg, sp[t].tid, sp[t].pos, sp[t].endpos))
+        {
+          if (n < cap) out[n] = sp[t];
+          ++n;
+        }
+    res[0] = n;
+    res[1] = cov;
+    res[2] = depth;
+    res[3] = poison ? 1u : 0u;
   }
 }
 __global__ __launch_bounds__(256) void k_bp_finish(bk_cluster *__restrict__ cl, uint32_t ncl, const uint32_t *__restrict__ voted, const uint32_t *__restrict__ depth)
@@ -708,4 +740,10 @@ void split_breakpoints(const RecView &r, const bk_split *sp, uint64_t nsp, bk_cl
   bp_vote(sp, nsp, cl, ncl, w, maxspan, cov, hdr_id, b, st);
   const uint32_t *depth = bp_depth_partial(r, cl, ncl, maxspan, b, st);
   bp_finish(cl, ncl, depth, b, st);
+}
+
+void debug_region(const RecView &r, const bk_split *sp, uint64_t nsp, int32_t tid, uint32_t start, uint32_t end, int maxspan, unsigned long long depth_pos, bk_split *out,
+                  uint32_t cap, uint32_t *res, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_debug_region, dim3(1), dim3(64), 0, st, r, sp, nsp, tid, start, end, maxspan, depth_pos, out, cap, res);
 }

@@ -424,3 +424,6 @@ void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &clust
   std::swap(L.goff, b.goff2);
   L.n = total;
 }
+
+// test hook: mask_pairs_chr_pos (BreakID.cc:1813-1877) on the list in its current order
+void debug_mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs &b, hipStream_t st) { mask_list(pairs, L, dist, b, st); }

@@ -61,3 +61,6 @@ void launch_sd_local(const uint16_t *flag, const int32_t *isize, uint64_t n, dou
                      unsigned long long *n_ex_out);
 void launch_sd_walk(const SdException *ex, unsigned long long n_ex, unsigned long long l_total, SdState *sd, hipStream_t st);
 void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdState *sd, SdBufs &b, hipStream_t st);
+// test hook: rows of the CIGAR table through the device CIGAR model (BAM word rows must start 4-byte aligned in c1)
+void debug_cigar(const uint8_t *kind, const uint32_t *c1_off, const uint8_t *c1, const uint32_t *c2_off, const uint8_t *c2, const int32_t *e, uint32_t n, int32_t *out,
+                 hipStream_t st);

@@ -186,6 +186,16 @@ __device__ __forceinline__ int32_t cigar_reflen_hts(const uint32_t *__restrict__
   return l;
 }
 
+// CigarRoller::is_complementary_cigar (CigarRoller.cc:323-346): c1 = this read's rolled cigar, c2 = the SA entry's raw text
+// (rolled into `sac`); both must match ([0-9]+[MS]){2} - c1 as its rolled string, c2 as written
+__device__ __forceinline__ bool is_complementary(const Roll &c1, const Roll &sac, const uint8_t *__restrict__ c2, uint32_t c2len, int e)
+{
+  if (!c1.two_op_ms() || !text_two_op_ms(c2, c2len)) return false;
+  int c1_m = c1.nmatch, c2_m = sac.nmatch;
+  int c1_s = c1.begin + c1.tail, c2_s = sac.tail + sac.begin;
+  return (c1_m <= c2_s + e && c1_m >= c2_s - e) && (c1_m + c1_s == c2_m + c2_s);
+}
+
 // Evidence tuple of one record (BreakID.cc:895-1016).  false = record yields no tuple.
 __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int32_t tid, int32_t pos, uint32_t c0, uint32_t c1,
                              int32_t endpos, bk_split &t)
@@ -240,13 +250,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
     roll_text(tmp, blob, oc_len);
   else
     tmp = own;
-  // is_complementary_cigar(sa[3], 10)  CigarRoller.cc:323-346
-  if (!tmp.two_op_ms() || !text_two_op_ms(c2, c2len)) return false;
-  {
-    int c1_m = tmp.nmatch, c2_m = sac.nmatch;
-    int c1_s = tmp.begin + tmp.tail, c2_s = sac.tail + sac.begin;
-    if (!((c1_m <= c2_s + 10 && c1_m >= c2_s - 10) && (c1_m + c1_s == c2_m + c2_s))) return false;
-  }
+  if (!is_complementary(tmp, sac, c2, c2len, 10)) return false;  // is_complementary_cigar(sa[3], 10), BreakID.cc:915
   t.rec = (uint32_t) (a.rec_base + i);
   t.tid = tid;
   t.pos = pos;
@@ -653,6 +657,25 @@ __global__ __launch_bounds__(256) void k_split_records(StreamArgs a, unsigned lo
   }
 }
 
+// test hook (bk_debug_cigar): the CIGAR model on rows of (c1 as text or BAM words, c2 text, e); out = n_ops, begin clips, end clips,
+// reference length, matches, complementary - the quantities ref_units prints for the reference's CigarRoller
+__global__ void k_debug_cigar(const uint8_t *__restrict__ kind, const uint32_t *__restrict__ c1_off, const uint8_t *__restrict__ c1, const uint32_t *__restrict__ c2_off,
+                              const uint8_t *__restrict__ c2, const int32_t *__restrict__ e, uint32_t n, int32_t *__restrict__ out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Roll r, sac;
+  const uint32_t a0 = c1_off[i], a1 = c1_off[i + 1], b0 = c2_off[i], b1 = c2_off[i + 1];
+  if (kind[i])
+    roll_bam(r, reinterpret_cast<const uint32_t *>(c1 + a0), (a1 - a0) / 4);
+  else
+    roll_text(r, c1 + a0, a1 - a0);
+  roll_text(sac, c2 + b0, b1 - b0);
+  int32_t *o = out + 6 * (size_t) i;
+  o[0] = r.n_ops; o[1] = r.begin; o[2] = r.tail; o[3] = r.reflen; o[4] = r.nmatch;
+  o[5] = is_complementary(r, sac, c2 + b0, b1 - b0, e[i]) ? 1 : 0;
+}
+
 // ---- bit-exact sd replay ----------------------------------------------------------------------------
 // The reference accumulates  long T += (v-mean)^2  with a truncation after every add (:1942-1946).
 // For T < 2^51 one step adds floor(d) unless d lies within half an ulp(T+d) below an integer, where the
@@ -826,4 +849,10 @@ void launch_sd(const uint16_t *flag, const int32_t *isize, uint64_t n, double me
   unsigned long long l_total = 0, n_ex = 0;
   launch_sd_local(flag, isize, n, mean, thr, b, st, &l_total, &n_ex);
   launch_sd_walk(b.exceptions.get<SdException>(), n_ex, l_total, sd, st);
+}
+
+void debug_cigar(const uint8_t *kind, const uint32_t *c1_off, const uint8_t *c1, const uint32_t *c2_off, const uint8_t *c2, const int32_t *e, uint32_t n, int32_t *out,
+                 hipStream_t st)
+{
+  if (n) hipLaunchKernelGGL(k_debug_cigar, dim3(cdiv(n, 64)), dim3(64), 0, st, kind, c1_off, c1, c2_off, c2, e, n, out);
 }

@@ -208,6 +208,25 @@ int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_of
  * surviving point indices in output order with their cluster numbers. */
 int bk_debug_ahc(bk_ctx *ctx, const uint32_t *x, const uint32_t *y, uint32_t n, double w, uint32_t *idx_out, int32_t *cluster_out, uint32_t *n_out);
 
+/* Test hooks that run the reference's unit vectors (tests/golden/units.json, *.regions.json) through the device code of the
+ * product path - the same kernels / device functions the stages use:
+ *   bk_debug_points  one group of points in the given order; mode 0 = mask_pairs_chr_pos (BreakID.cc:1813-1877), 1 =
+ *                    remove_isolated_pairs (:1271-1285), 2 = find_cluster_pairs_enspan_fast (:1046-1160, x-sorted input):
+ *                    surviving point indices in output order (+ cluster numbers for mode 2)
+ *   bk_debug_cigar   n rows of the CIGAR model (CigarRoller.cc / Cigar.cc): c1 = text (kind 0) or BAM words (kind 1, 4-byte
+ *                    aligned rows), c2 = SA cigar text, e = tolerance; out6 = rolled op count, begin clips, end clips,
+ *                    reference length, matches, is_complementary_cigar(c2, e) (CigarRoller.cc:323-346)
+ *   bk_debug_vote    find_bp_pair (BreakID.cc:577-857) on two tuple tables: voted (p1_bp, p2_bp, count) or (-1, -1, 0) when the
+ *                    best count stays below 2 (:446)
+ *   bk_debug_region  find_sa_reads (:868-1037) on a raw region of the uploaded table: evidence tuples that survive the region
+ *                    verdict, total_coverage capped at 5, and cal_single_base_depth (util_bed.cc:154-192) at depth_pos */
+int bk_debug_points(bk_ctx *ctx, int mode, const uint32_t *x, const uint32_t *y, uint32_t n, double w, uint32_t *idx_out, int32_t *cluster_out, uint32_t *n_out);
+int bk_debug_cigar(bk_ctx *ctx, uint32_t n, const uint8_t *kind, const uint32_t *c1_off, const uint8_t *c1, const uint32_t *c2_off, const uint8_t *c2, const int32_t *e,
+                   int32_t *out6);
+int bk_debug_vote(bk_ctx *ctx, const bk_split *side1, uint32_t n1, const bk_split *side2, uint32_t n2, int32_t p1_tid, int32_t p2_tid, int32_t *out3);
+int bk_debug_region(bk_ctx *ctx, int32_t tid, uint32_t start, uint32_t end, uint64_t depth_pos, bk_split *out, uint32_t cap, uint32_t *n_out, uint32_t *cov_out,
+                    uint32_t *depth_out);
+
 /* ---- host feed (C++ BGZF/BAM decoder -> pinned SoA); replaces htslib's reader for this path --- */
 typedef struct bk_bam bk_bam;
 uint64_t bk_qname_hash(const char *name, size_t len);
