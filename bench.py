@@ -119,26 +119,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timing = ctx.timing()
+    touched = ctx.timing_touched()
     ctx.timing_enable(False)
 
     if rank == 0:
+        PEAK = 8000.0  # GB/s, HBM3E (MI355X_MICROARCH.md)
         per = {}
-        for name, ms, by in timing:
-            a = per.setdefault(name, [0.0, 0, 0])
+        for (name, ms, by), tb in zip(timing, touched):
+            a = per.setdefault(name, [0.0, 0, 0, 0])
             a[0] += ms
             a[1] += by
             a[2] += 1
-        ks = per.get("k_stream", [0.0, 0, 1])
-        achieved = (ks[1] / 1e9) / (ks[0] / 1e3) if ks[0] > 0 else 0.0
-        # HBM traffic of k_stream comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
-        # committed under profiles/; it is only quoted for the workload it was measured on
+            a[3] += tb
+        ks = per.get("k_stream", [0.0, 0, 1, 0])
+        launches = max(1, ks[2])
+        avg_ms = ks[0] / launches
+        # roofline of the dominant HBM kernel.  `achieved` counts the bytes k_stream itself has to move per launch (23 B of
+        # fixed columns per record + CIGAR words + 48 B per candidate + 4 B per SA-bearing record: DESIGN.md 4); the SURVEY
+        # 8(d) per-record formula (39 B/record: qhash/mtid/mpos credited for every record although only candidates load them)
+        # is reported beside it as survey_formula_*, and the PMC traffic (separate rocprofv3 --pmc passes) as traffic.
+        achieved = (ks[3] / launches / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+        survey = (ks[1] / launches / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
         traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_stream.json")))
-            if abs(pm["algorithmic_bytes_per_launch"] - ks[1] / max(1, ks[2])) < 0.02 * pm["algorithmic_bytes_per_launch"]:
-                traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        for pm_name in ("r02_pmc_k_stream.json", "r01_pmc_k_stream.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
+                if abs(pm["algorithmic_bytes_per_launch"] - ks[1] / launches) < 0.02 * pm["algorithmic_bytes_per_launch"]:
+                    traffic = pm["traffic_bytes_per_launch"]
+                    break
+            except Exception:
+                pass
+        # path-level fraction (SURVEY 8(d) / BASELINE.md 3): sum of algorithmic bytes / sum of stage time / peak
+        path_ms = sum(v[0] for v in per.values()) / args.steps
+        path_bytes = sum(v[1] for v in per.values()) / args.steps
+        path_gbs = (path_bytes / 1e9) / (path_ms / 1e3) if path_ms > 0 else 0.0
+        stages = []
+        for k, v in per.items():
+            ms = v[0] / args.steps
+            b_alg, b_own = v[1] / args.steps, v[3] / args.steps
+            gbs = (b_own / 1e9) / (ms / 1e3) if ms > 0 and b_own else None
+            stages.append({"stage": k, "ms": round(ms, 3), "algorithmic_bytes": int(b_alg), "own_bytes": int(b_own) if b_own else None,
+                           "GBps": round(gbs, 1) if gbs else None, "frac": round(gbs / PEAK, 4) if gbs else None,
+                           "share_of_step": round(ms / path_ms, 4) if path_ms else None})
         value = (n_total * args.steps) / dt / 1e6
         out = {
             "metric": "M reads/s clustered+split-scanned", "value": round(value, 3), "unit": "M records/s",
@@ -147,14 +169,21 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("configs[1]: 30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" if args.workload == "wgs" else
                                     "configs[3]: targeted-panel shape, 500 fusion loci x 2000x, 20%% split reads, 10%% discordant, -%s clustering") % args.mode,
-                       "records_per_gpu": int(n), "bytes_per_record_algorithmic": round(ks[1] / max(1, ks[2]) / n, 2),
+                       "records_per_gpu": int(n), "bytes_per_record_algorithmic": round(path_bytes / max(1, n), 2),
                        "valid_clusters": int(n_valid), "w": w, "generator_s": round(gen_s, 2),
                        "sharding": ("one sample of %d records, contiguous record range per rank; RCCL all-to-all of candidates (to the owner of "
                                     "the read-name hash) and of pairs (to the owner of the chr-pair group, LPT), all-gather of tuples/cluster "
                                     "summaries, all-reduce of coverage/depth counts" % n_total) if use_shards else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_stream", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "avg_launch_ms": round(ks[0] / max(1, ks[2]), 4), "algorithmic_bytes_per_launch": int(ks[1] / max(1, ks[2]))},
+            "roofline": {"bound": "hbm", "kernel": "k_stream", "achieved": round(achieved, 1), "peak": PEAK, "unit": "GB/s",
+                         "frac": round(achieved / PEAK, 4), "traffic": traffic,
+                         "traffic_frac": round((traffic / 1e9) / (avg_ms / 1e3) / PEAK, 4) if traffic and avg_ms > 0 else None,
+                         "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(ks[3] / launches),
+                         "survey_formula_bytes_per_launch": int(ks[1] / launches), "survey_formula_frac": round(survey / PEAK, 4),
+                         "path_frac": round(path_gbs / PEAK, 5), "path_achieved": round(path_gbs, 1), "path_ms": round(path_ms, 3),
+                         "path_algorithmic_bytes": int(path_bytes),
+                         "note": "frac = k_stream own bytes / HIP-event time / 8 TB/s; path_frac = SURVEY 8(d): sum of algorithmic bytes of the whole "
+                                 "hot path / sum of stage times / 8 TB/s (the sort emulation and the joins add time, no algorithmic bytes)",
+                         "stages": stages},
             "stage_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in per.items()},
         }
         # CPU baseline: the oracle port on a bounded sample of the same workload (rank 0, N = 1 only)

@@ -35,7 +35,7 @@ def build(verbose=False):
 
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
-           "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_qname_hash",
+           "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_timing_touched", "bk_group_stats", "bk_qname_hash",
            "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
            "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
@@ -73,6 +73,7 @@ def lib():
         L.bk_timing.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
                                 C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]
         L.bk_timing_enable.argtypes = [vp, C.c_int]
+        L.bk_timing_touched.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]
         L.bk_debug_std_sort.argtypes = [vp, vp, vp, C.c_uint32, vp]
         L.bk_debug_ahc.argtypes = [vp, vp, vp, C.c_uint32, C.c_double, vp, vp, C.POINTER(C.c_uint32)]
         L.bk_debug_points.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_double, vp, vp, C.POINTER(C.c_uint32)]
@@ -307,6 +308,13 @@ class Context:
         n = C.c_int()
         self._check(self.L.bk_timing(self.h, C.byref(names), C.byref(ms), C.byref(by), C.byref(n)))
         return [(names[i].decode(), float(ms[i]), int(by[i])) for i in range(n.value)]
+
+    def timing_touched(self):
+        """bytes the kernels of each timed stage load + store themselves (call after timing(); same order)"""
+        t = C.POINTER(C.c_uint64)()
+        n = C.c_int()
+        self._check(self.L.bk_timing_touched(self.h, C.byref(t), C.byref(n)))
+        return [int(t[i]) for i in range(n.value)]
 
 
 class DeviceBamTable:

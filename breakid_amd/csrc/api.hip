@@ -38,7 +38,8 @@ struct StageTimer
 {
   std::string name;
   hipEvent_t a = nullptr, b = nullptr;
-  uint64_t bytes = 0;
+  uint64_t bytes = 0;    // SURVEY 8(d) algorithmic bytes credited to this stage (every column once for the whole path)
+  uint64_t touched = 0;  // bytes this stage's kernels themselves load + store (0 = not modelled)
 };
 }  // namespace
 
@@ -110,13 +111,14 @@ struct bk_ctx
   std::vector<bk_split> f_splits;
   std::vector<bk_cluster> f_clusters;
   std::vector<int32_t> f_gkeys;
+  std::vector<bk_group_stat> f_gstats;
 
   // timing
   bool timing = false;
   std::vector<StageTimer> timers;
   Timing tout;
 
-  void tick(const char *name, uint64_t bytes, bool begin)
+  void tick(const char *name, uint64_t bytes, bool begin, uint64_t touched = 0)
   {
     if (!timing) return;
     if (begin)
@@ -124,6 +126,7 @@ struct bk_ctx
       StageTimer t;
       t.name = name;
       t.bytes = bytes;
+      t.touched = touched;
       HIP_CHECK(hipEventCreate(&t.a));
       HIP_CHECK(hipEventCreate(&t.b));
       HIP_CHECK(hipEventRecord(t.a, st));
@@ -148,7 +151,7 @@ namespace
 struct Scope
 {
   bk_ctx *c;
-  Scope(bk_ctx *c, const char *name, uint64_t bytes = 0) : c(c) { c->tick(name, bytes, true); }
+  Scope(bk_ctx *c, const char *name, uint64_t bytes = 0, uint64_t touched = 0) : c(c) { c->tick(name, bytes, true, touched); }
   ~Scope()
   {
     try
@@ -276,7 +279,13 @@ void run_stream(bk_ctx *c)
     c->sa_cap = std::max<uint64_t>(c->sa_cap, c->hc.n_sa + 1024);
     if (attempt == 2) throw bk_error(BK_ERR_LIMIT, "stream pass: output capacity");
   }
-  if (c->timing && !c->timers.empty()) c->timers.back().bytes += 32ull * c->hc.n_cand + 4ull * c->hc.n_sa;
+  if (c->timing && !c->timers.empty())
+  {
+    c->timers.back().bytes += 32ull * c->hc.n_cand + 4ull * c->hc.n_sa;
+    // what k_stream itself moves: tid, pos, isize, flag, mapq, cigar_off, aux_off of every record (23 B), the CIGAR words (span bound),
+    // qhash + mtid + mpos only of the candidates (16 B read) + the 32-byte candidate written, 4 B per SA-bearing record index
+    c->timers.back().touched = 23ull * n + 4ull * c->rec.n_cigar_words + 48ull * c->hc.n_cand + 4ull * c->hc.n_sa;
+  }
   if (c->hc.unsorted) throw bk_error(BK_ERR_UNSORTED, "records are not coordinate sorted (the reference requires an indexed, sorted BAM)");
   // rare path: evidence tuples of the SA-bearing records (capacity = one tuple per listed record)
   if (c->hc.n_sa > c->split_cap)
@@ -291,7 +300,11 @@ void run_stream(bk_ctx *c)
   }
   HIP_CHECK(hipMemcpyAsync(&c->hc, c->d_counters.get<StreamCounters>(), sizeof(StreamCounters), hipMemcpyDeviceToHost, c->st));
   HIP_CHECK(hipStreamSynchronize(c->st));
-  if (c->timing && !c->timers.empty()) c->timers.back().bytes += 48ull * c->hc.n_split;
+  if (c->timing && !c->timers.empty())
+  {
+    c->timers.back().bytes += 48ull * c->hc.n_split;
+    c->timers.back().touched = c->timers.back().bytes + 40ull * c->hc.n_sa + 32ull * c->hc.n_split;  // + the fixed columns of the listed records, 80-byte tuples
+  }
   c->stream_done = true;
   c->stream_mapq = c->mapq_min;
   c->splits_sorted = false;
@@ -445,7 +458,7 @@ int bk_isize_stats(bk_ctx *ctx, double *mean, double *sd)
         int k = std::ilogb(bound) + 1;
         double thr = k >= 51 ? 1.0e300 : std::ldexp(1.0, k - 53);
         {
-          Scope s(ctx, "isize_sd", 6ull * ctx->rec.n);
+          Scope s(ctx, "isize_sd", 0, 6ull * ctx->rec.n);  // flag + isize re-read: already credited to the path once (k_stream)
           launch_sd(ctx->rec.flag, ctx->rec.isize, ctx->rec.n, m, thr, ctx->d_sd.get<SdState>(), ctx->sdb, ctx->st);
         }
         HIP_CHECK(hipMemcpyAsync(&ctx->hsd, ctx->d_sd.get<SdState>(), sizeof(SdState), hipMemcpyDeviceToHost, ctx->st));
@@ -994,6 +1007,39 @@ int bk_debug_ahc(bk_ctx *ctx, const uint32_t *x, const uint32_t *y, uint32_t n, 
   });
 }
 
+int bk_group_stats(bk_ctx *ctx, const bk_group_stat **out, uint32_t *n_groups)
+{
+  return guarded(ctx, [&] {
+    if (!out || !n_groups) throw bk_error(BK_ERR_ARG, "bk_group_stats: null output");
+    if (!ctx->clustered) throw bk_error(BK_ERR_ARG, "bk_group_stats: call bk_mask_and_cluster (and bk_cluster_summary) first");
+    const uint32_t ng = ctx->jr.n_groups;
+    std::vector<uint64_t> iso(ng + 1, 0), clu(ng + 1, 0);
+    std::vector<uint32_t> kmax(ng + 1, 0);
+    if (ng)
+    {
+      HIP_CHECK(hipMemcpyAsync(iso.data(), ctx->iso_goff.get<uint64_t>(), ((uint64_t) ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipMemcpyAsync(clu.data(), ctx->list.goff.get<uint64_t>(), ((uint64_t) ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
+      if (ctx->list.n && ctx->bb.kmax.p) HIP_CHECK(hipMemcpyAsync(kmax.data(), ctx->bb.kmax.get<uint32_t>(), (uint64_t) ng * 4, hipMemcpyDeviceToHost, ctx->st));
+      HIP_CHECK(hipStreamSynchronize(ctx->st));
+    }
+    ctx->f_gstats.assign(ng, bk_group_stat{});
+    for (uint32_t l = 0; l < ng; ++l)
+    {
+      const uint32_t g = ctx->lex_to_num[l];
+      bk_group_stat &o = ctx->f_gstats[l];
+      const uint32_t k = ctx->gkey_host[g];
+      o.p1_tid = (int32_t) (k / (uint32_t) (ctx->nt + 1)) - 1;
+      o.p2_tid = (int32_t) (k % (uint32_t) (ctx->nt + 1)) - 1;
+      o.n_scan = ctx->gstart_host[g + 1] - ctx->gstart_host[g];
+      o.n_isolated_removed = iso[g + 1] - iso[g];
+      o.n_clustered = clu[g + 1] - clu[g];
+      o.cluster_id_end = o.n_clustered ? kmax[g] : 0;
+    }
+    *out = ctx->f_gstats.data();
+    *n_groups = ng;
+  });
+}
+
 int bk_debug_points(bk_ctx *ctx, int mode, const uint32_t *x, const uint32_t *y, uint32_t n, double w, uint32_t *idx_out, int32_t *cluster_out, uint32_t *n_out)
 {
   return guarded(ctx, [&] {
@@ -1155,7 +1201,7 @@ int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const ui
   return guarded(ctx, [&] {
     HIP_CHECK(hipStreamSynchronize(ctx->st));
     Timing &t = ctx->tout;
-    t.names.clear(); t.ms.clear(); t.bytes.clear(); t.cnames.clear();
+    t.names.clear(); t.ms.clear(); t.bytes.clear(); t.touched.clear(); t.cnames.clear();
     for (auto &s : ctx->timers)
     {
       float v = 0;
@@ -1163,12 +1209,21 @@ int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const ui
       t.names.push_back(s.name);
       t.ms.push_back(v);
       t.bytes.push_back(s.bytes);
+      t.touched.push_back(s.touched);
     }
     for (auto &s : t.names) t.cnames.push_back(s.c_str());
     if (names) *names = t.cnames.data();
     if (ms) *ms = t.ms.data();
     if (bytes) *bytes = t.bytes.data();
     if (n) *n = (int) t.names.size();
+  });
+}
+
+int bk_timing_touched(bk_ctx *ctx, const uint64_t **touched, int *n)
+{
+  return guarded(ctx, [&] {
+    if (touched) *touched = ctx->tout.touched.data();
+    if (n) *n = (int) ctx->tout.touched.size();
   });
 }
 

@@ -115,6 +115,6 @@ struct Timing
 {
   std::vector<std::string> names;
   std::vector<float> ms;
-  std::vector<uint64_t> bytes;
+  std::vector<uint64_t> bytes, touched;
   std::vector<const char *> cnames;
 };

@@ -383,6 +383,7 @@ int main(int argc, char *argv[])
   clock_t cluster_start = clock();
   if ((rc = bk_mask_and_cluster(ctx, w, fast ? 1 : 0, &n_clustered)) != BK_OK) die(rc);
   clock_t cluster_end = clock();
+  clock_t bp_start = clock();
   if ((rc = bk_split_evidence(ctx, nullptr)) != BK_OK) die(rc);
   if ((rc = bk_cluster_summary(ctx, w, &n_clusters)) != BK_OK) die(rc);
   if (n_clustered)  // findEncompassingReadsAndBreakPointInfo opens the index for every group that reaches it (:405-416)
@@ -395,6 +396,7 @@ int main(int argc, char *argv[])
     }
   }
   if ((rc = bk_split_breakpoints(ctx, w, &n_valid)) != BK_OK) die(rc);
+  clock_t bp_end = clock();
   std::cout << "valid cluster count: " << n_valid << std::endl;
   const void *data = nullptr;
   uint64_t cnt = 0;
@@ -464,10 +466,25 @@ int main(int argc, char *argv[])
   clock_t end = clock();
   std::cout << "the fusion process of file " << inp_file << "  costs time: " << (end - start) / double(CLOCKS_PER_SEC) << " seconds" << std::endl;
   {
-    std::ofstream p((out_file + "_performance.txt").c_str());  // :175-191 (the two counters are always 0 there too)
+    // :175-191.  scan_pairs_count and after_cluster_count are never updated by the reference (always 0);
+    // removed_isolated_pair_count sums the groups that keep >= 2 pairs (:128); root_cluster_num is what the clustering of the
+    // LAST such group returned (:131-136; the reference leaves it uninitialised when no group qualifies - 0 here)
+    const bk_group_stat *gs = nullptr;
+    uint32_t ngs = 0;
+    if ((rc = bk_group_stats(ctx, &gs, &ngs)) != BK_OK) die(rc);
+    int removed_isolated_pair_count = 0, root_cluster_num = 0;
+    for (uint32_t g = 0; g < ngs; ++g)
+      if (gs[g].n_isolated_removed >= 2)
+      {
+        removed_isolated_pair_count += (int) gs[g].n_isolated_removed;
+        root_cluster_num = fast ? (gs[g].cluster_id_end ? (int) gs[g].cluster_id_end - 1 : 0)
+                                : (int) (gs[g].cluster_id_end + gs[g].n_isolated_removed - gs[g].n_clustered);
+      }
+    std::ofstream p((out_file + "_performance.txt").c_str());
     p << "scan_dist\tdiscordant pairs\tremove isolated\tafter_cluster\troot cluster\tscanning time\tcluster time\tfind breakpoint time\ttotal time" << std::endl;
-    p << w << "\t" << 0 << "\t" << (long) n_clustered << "\t" << 0 << "\t" << 0 << "\t" << (scan_end - scan_start) / double(CLOCKS_PER_SEC) << "\t"
-      << (cluster_end - cluster_start) / double(CLOCKS_PER_SEC) << "\t" << 0.0 << "\t" << (end - start) / double(CLOCKS_PER_SEC) << std::endl;
+    p << w << "\t" << 0 << "\t" << removed_isolated_pair_count << "\t" << 0 << "\t" << root_cluster_num << "\t" << (scan_end - scan_start) / double(CLOCKS_PER_SEC)
+      << "\t" << (cluster_end - cluster_start) / double(CLOCKS_PER_SEC) << "\t" << (bp_end - bp_start) / double(CLOCKS_PER_SEC) << "\t"
+      << (end - start) / double(CLOCKS_PER_SEC) << std::endl;
   }
   bk_free(ctx);
   if (bam) bk_bam_close(bam);

@@ -145,9 +145,22 @@ int bk_run(bk_ctx *ctx, int mapq_min, int fast, double *w_out, uint64_t *n_valid
  * of the same stage or bk_free.  group_off (may be NULL) receives n_groups+1 offsets for pair stages. */
 int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const uint64_t **group_off, uint32_t *n_groups);
 
+/* Per-group counts behind the reference's stage log and `_performance.txt` (BreakID.cc:119-191), groups in the reference's
+ * std::map<string> order: pairs after scan_discordant_pairs, after remove_isolated_pairs (:123), after clustering (:129-137), and
+ * one past the largest cluster number of the group (-fast numbers from 1: find_cluster_pairs_enspan_fast returned
+ * cluster_id_end - 1; AHC from 0: #roots = cluster_id_end + n_isolated_removed - n_clustered).  Valid after bk_cluster_summary. */
+typedef struct bk_group_stat {
+  int32_t p1_tid, p2_tid;
+  uint64_t n_scan, n_isolated_removed, n_clustered;
+  uint32_t cluster_id_end, pad;
+} bk_group_stat;
+int bk_group_stats(bk_ctx *ctx, const bk_group_stat **out, uint32_t *n_groups);
+
 /* per-kernel timing of the last stage calls: name/ms pairs, for bench.py's roofline leg */
 int bk_timing(bk_ctx *ctx, const char *const **names, const float **ms, const uint64_t **bytes, int *n);
 int bk_timing_enable(bk_ctx *ctx, int on);
+/* after bk_timing: bytes each timed stage's own kernels load + store (0 = not modelled), same order and count as bk_timing */
+int bk_timing_touched(bk_ctx *ctx, const uint64_t **touched, int *n);
 
 /* ---- one sample sharded over several GPUs -----------------------------------------------------
  * One context per GPU holds a contiguous range of the sample's coordinate-sorted records.  The library does the

@@ -1,0 +1,158 @@
+// TEST INFRASTRUCTURE ONLY - never built into, shipped with or loaded by the product.
+//
+// The C ABI of include/breakid_hip.h answered by the CPU oracle (oracle.cc), so that the HOST code of the product - the
+// command line (breakid_amd/csrc/breakid_main.cc: options, fatal paths, refGene / nib annotation, writers,
+// _performance.txt) and the host BAM decoder (breakid_amd/csrc/bam_reader.cc) - can be run on a box without a GPU,
+// and under AddressSanitizer / UBSan (the GPU pool has no sanitizer runs).  `make -C oracle cpucli asan ubsan` links
+// these three sources + oracle.cc into oracle/_san/BreakID_cpu{,_asan,_ubsan}; tests/test_cpu_cli.py runs them against
+// the reference's golden txt files.  The GPU feed entry point answers "no device", which is exactly what makes the CLI
+// take its host decoder.
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../include/breakid_hip.h"
+
+extern "C" {
+struct Oracle;
+typedef struct Oracle ora;
+ora *ora_new(const uint32_t *target_len, const char *const *target_name, int nt);
+void ora_free(ora *o);
+const char *ora_last_error(ora *o);
+int ora_set_records(ora *o, const bk_soa *s);
+int ora_isize_stats(ora *o, double *mean, double *sd);
+int ora_discordant_pairs(ora *o, int qual, double w);
+int ora_mask_and_cluster(ora *o, double w, int fast);
+int ora_split_evidence(ora *o);
+int ora_cluster_summary(ora *o, double w);
+int ora_split_breakpoints(ora *o, double w);
+int ora_fetch(ora *o, int stage, const void **data, uint64_t *count, const uint64_t **group_off, uint32_t *n_groups);
+}
+
+struct bk_ctx
+{
+  ora *o = nullptr;
+  std::string err;
+  std::vector<bk_group_stat> gstats;
+};
+static std::string g_init_error;
+
+static uint64_t count_of(bk_ctx *c, int stage, const uint64_t **off = nullptr, uint32_t *ng = nullptr, const void **data = nullptr)
+{
+  const void *d = nullptr;
+  uint64_t n = 0;
+  ora_fetch(c->o, stage, &d, &n, off, ng);
+  if (data) *data = d;
+  return n;
+}
+
+extern "C" {
+
+int bk_init(int, const uint32_t *target_len, const char *const *target_name, int n_targets, bk_ctx **out)
+{
+  if (!out) return BK_ERR_ARG;
+  bk_ctx *c = new bk_ctx();
+  c->o = ora_new(target_len, target_name, n_targets);
+  *out = c;
+  return BK_OK;
+}
+void bk_free(bk_ctx *c)
+{
+  if (!c) return;
+  ora_free(c->o);
+  delete c;
+}
+const char *bk_last_error(const bk_ctx *c) { return c ? (c->err.empty() ? ora_last_error(c->o) : c->err.c_str()) : g_init_error.c_str(); }
+int bk_upload_records(bk_ctx *c, const bk_soa *cols, int mem_space)
+{
+  if (mem_space != BK_MEM_HOST) return BK_ERR_ARG;
+  // the product rejects unsorted tables in its stream pass (BK_ERR_UNSORTED); same contract here
+  for (uint64_t i = 1; i < cols->n; ++i)
+  {
+    uint32_t a = (uint32_t) cols->tid[i - 1], b = (uint32_t) cols->tid[i];
+    if (a > b || (a == b && cols->pos[i - 1] > cols->pos[i]))
+    {
+      c->err = "records are not coordinate sorted (the reference requires an indexed, sorted BAM)";
+      return BK_ERR_UNSORTED;
+    }
+  }
+  return ora_set_records(c->o, cols);
+}
+int bk_isize_stats(bk_ctx *c, double *mean, double *sd) { return ora_isize_stats(c->o, mean, sd); }
+int bk_discordant_pairs(bk_ctx *c, int mapq_min, double w, uint64_t *n_pairs, uint32_t *n_groups)
+{
+  int rc = ora_discordant_pairs(c->o, mapq_min, w);
+  uint32_t ng = 0;
+  uint64_t n = count_of(c, BK_STAGE_SCAN, nullptr, &ng);
+  if (n_pairs) *n_pairs = n;
+  if (n_groups) *n_groups = ng;
+  return rc;
+}
+int bk_mask_and_cluster(bk_ctx *c, double w, int fast, uint64_t *n_clustered)
+{
+  int rc = ora_mask_and_cluster(c->o, w, fast);
+  if (n_clustered) *n_clustered = count_of(c, BK_STAGE_CLUSTERED);
+  return rc;
+}
+int bk_split_evidence(bk_ctx *c, uint64_t *n) 
+{
+  int rc = ora_split_evidence(c->o);
+  if (n) *n = count_of(c, BK_STAGE_SPLITS);
+  return rc;
+}
+int bk_cluster_summary(bk_ctx *c, double w, uint64_t *n)
+{
+  int rc = ora_cluster_summary(c->o, w);
+  if (n) *n = count_of(c, BK_STAGE_CLUSTERS);
+  return rc;
+}
+int bk_split_breakpoints(bk_ctx *c, double w, uint64_t *n_valid)
+{
+  int rc = ora_split_breakpoints(c->o, w);
+  if (rc == BK_ERR_CIGAR) c->err = "error cigar: ";
+  const void *d = nullptr;
+  uint64_t n = count_of(c, BK_STAGE_CLUSTERS, nullptr, nullptr, &d);
+  uint64_t v = 0;
+  for (uint64_t i = 0; i < n; ++i) v += (((const bk_cluster *) d)[i].flags & 2u) != 0;
+  if (n_valid) *n_valid = v;
+  return rc;
+}
+int bk_fetch(bk_ctx *c, int stage, const void **data, uint64_t *count, const uint64_t **group_off, uint32_t *n_groups)
+{
+  return ora_fetch(c->o, stage, data, count, group_off, n_groups);
+}
+int bk_group_stats(bk_ctx *c, const bk_group_stat **out, uint32_t *n_groups)
+{
+  const uint64_t *so = nullptr, *io = nullptr, *co = nullptr;
+  uint32_t ng = 0;
+  const void *keys = nullptr, *cl = nullptr;
+  count_of(c, BK_STAGE_SCAN, &so, &ng);
+  count_of(c, BK_STAGE_ISO, &io);
+  count_of(c, BK_STAGE_CLUSTERED, &co, nullptr, &cl);
+  count_of(c, BK_STAGE_GROUP_KEYS, nullptr, nullptr, &keys);
+  c->gstats.assign(ng, bk_group_stat{});
+  for (uint32_t g = 0; g < ng; ++g)
+  {
+    bk_group_stat &o = c->gstats[g];
+    o.p1_tid = ((const int32_t *) keys)[2 * g];
+    o.p2_tid = ((const int32_t *) keys)[2 * g + 1];
+    o.n_scan = so[g + 1] - so[g];
+    o.n_isolated_removed = io[g + 1] - io[g];
+    o.n_clustered = co[g + 1] - co[g];
+    int32_t mx = -1;
+    for (uint64_t p = co[g]; p < co[g + 1]; ++p) mx = std::max(mx, ((const bk_pair *) cl)[p].cluster);
+    o.cluster_id_end = (uint32_t) (mx + 1);
+  }
+  *out = c->gstats.data();
+  *n_groups = ng;
+  return BK_OK;
+}
+int bk_bam_decode_device(const char *, int, bk_bam_dev **, bk_soa *, int *, const char *const **, const uint32_t **, char *err, size_t errlen)
+{
+  if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
+  return BK_ERR_NO_DEVICE;
+}
+void bk_bam_dev_free(bk_bam_dev *) {}
+
+}  // extern "C"

@@ -20,7 +20,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("BREAKID_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # sanitizer builds: oracle/_san/liboracle_*.so
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -50,6 +50,10 @@ def test_cli_txt_outputs_match_reference(golden_dir, name, mode):
         got = open(prefix + "_params.txt").read().replace(tmp, "<TMP>").replace("out_file\t<TMP>/out", "out_file\t<TMP>/out_" + mode)
         exp = open(os.path.join(golden_dir, "%s.%s_params.txt" % (name, mode))).read()
         assert got == exp, (got, exp)
+        # _performance.txt (BreakID.cc:175-191): header + the five deterministic columns; four clock() columns follow
+        perf = open(prefix + "_performance.txt").read().split("\n")
+        exp = open(os.path.join(golden_dir, "%s.%s_perf5.txt" % (name, mode))).read().split("\n")
+        assert perf[0] == exp[0] and perf[1].split("\t")[:5] == exp[1].split("\t") and len(perf[1].split("\t")) == 9, (perf, exp)
 
 
 def test_cli_usage_errors():
@@ -59,3 +63,10 @@ def test_cli_usage_errors():
     assert r.returncode == 1 and "input- and output file is required" in r.stderr
     r = subprocess.run([BIN, "-i", "x.bam", "-o", "p"], capture_output=True, text=True)
     assert r.returncode == 1 and "nib file's root dir is required" in r.stderr
+
+
+def test_cli_fatal_paths_match_the_reference_messages():
+    """missing BAM / ref_names.txt / index / refGene.txt: the reference's messages and exit codes (BreakID.cc:1917-1921, :1399-1404,
+    :411-416, RefSeqTranscript.cc:212-216), same table as the CPU build of the host code (tests/test_cpu_cli.py)"""
+    from tests.test_cpu_cli import check_fatal_paths
+    check_fatal_paths(BIN)

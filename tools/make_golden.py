@@ -75,6 +75,10 @@ def make_dataset_golden(name, ds, refgene):
                     g.write(f.read())
             with open(prefix + "_params.txt") as f, open(os.path.join(GOLD, "%s.%s_params.txt" % (name, mode)), "w") as g:
                 g.write(f.read().replace(tmp, "<TMP>"))
+            # _performance.txt (BreakID.cc:175-191): header + the five deterministic columns (the other four are clock() times)
+            with open(prefix + "_performance.txt") as f, open(os.path.join(GOLD, "%s.%s_perf5.txt" % (name, mode)), "w") as g:
+                lines = f.read().split("\n")
+                g.write(lines[0] + "\n" + "\t".join(lines[1].split("\t")[:5]) + "\n")
         # a few raw region / depth queries (find_sa_reads / cal_single_base_depth) incl. edge regions
         queries = []
         rng = np.random.default_rng(5)
