@@ -77,7 +77,7 @@ def main():
     n = cols["n"]
 
     ctx = capi.Context(contigs, device=local_rank)
-    ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+    ptrs = abi.device_ptrs(cols)
     ctx.attach_device(ptrs, n, cols["n_cigar_words"], cols["n_aux_bytes"])
     fast = args.mode == "fast"
     n_total = n * world
@@ -201,7 +201,7 @@ def main():
             cpu_s = time.perf_counter() - t1
             # same sample through the GPU path: bit-exact check of the final calls
             sctx = capi.Context(c2, device=local_rank)
-            sctx.attach_device({k: scols[k].data_ptr() for k, _ in abi.SOA_COLS}, scols["n"], scols["n_cigar_words"], scols["n_aux_bytes"])
+            sctx.attach_device(abi.device_ptrs(scols), scols["n"], scols["n_cigar_words"], scols["n_aux_bytes"])
             gw, _ = sctx.run(qual=20, fast=fast)
             a, _ = sctx.fetch(abi.STAGE_CLUSTERS)
             b, _ = o.fetch(abi.STAGE_CLUSTERS)

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 BK_OK = 0
-BK_ERR_ARG, BK_ERR_HIP, BK_ERR_NO_DEVICE, BK_ERR_UNSORTED, BK_ERR_CIGAR, BK_ERR_IO, BK_ERR_LIMIT = -1, -2, -3, -4, -5, -6, -7
+BK_ERR_ARG, BK_ERR_HIP, BK_ERR_NO_DEVICE, BK_ERR_UNSORTED, BK_ERR_CIGAR, BK_ERR_IO, BK_ERR_LIMIT, BK_ERR_COLLISION = -1, -2, -3, -4, -5, -6, -7, -8
 BK_MEM_HOST, BK_MEM_DEVICE = 0, 1
 STAGE_SCAN, STAGE_ISO, STAGE_CLUSTERED, STAGE_SPLITS, STAGE_CLUSTERS, STAGE_GROUP_KEYS = range(6)
 
@@ -15,7 +15,7 @@ PAIR = np.dtype([("x", "<u4"), ("y", "<u4"), ("p1_pos", "<u4"), ("p2_pos", "<u4"
 SPLIT = np.dtype([("rec", "<u4"), ("tid", "<i4"), ("pos", "<i4"), ("endpos", "<i4"), ("qhash", "<u8"),
                   ("prim_chr", "<i4"), ("sec_chr", "<i4"), ("prim_start", "<u4"), ("prim_end", "<u4"),
                   ("prim_bp", "<u4"), ("sec_start", "<u4"), ("sec_end", "<u4"), ("sec_bp", "<u4"),
-                  ("prim_cigar", "<u8"), ("sec_cigar", "<u8"), ("flags", "<u4"), ("pad", "<u4")])
+                  ("prim_cigar", "<u8"), ("sec_cigar", "<u8"), ("flags", "<u4"), ("qcheck", "<u4")])
 CLUSTER = np.dtype([("group", "<u4"), ("id", "<i4"), ("p1_tid", "<i4"), ("p2_tid", "<i4"), ("p1_mean", "<u4"),
                     ("p2_mean", "<u4"), ("p1_min", "<u4"), ("p1_max", "<u4"), ("p2_min", "<u4"), ("p2_max", "<u4"),
                     ("p1_exact", "<u4"), ("p2_exact", "<i4"), ("n_drp", "<u4"), ("n_sr", "<u4"), ("depth1", "<u4"),
@@ -32,12 +32,15 @@ class Soa(C.Structure):
                 ("mpos", C.c_void_p), ("isize", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
                 ("qhash", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
                 ("aux_off", C.c_void_p), ("aux", C.c_void_p), ("n_cigar_words", C.c_uint64),
-                ("n_aux_bytes", C.c_uint64)]
+                ("n_aux_bytes", C.c_uint64), ("qcheck", C.c_void_p)]
 
 
 SOA_COLS = [("tid", np.int32), ("pos", np.int32), ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32),
             ("flag", np.uint16), ("mapq", np.uint8), ("qhash", np.uint64), ("cigar_off", np.uint32),
             ("cigar", np.uint32), ("aux_off", np.uint32), ("aux", np.uint8)]
+
+
+SOA_COLS_ALL = SOA_COLS + [("qcheck", np.uint32)]  # with the optional second read-name hash (the BAM decoders fill it)
 
 
 def soa_from_numpy(cols) -> Soa:
@@ -51,6 +54,10 @@ def soa_from_numpy(cols) -> Soa:
     assert len(cols["cigar_off"]) == s.n + 1 and len(cols["aux_off"]) == s.n + 1
     s.n_cigar_words = int(cols["cigar_off"][-1]) if s.n else 0
     s.n_aux_bytes = int(cols["aux_off"][-1]) if s.n else 0
+    q = cols.get("qcheck")  # optional column: second hash of the read names
+    if q is not None and s.n:
+        assert q.dtype == np.uint32 and q.flags["C_CONTIGUOUS"] and len(q) == s.n
+        s.qcheck = q.ctypes.data
     return s
 
 
@@ -82,3 +89,11 @@ class ShardStats(C.Structure):
 
 
 BUF_CANDIDATES, BUF_TUPLES, BUF_CLUSTERS = 0, 1, 2
+
+
+def device_ptrs(cols):
+    """torch column dict (breakid_amd.synth_gpu) -> name -> device pointer, incl. the optional qcheck column"""
+    p = {k: cols[k].data_ptr() for k, _ in SOA_COLS}
+    if "qcheck" in cols:
+        p["qcheck"] = cols["qcheck"].data_ptr()
+    return p

@@ -35,7 +35,7 @@ def build(verbose=False):
 
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
-           "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_timing_touched", "bk_group_stats", "bk_qname_hash",
+           "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_timing_touched", "bk_group_stats", "bk_qname_hash", "bk_qname_check",
            "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
            "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
@@ -102,6 +102,8 @@ def lib():
         L.bk_shard_bp_finish.argtypes = [vp, vp]
         L.bk_qname_hash.restype = C.c_uint64
         L.bk_qname_hash.argtypes = [C.c_char_p, C.c_size_t]
+        L.bk_qname_check.restype = C.c_uint32
+        L.bk_qname_check.argtypes = [C.c_char_p, C.c_size_t]
         L.bk_bam_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.bk_bam_header.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_uint32))]
         L.bk_bam_decode.argtypes = [vp, C.POINTER(abi.Soa), C.c_char_p, C.c_size_t]
@@ -157,7 +159,10 @@ class Context:
 
     def upload(self, cols):
         """cols: dict of numpy arrays (host) laid out as abi.SOA_COLS."""
+        qc = cols.get("qcheck")
         cols = {k: np.ascontiguousarray(cols[k], dtype=dt) for k, dt in abi.SOA_COLS}
+        if qc is not None:
+            cols["qcheck"] = np.ascontiguousarray(qc, dtype=np.uint32)
         for k in ("cigar", "aux"):
             if cols[k].size == 0:
                 cols[k] = np.zeros(1, cols[k].dtype)
@@ -181,6 +186,8 @@ class Context:
         s.n = n
         for name, _ in abi.SOA_COLS:
             setattr(s, name, ptrs[name])
+        if ptrs.get("qcheck"):
+            s.qcheck = ptrs["qcheck"]
         s.n_cigar_words = n_cigar_words
         s.n_aux_bytes = n_aux_bytes
         self._keep = (ptrs, s)
@@ -380,7 +387,7 @@ def decode_bam(path, keep=False):
         n = s.n
         sizes = {"cigar_off": n + 1, "aux_off": n + 1, "cigar": max(1, s.n_cigar_words), "aux": max(1, s.n_aux_bytes)}
         cols = {}
-        for name, dt in abi.SOA_COLS:
+        for name, dt in abi.SOA_COLS_ALL:
             cnt = sizes.get(name, n)
             ptr = getattr(s, name)
             if cnt == 0 or not ptr:

@@ -58,7 +58,7 @@ struct bk_ctx
 
   // records
   bk_soa rec{};
-  DevBuf col[12];
+  DevBuf col[13];
   bool have_records = false;
 
   // stream pass
@@ -253,7 +253,7 @@ void run_stream(bk_ctx *c)
     a.n = n;
     a.rec_base = c->rec_base;
     a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
-    a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash;
+    a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash; a.qcheck = c->rec.qcheck;
     a.cigar_off = c->rec.cigar_off; a.cigar = c->rec.cigar; a.aux_off = c->rec.aux_off; a.aux = c->rec.aux;
     a.mapq_min = c->mapq_min;
     a.names = c->names;
@@ -283,8 +283,8 @@ void run_stream(bk_ctx *c)
   {
     c->timers.back().bytes += 32ull * c->hc.n_cand + 4ull * c->hc.n_sa;
     // what k_stream itself moves: tid, pos, isize, flag, mapq, cigar_off, aux_off of every record (23 B), the CIGAR words (span bound),
-    // qhash + mtid + mpos only of the candidates (16 B read) + the 32-byte candidate written, 4 B per SA-bearing record index
-    c->timers.back().touched = 23ull * n + 4ull * c->rec.n_cigar_words + 48ull * c->hc.n_cand + 4ull * c->hc.n_sa;
+    // qhash + mtid + mpos (+ qcheck) only of the candidates (16-20 B read) + the 40-byte candidate written, 4 B per SA-bearing record index
+    c->timers.back().touched = 23ull * n + 4ull * c->rec.n_cigar_words + (c->rec.qcheck ? 60ull : 56ull) * c->hc.n_cand + 4ull * c->hc.n_sa;
   }
   if (c->hc.unsorted) throw bk_error(BK_ERR_UNSORTED, "records are not coordinate sorted (the reference requires an indexed, sorted BAM)");
   // rare path: evidence tuples of the SA-bearing records (capacity = one tuple per listed record)
@@ -419,10 +419,11 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
     else
     {
       const uint64_t n = s->n;
-      const void *src[12] = {s->tid, s->pos, s->mtid, s->mpos, s->isize, s->flag, s->mapq, s->qhash, s->cigar_off, s->cigar, s->aux_off, s->aux};
-      const size_t bytes[12] = {n * 4, n * 4, n * 4, n * 4, n * 4, n * 2, n, n * 8, (n + 1) * 4, s->n_cigar_words * 4, (n + 1) * 4, s->n_aux_bytes};
-      void *dst[12];
-      for (int k = 0; k < 12; ++k)
+      const void *src[13] = {s->tid, s->pos, s->mtid, s->mpos, s->isize, s->flag, s->mapq, s->qhash, s->cigar_off, s->cigar, s->aux_off, s->aux, s->qcheck};
+      const size_t bytes[13] = {n * 4, n * 4, n * 4, n * 4, n * 4, n * 2, n, n * 8, (n + 1) * 4, s->n_cigar_words * 4, (n + 1) * 4, s->n_aux_bytes,
+                                s->qcheck ? n * 4 : 0};
+      void *dst[13];
+      for (int k = 0; k < 13; ++k)
       {
         dst[k] = ctx->col[k].ensure(bytes[k] + 16);
         if (bytes[k]) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->st));
@@ -432,6 +433,7 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
       d.tid = (const int32_t *) dst[0]; d.pos = (const int32_t *) dst[1]; d.mtid = (const int32_t *) dst[2]; d.mpos = (const int32_t *) dst[3];
       d.isize = (const int32_t *) dst[4]; d.flag = (const uint16_t *) dst[5]; d.mapq = (const uint8_t *) dst[6]; d.qhash = (const uint64_t *) dst[7];
       d.cigar_off = (const uint32_t *) dst[8]; d.cigar = (const uint32_t *) dst[9]; d.aux_off = (const uint32_t *) dst[10]; d.aux = (const uint8_t *) dst[11];
+      d.qcheck = s->qcheck ? (const uint32_t *) dst[12] : nullptr;
       ctx->rec = d;
     }
     ctx->have_records = true;

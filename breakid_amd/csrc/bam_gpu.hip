@@ -155,6 +155,7 @@ struct BamCols
   uint16_t *flag;
   uint8_t *mapq;
   uint64_t *qhash;
+  uint32_t *qcheck;
   uint32_t *cigar_off, *cigar, *aux_off;
   uint8_t *aux;
 };
@@ -296,6 +297,11 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
         c.mpos[ri] = (int32_t) ld32(r + 24);
         c.isize[ri] = (int32_t) ld32(r + 28);
         c.qhash[ri] = qname_hash_dev(r + 32, l_name);
+        {
+          uint32_t ql = 0;  // bam_get_qname is a C string
+          while (ql < l_name && r[32 + ql]) ++ql;
+          c.qcheck[ri] = qname_check32(r + 32, ql);
+        }
         c.cigar_off[ri] = (uint32_t) ci;
         c.aux_off[ri] = (uint32_t) ai;
         const uint8_t *cg = r + 32 + l_name;
@@ -429,7 +435,7 @@ struct bk_bam_dev
   std::vector<std::string> names;
   std::vector<const char *> name_ptrs;
   std::vector<uint32_t> lens;
-  DevBuf tid, pos, mtid, mpos, isize, flag, mapq, qhash, cigar_off, cigar, aux_off, aux;
+  DevBuf tid, pos, mtid, mpos, isize, flag, mapq, qhash, qcheck, cigar_off, cigar, aux_off, aux;
 };
 
 namespace
@@ -811,6 +817,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
         grow_keep(h->flag, n_rec * 2, (nc + 4) * 2);
         grow_keep(h->mapq, n_rec, nc + 4);
         grow_keep(h->qhash, n_rec * 8, (nc + 4) * 8);
+        grow_keep(h->qcheck, n_rec * 4, (nc + 4) * 4);
         grow_keep(h->cigar_off, n_rec * 4, (nc + 4) * 4);
         grow_keep(h->aux_off, n_rec * 4, (nc + 4) * 4);
         cap_rec = nc;
@@ -835,6 +842,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       c.flag = h->flag.get<uint16_t>();
       c.mapq = h->mapq.get<uint8_t>();
       c.qhash = h->qhash.get<uint64_t>();
+      c.qcheck = h->qcheck.get<uint32_t>();
       c.cigar_off = h->cigar_off.get<uint32_t>();
       c.aux_off = h->aux_off.get<uint32_t>();
       c.cigar = h->cigar.get<uint32_t>();
@@ -941,7 +949,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     memset(cols, 0, sizeof *cols);
     cols->n = n_rec;
     cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
-    cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
+    cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash; cols->qcheck = c.qcheck;
     cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
     cols->n_cigar_words = (uint32_t) n_cig;
     cols->n_aux_bytes = (uint32_t) n_aux;
@@ -1023,6 +1031,7 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
   c.flag = h->flag.as<uint16_t>(n + 4);
   c.mapq = h->mapq.as<uint8_t>(n + 4);
   c.qhash = h->qhash.as<uint64_t>(n + 4);
+  c.qcheck = h->qcheck.as<uint32_t>(n + 4);
   c.cigar_off = h->cigar_off.as<uint32_t>(n + 4);
   c.aux_off = h->aux_off.as<uint32_t>(n + 4);
   c.cigar = h->cigar.as<uint32_t>(tot[1] + 4);
@@ -1035,7 +1044,7 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
   memset(cols, 0, sizeof *cols);
   cols->n = n;
   cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
-  cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
+  cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash; cols->qcheck = c.qcheck;
   cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
   cols->n_cigar_words = (uint32_t) tot[1];
   cols->n_aux_bytes = (uint32_t) tot[2];
@@ -1062,6 +1071,7 @@ struct ColumnSink
       grow_keep(h->flag, n_rec * 2, (nc + 4) * 2);
       grow_keep(h->mapq, n_rec, nc + 4);
       grow_keep(h->qhash, n_rec * 8, (nc + 4) * 8);
+        grow_keep(h->qcheck, n_rec * 4, (nc + 4) * 4);
       cap_rec = nc;
     }
     if (g > cap_cig)
@@ -1084,6 +1094,7 @@ struct ColumnSink
     c.flag = h->flag.get<uint16_t>();
     c.mapq = h->mapq.get<uint8_t>();
     c.qhash = h->qhash.get<uint64_t>();
+      c.qcheck = h->qcheck.get<uint32_t>();
     c.cigar_off = h->cigar_off.get<uint32_t>();
     c.aux_off = h->aux_off.get<uint32_t>();
     c.cigar = h->cigar.get<uint32_t>();
@@ -1097,7 +1108,7 @@ struct ColumnSink
     memset(cols, 0, sizeof *cols);
     cols->n = n_rec;
     cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
-    cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash;
+    cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash; cols->qcheck = c.qcheck;
     cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
     cols->n_cigar_words = (uint32_t) n_cig;
     cols->n_aux_bytes = (uint32_t) n_aux;

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/breakid_hip.h"
+#include "bk_hash.h"
 
 namespace
 {
@@ -112,7 +113,7 @@ struct bk_bam
   std::vector<const char *> name_ptrs;
   std::vector<uint32_t> lens;
   // decoded columns
-  HostBuf tid, pos, mtid, mpos, isize, flag, mapq, qhash, cigar_off, cigar, aux_off, aux;
+  HostBuf tid, pos, mtid, mpos, isize, flag, mapq, qhash, qcheck, cigar_off, cigar, aux_off, aux;
   double t_inflate_s = 0, t_decode_s = 0;
 };
 
@@ -131,6 +132,8 @@ extern "C" uint64_t bk_qname_hash(const char *name, size_t len)
   h ^= h >> 31;
   return h;
 }
+
+extern "C" uint32_t bk_qname_check(const char *name, size_t len) { return qname_check32((const uint8_t *) name, (uint32_t) len); }
 
 namespace
 {
@@ -329,6 +332,7 @@ struct Cols
   uint16_t *flag;
   uint8_t *mapq;
   uint64_t *qhash;
+  uint32_t *qcheck;
   uint32_t *cigar_off, *aux_off;  // chunk-local offsets first, rebased in the placement pass
 };
 
@@ -359,6 +363,7 @@ void decode_chunk(const uint8_t *d, size_t dsize, size_t p, size_t r0, size_t r1
     c.isize[i] = (int32_t) rd32(r + 28);
     size_t qn = l_name ? strnlen((const char *) r + q, l_name) : 0;  // bam_get_qname is a C string
     c.qhash[i] = bk_qname_hash((const char *) r + q, qn);
+    c.qcheck[i] = bk_qname_check((const char *) r + q, qn);
     q += l_name;
     c.cigar_off[i] = (uint32_t) o.cigar.size();
     for (uint16_t k = 0; k < n_cig; ++k) o.cigar.push_back(rd32(r + q + 4 * (size_t) k));
@@ -451,14 +456,14 @@ static int bam_decode_impl(bk_bam *b, bk_soa *out, char *err, size_t errlen)
   const bool pin = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
   (void) hipGetLastError();
   bool ok = b->tid.alloc(n * 4, pin) && b->pos.alloc(n * 4, pin) && b->mtid.alloc(n * 4, pin) && b->mpos.alloc(n * 4, pin) && b->isize.alloc(n * 4, pin) &&
-            b->flag.alloc(n * 2, pin) && b->mapq.alloc(n, pin) && b->qhash.alloc(n * 8, pin) && b->cigar_off.alloc((n + 1) * 4, pin) && b->aux_off.alloc((n + 1) * 4, pin);
+            b->flag.alloc(n * 2, pin) && b->mapq.alloc(n, pin) && b->qhash.alloc(n * 8, pin) && b->qcheck.alloc(n * 4, pin) && b->cigar_off.alloc((n + 1) * 4, pin) && b->aux_off.alloc((n + 1) * 4, pin);
   if (!ok)
   {
     set_err(err, errlen, "out of host memory for the record table");
     return BK_ERR_IO;
   }
   Cols c{b->tid.as<int32_t>(), b->pos.as<int32_t>(), b->mtid.as<int32_t>(), b->mpos.as<int32_t>(), b->isize.as<int32_t>(), b->flag.as<uint16_t>(),
-         b->mapq.as<uint8_t>(), b->qhash.as<uint64_t>(), b->cigar_off.as<uint32_t>(), b->aux_off.as<uint32_t>()};
+         b->mapq.as<uint8_t>(), b->qhash.as<uint64_t>(), b->qcheck.as<uint32_t>(), b->cigar_off.as<uint32_t>(), b->aux_off.as<uint32_t>()};
   // pass 2: chunks in parallel
   const size_t nchunks = ckpt.size();
   std::vector<ChunkOut> co(nchunks);
@@ -514,7 +519,7 @@ static int bam_decode_impl(bk_bam *b, bk_soa *out, char *err, size_t errlen)
   memset(out, 0, sizeof *out);
   out->n = n;
   out->tid = c.tid; out->pos = c.pos; out->mtid = c.mtid; out->mpos = c.mpos; out->isize = c.isize;
-  out->flag = c.flag; out->mapq = c.mapq; out->qhash = c.qhash;
+  out->flag = c.flag; out->mapq = c.mapq; out->qhash = c.qhash; out->qcheck = c.qcheck;
   out->cigar_off = c.cigar_off; out->cigar = cig; out->aux_off = c.aux_off; out->aux = aux;
   out->n_cigar_words = (uint32_t) ncig;
   out->n_aux_bytes = (uint32_t) naux;

@@ -84,8 +84,12 @@ struct Cand
   int32_t tid, pos, mtid, mpos;
   uint16_t flag;
   uint8_t mapq, pad;
+  uint32_t qcheck;  // second hash of the read name (0 = table without a qcheck column)
+  uint32_t pad2;
 };
-static_assert(sizeof(Cand) == 32, "Cand must be 32 bytes");
+static_assert(sizeof(Cand) == 40, "Cand must be 40 bytes");
+
+#include "bk_hash.h"
 
 // counters written by the stream kernel
 struct StreamCounters

@@ -293,10 +293,16 @@ __device__ bool side_verdict(const bk_split *__restrict__ sp, uint64_t nsp, cons
 
 // the same over tuples in memory: the read-name hash decides nearly every comparison, so it is looked at first and the
 // other 72 bytes of a tuple are only loaded for the pairs that share it
-__device__ __forceinline__ bool tuples_match_at(const bk_split *__restrict__ pa, const bk_split *__restrict__ pb)
+// bit 1 of *err: two tuples share the 64-bit read-name hash but not the second hash (BK_ERR_COLLISION)
+__device__ __forceinline__ bool tuples_match_at(const bk_split *__restrict__ pa, const bk_split *__restrict__ pb, uint32_t *__restrict__ err)
 {
   if (pa->qhash != pb->qhash) return false;
   const bk_split a = *pa, b = *pb;
+  if (a.qcheck != b.qcheck)
+  {
+    if (err) atomicOr(err, 2u);
+    return false;
+  }
   return ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.prim_start == b.prim_start && a.sec_start == b.sec_start &&
          a.prim_end == b.prim_end && a.sec_end == b.sec_end && a.prim_cigar == b.prim_cigar && a.sec_cigar == b.sec_cigar && a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;
 }
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void k_bp_regions(const bk_split *__restrict__
     {
       const uint64_t qi = total <= 0xFFFFFFFFull ? (uint64_t) ((uint32_t) q / (uint32_t) n2) : q / n2;
       const bk_split *pa = sp + wk.t1lo + qi, *pb = sp + wk.t2lo + (q - qi * n2);
-      if (!tuples_match_at(pa, pb)) continue;
+      if (!tuples_match_at(pa, pb, err)) continue;
       if (in_region(r1, pa->tid, pa->pos, pa->endpos) && in_region(r2, pb->tid, pb->pos, pb->endpos)) ++m;
     }
     m = wave_sum(m);
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
     const uint64_t qi = total <= 0xFFFFFFFFull ? (uint64_t) ((uint32_t) q / (uint32_t) n2) : q / n2;
     const uint64_t i = wk.t1lo + qi, j = wk.t2lo + (q - qi * n2);
     const bk_split *pa = sp + i, *pb = sp + j;
-    if (!tuples_match_at(pa, pb)) continue;
+    if (!tuples_match_at(pa, pb, nullptr)) continue;
     {
       const bk_split a = *pa, b = *pb;
       if (in_region(r1, a.tid, a.pos, a.endpos) && in_region(r2, b.tid, b.pos, b.endpos))
@@ -672,7 +678,9 @@ void bp_vote(const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, dou
   HIP_CHECK(hipMemcpyAsync(&host[0], moff + ncl, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(&host[1], err, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
-  if (host[1]) throw bk_error(BK_ERR_CIGAR, "error cigar: ");  // the reference's exit(-1), BreakID.cc:954-968
+  if (host[1] & 2u)
+    throw bk_error(BK_ERR_COLLISION, "two different read names share one 64-bit name hash (their second hashes differ): the breakpoint vote would not be the reference's");
+  if (host[1] & 1u) throw bk_error(BK_ERR_CIGAR, "error cigar: ");  // the reference's exit(-1), BreakID.cc:954-968
   if (getenv("BK_DEBUG_BP"))
   {
     std::vector<uint32_t> nm(ncl);

@@ -50,6 +50,9 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
   {
     r0 = cand[val[i]];
     r1 = cand[val[i + 1]];
+    // same 64-bit read-name hash, different second hash: two different names collided (the reference compares the strings,
+    // BreakID.cc:1424) - the run ends with BK_ERR_COLLISION rather than with a pair the reference would not form
+    if (r0.qcheck != r1.qcheck) atomicOr(err, 2u);
     if (r1.rec < r0.rec)
     {
       const Cand t = r0;
@@ -70,6 +73,7 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
       for (uint32_t k = 0; k < len; ++k)
       {
         uint32_t ci = val[i + k];
+        if (step == 0 && cand[ci].qcheck != cand[val[i]].qcheck) atomicOr(err, 2u);
         long long r = cand[ci].rec;
         if (r > last_rec && r < best_rec)
         {
@@ -267,7 +271,9 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
   unsigned long long host[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
-  if ((uint32_t) host[1]) throw bk_error(BK_ERR_LIMIT, "more than 4096 candidate records share one read-name hash");
+  if ((uint32_t) host[1] & 2u)
+    throw bk_error(BK_ERR_COLLISION, "two different read names share one 64-bit name hash (their second hashes differ): the mate join would not be the reference's");
+  if ((uint32_t) host[1] & 1u) throw bk_error(BK_ERR_LIMIT, "more than 4096 candidate records share one read-name hash");
   if (host[0] > cap) throw bk_error(BK_ERR_LIMIT, "pair capacity exceeded");  // cannot happen: one pair per two candidates
   return host[0];
 }

@@ -40,6 +40,7 @@ struct StreamArgs
   const uint16_t *flag;
   const uint8_t *mapq;
   const uint64_t *qhash;
+  const uint32_t *qcheck;  // may be null
   const uint32_t *cigar_off, *cigar, *aux_off;
   const uint8_t *aux;
   int mapq_min;

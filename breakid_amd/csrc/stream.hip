@@ -289,17 +289,28 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
   bool poison = false;
   if (oc_len)
   {
-    own_cig = fnv_bytes(blob, oc_len);
+    own_cig = cigar_text_code(blob, oc_len);
     own_end_val = (uint32_t) a_start + (uint32_t) tmp.reflen - 1u;
   }
   else
   {
-    uint64_t h = 0xCBF29CE484222325ull;  // text of the rolled BAM cigar: exactly two ops here
-    fnv_push_dec(h, own.c0);
-    fnv_push(h, (uint8_t) cls_char(own.op0));
-    fnv_push_dec(h, own.c1);
-    fnv_push(h, (uint8_t) cls_char(own.op1));
-    own_cig = h;
+    // text of the rolled BAM cigar (getCigarString): exactly two ops here
+    uint8_t txt[24];
+    uint32_t tl = 0;
+    for (int k = 0; k < 2; ++k)
+    {
+      uint32_t v = k ? own.c1 : own.c0;
+      uint8_t tmp[10];
+      int nd = 0;
+      do
+      {
+        tmp[nd++] = (uint8_t) ('0' + v % 10);
+        v /= 10;
+      } while (v);
+      while (nd) txt[tl++] = tmp[--nd];
+      txt[tl++] = (uint8_t) cls_char(k ? own.op1 : own.op0);
+    }
+    own_cig = cigar_text_code(txt, tl);
     own_end_val = (uint32_t) a_end;
   }
   if (tmp.begin != 0)
@@ -314,7 +325,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
     sa_bp = sa_end;
   else
     poison = true;
-  uint64_t sa_cig = fnv_bytes(c2, c2len);
+  uint64_t sa_cig = cigar_text_code(c2, c2len);
   if (!secondary)
   {
     t.prim_chr = own_chr; t.prim_start = (uint32_t) a_start; t.prim_end = own_end_val; t.prim_cigar = own_cig; t.prim_bp = own_bp;
@@ -327,7 +338,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
   }
   if (poison) flags |= 2u;
   t.flags = flags;
-  t.pad = 0;
+  t.qcheck = a.qcheck ? a.qcheck[i] : 0u;
   return true;
 }
 
@@ -338,7 +349,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
 // a single device counter saturates near 90 returning atomics/us (MI355X_MICROARCH.md, dequeue row),
 // which a per-wave append would hit at this record rate.
 constexpr int ST_V = 4;             // records per lane per iteration
-constexpr int ST_CAND_CAP = 768;    // LDS candidate bin (24 KiB)
+constexpr int ST_CAND_CAP = 640;    // LDS candidate bin (25 KiB of 40-byte candidates: 5 workgroups per CU still fit)
 constexpr int ST_SA_CAP = 1024;     // LDS bin of SA-bearing record indices (4 KiB)
 
 struct StreamAcc
@@ -471,6 +482,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
           cd.flag = flv[k];
           cd.mapq = mqv[k];
           cd.pad = 0;
+          cd.qcheck = a.qcheck ? a.qcheck[i] : 0u;
+          cd.pad2 = 0;
           if (slot < ST_CAND_CAP)
             s_cand[slot] = cd;
           else
@@ -537,11 +550,11 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
       if (flush_c)
       {
         const unsigned long long g = s_gbase[0];
-        // 32-byte records as two 16-byte halves per lane pair: contiguous 16 B stores across the block
-        const uint4 *src = reinterpret_cast<const uint4 *>(s_cand);
-        uint4 *dst = reinterpret_cast<uint4 *>(a.cand);
-        for (unsigned int h = threadIdx.x; h < nc * 2; h += 256)
-          if (g + (h >> 1) < a.cand_cap) dst[g * 2 + h] = src[h];
+        // 40-byte records as five 8-byte words: contiguous 8 B stores across the block
+        const uint2 *src = reinterpret_cast<const uint2 *>(s_cand);
+        uint2 *dst = reinterpret_cast<uint2 *>(a.cand);
+        for (unsigned int h = threadIdx.x; h < nc * 5; h += 256)
+          if (g + h / 5 < a.cand_cap) dst[g * 5 + h] = src[h];
       }
       if (flush_s)
       {
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     {
       Cand cd;
       cd.qhash = a.qhash[i]; cd.rec = (uint32_t) (a.rec_base + i); cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
-      cd.flag = flag; cd.mapq = mapq; cd.pad = 0;
+      cd.flag = flag; cd.mapq = mapq; cd.pad = 0; cd.qcheck = a.qcheck ? a.qcheck[i] : 0u; cd.pad2 = 0;
       unsigned long long g = atomicAdd(&a.counters->n_cand, 1ull);
       if (g < a.cand_cap) a.cand[g] = cd;
     }

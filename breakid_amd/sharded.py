@@ -5,7 +5,7 @@ and is what the 2-rank tests use).  Exchange steps:
 
   all-reduce   insert-size sums / spans                      (4 scalars)
   all-gather   sd exceptions (16 B x ~2e-4 n)                 bit-exact `long += double` replay in record order
-  all-gather   discordant candidates (32 B x ~5 % n)          mates live on other shards
+  all-gather   discordant candidates (40 B x ~5 % n)          mates live on other shards
   all-gather   split-evidence tuples (80 B x ~0.5 % n), cluster summaries of the owned chr-pair groups
   all-reduce   coverage and depth counts per cluster          range counts add over record shards
 
@@ -20,6 +20,8 @@ import torch
 import torch.distributed as dist
 
 from . import abi, capi
+
+CAND_BYTES = 40  # sizeof(Cand), csrc/bk_common.h (bk_shard_buffer reports it as elem_bytes)
 
 
 class _Raw:
@@ -151,10 +153,10 @@ class ShardedRun:
         ptr, cnt = C.c_void_p(), C.POINTER(C.c_uint64)()
         ctx._check(L.bk_shard_route_candidates(h, W, C.byref(ptr), C.byref(cnt)))
         counts = [int(cnt[d]) for d in range(W)]
-        send = tensor_from_ptr(ptr.value, sum(counts) * 32, dev)
-        mine = comm.all_to_all_var(send, [c * 32 for c in counts])
+        send = tensor_from_ptr(ptr.value, sum(counts) * CAND_BYTES, dev)
+        mine = comm.all_to_all_var(send, [c * CAND_BYTES for c in counts])
         self._keep.append(mine)
-        ctx._check(L.bk_shard_set_buffer(h, abi.BUF_CANDIDATES, C.c_void_p(mine.data_ptr() if mine.numel() else 0), mine.numel() // 32))
+        ctx._check(L.bk_shard_set_buffer(h, abi.BUF_CANDIDATES, C.c_void_p(mine.data_ptr() if mine.numel() else 0), mine.numel() // CAND_BYTES))
         ctx.discordant_pairs(qual, w)  # joins the read names this rank owns
         starts, ng, keys = C.POINTER(C.c_uint64)(), C.c_uint32(), C.POINTER(C.c_uint32)()
         ctx._check(L.bk_shard_group_sizes(h, C.byref(starts), C.byref(ng)))

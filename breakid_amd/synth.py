@@ -41,6 +41,22 @@ def fnv1a64(name: bytes) -> int:
     return h
 
 
+def qname_check(name: bytes) -> int:
+    """second, independent 32-bit hash of a read name (csrc/bk_hash.h: qname_check32 = bk_qname_check); never 0"""
+    M = 0xFFFFFFFF
+    h = (0x811C9DC5 ^ ((len(name) * 0x9E3779B1) & M)) & M
+    for b in name:
+        h = ((h ^ b) * 0x01000193) & M
+        h = ((h << 13) | (h >> 19)) & M
+        h = (h * 5 + 0xE6546B64) & M
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M
+    h ^= h >> 16
+    return h or 1
+
+
 @dataclass
 class Rec:
     qname: str
@@ -85,7 +101,7 @@ class Dataset:
         soa = {
             "tid": np.empty(n, np.int32), "pos": np.empty(n, np.int32), "mtid": np.empty(n, np.int32),
             "mpos": np.empty(n, np.int32), "isize": np.empty(n, np.int32), "flag": np.empty(n, np.uint16),
-            "mapq": np.empty(n, np.uint8), "qhash": np.empty(n, np.uint64),
+            "mapq": np.empty(n, np.uint8), "qhash": np.empty(n, np.uint64), "qcheck": np.empty(n, np.uint32),
             "cigar_off": np.zeros(n + 1, np.uint32), "aux_off": np.zeros(n + 1, np.uint32),
         }
         cig: List[int] = []
@@ -99,6 +115,7 @@ class Dataset:
             soa["flag"][i] = r.flag
             soa["mapq"][i] = r.mapq
             soa["qhash"][i] = fnv1a64(r.qname.encode())
+            soa["qcheck"][i] = qname_check(r.qname.encode())
             cig.extend(bamio.parse_cigar(r.cigar))
             soa["cigar_off"][i + 1] = len(cig)
             aux += encode_aux(r.sa, r.oc)
@@ -134,7 +151,25 @@ def name_records(cols):
         names[:, j] = digits[((q >> np.uint64(60 - 4 * j)) & np.uint64(15)).astype(np.int64)]
     out = dict(cols)
     out["qhash"] = fnv1a64_fixed(names)
+    out["qcheck"] = qname_check_fixed(names)
     return out, names
+
+
+def qname_check_fixed(names) -> "np.ndarray":
+    """qname_check() of many equal-length byte strings at once: `names` is a (n, L) uint8 array."""
+    with np.errstate(over="ignore"):
+        n, L = names.shape
+        h = np.full(n, (0x811C9DC5 ^ ((L * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF, np.uint32)
+        for j in range(L):
+            h = (h ^ names[:, j].astype(np.uint32)) * np.uint32(0x01000193)
+            h = (h << np.uint32(13)) | (h >> np.uint32(19))
+            h = h * np.uint32(5) + np.uint32(0xE6546B64)
+        h ^= h >> np.uint32(16)
+        h *= np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+    return np.where(h == 0, np.uint32(1), h).astype(np.uint32)
 
 
 def encode_aux(sa: str, oc: str) -> bytes:

@@ -105,6 +105,13 @@ def _mix64(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _qcheck_of(pid: torch.Tensor, salt: int) -> torch.Tensor:
+    """the qcheck column of a generated table: a second hash of the pair id (mates share it), never 0; int32 bits == uint32"""
+    q = (_mix64(pid ^ (salt ^ 0x5851F42D4C957F2D)) >> 32) & 0xFFFFFFFF
+    q = torch.where(q == 0, torch.ones_like(q), q)
+    return torch.where(q >= (1 << 31), q - (1 << 32), q).to(torch.int32)
+
+
 def make_wgs(n_records: int, seed: int, device, contigs=HG19, read_len=150, disc_frac=0.05, pairs_per_locus=50,
              split_every=2, splits_per_locus=8, jitter=400, ins_mean=350.0, ins_sd=40.0):
     """Returns (contigs, cols) with cols a dict of torch tensors on `device` (see abi.SOA_COLS) plus
@@ -146,7 +153,10 @@ def make_wgs(n_records: int, seed: int, device, contigs=HG19, read_len=150, disc
     m = torch.full((P,), 60, device=device, dtype=torch.uint8)
     c_mapq = cat(m, m, sp["mapq"], torch.uint8)
     salt = ((seed & 0x7FFF) << 48) ^ 0x1E3779B97F4A7C15
-    c_qh = _mix64(cat(pid, pid, sp["pairid"], torch.int64) ^ salt)
+    c_pid = cat(pid, pid, sp["pairid"], torch.int64)
+    c_qh = _mix64(c_pid ^ salt)
+    c_qc = _qcheck_of(c_pid, salt)
+    del c_pid
     w150 = torch.full((P,), (read_len << 4), device=device, dtype=torch.int64)
     c_c0 = cat(w150, w150, sp["c0"].astype(np.int64), torch.int64)
     zeros = torch.zeros(P, device=device, dtype=torch.int64)
@@ -166,7 +176,8 @@ def make_wgs(n_records: int, seed: int, device, contigs=HG19, read_len=150, disc
     out["flag"] = take(c_flag).to(torch.int16)  # same bits as uint16
     out["mapq"] = take(c_mapq)
     out["qhash"] = take(c_qh)  # int64 bits == uint64 hash
-    del c_flag, c_mapq, c_qh
+    out["qcheck"] = take(c_qc)
+    del c_flag, c_mapq, c_qh, c_qc
     c0 = take(c_c0)
     c1 = take(c_c1)
     ncig = 1 + (c1 != 0).to(torch.int64)
@@ -215,9 +226,9 @@ def make_wgs(n_records: int, seed: int, device, contigs=HG19, read_len=150, disc
 
 def to_numpy_cols(cols):
     """Device table -> host numpy dict in the abi.SOA_COLS layout (for the oracle / cpu_baseline leg)."""
-    view = {"flag": np.uint16, "qhash": np.uint64, "cigar_off": np.uint32, "cigar": np.uint32, "aux_off": np.uint32}
+    view = {"flag": np.uint16, "qhash": np.uint64, "cigar_off": np.uint32, "cigar": np.uint32, "aux_off": np.uint32, "qcheck": np.uint32}
     out = {}
-    for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "qhash", "cigar_off", "cigar", "aux_off", "aux"):
+    for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "qhash", "cigar_off", "cigar", "aux_off", "aux") + (("qcheck",) if "qcheck" in cols else ()):
         a = cols[k].cpu().numpy()
         out[k] = a.view(view[k]) if k in view else a
     out["cigar"] = out["cigar"][: cols["n_cigar_words"]]
@@ -376,7 +387,10 @@ def _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len):
     m = torch.full((P,), 60, device=device, dtype=torch.uint8)
     c_mapq = cat(m, m, sp["mapq"].astype(np.uint8), torch.uint8)
     salt = ((seed & 0x7FFF) << 48) ^ 0x1E3779B97F4A7C15
-    c_qh = _mix64(cat(pid, pid, sp["pairid"].astype(np.int64), torch.int64) ^ salt)
+    c_pid = cat(pid, pid, sp["pairid"].astype(np.int64), torch.int64)
+    c_qh = _mix64(c_pid ^ salt)
+    c_qc = _qcheck_of(c_pid, salt)
+    del c_pid
     w150 = torch.full((P,), (read_len << 4), device=device, dtype=torch.int64)
     c_c0 = cat(w150, w150, sp["c0"].astype(np.int64), torch.int64)
     zeros = torch.zeros(P, device=device, dtype=torch.int64)
@@ -390,6 +404,7 @@ def _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len):
     out["flag"] = take(c_flag).to(torch.int16)
     out["mapq"] = take(c_mapq)
     out["qhash"] = take(c_qh)
+    out["qcheck"] = take(c_qc)
     c0 = take(c_c0)
     c1 = take(c_c1)
     ncig = 1 + (c1 != 0).to(torch.int64)

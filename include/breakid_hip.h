@@ -31,6 +31,7 @@ extern "C" {
 #define BK_ERR_CIGAR (-5)     /* the reference's "error cigar" exit(-1) (src/BreakID.cc:954-968) */
 #define BK_ERR_IO (-6)        /* BAM decode errors (bk_bam_*) */
 #define BK_ERR_LIMIT (-7)     /* an internal capacity was exceeded (text says which) */
+#define BK_ERR_COLLISION (-8) /* two different read names (or contig names) share a hash: the call would not be the reference's */
 
 #define BK_MEM_HOST 0
 #define BK_MEM_DEVICE 1
@@ -43,6 +44,11 @@ typedef struct bk_ctx bk_ctx;
  *   aux_off[i]..aux_off[i+1]      aux blob of record i: empty when the record has no SA:Z tag,
  *                                 else the SA text, or  OC-text '\t' SA-text  when an OC:Z tag exists
  *   qhash                         64-bit hash of the read name (bk_qname_hash) used for the qname joins
+ *   qcheck                        optional (may be NULL): second, independent 32-bit hash of the read name
+ *                                 (bk_qname_check, never 0).  The reference compares read names as strings
+ *                                 (BreakID.cc:1424, :627-637); with this column every equal-qhash decision of the mate join
+ *                                 and of the breakpoint vote is verified, and a mismatch ends the run with BK_ERR_COLLISION
+ *                                 instead of a silently different call.  The BAM decoders (bk_bam_*) fill it.
  */
 typedef struct bk_soa {
   uint64_t n;
@@ -56,6 +62,7 @@ typedef struct bk_soa {
   const uint8_t *aux;        /* aux_off[n] bytes */
   uint64_t n_cigar_words;    /* = cigar_off[n] (given so that device-resident tables need no read-back) */
   uint64_t n_aux_bytes;      /* = aux_off[n] */
+  const uint32_t *qcheck;    /* n entries or NULL */
 } bk_soa;
 
 /* One discordant pair = the numeric content of `discordant_pair` (src/BreakID.h:39-58). */
@@ -72,8 +79,10 @@ typedef struct bk_pair {
 } bk_pair;
 
 /* One split-read evidence tuple = numeric content of `split_align_pair` (src/BreakID.h:116-133).
- * Chromosome names are interned (ids < n_targets are header names); CIGAR strings are carried as
- * 64-bit hashes of their text because the reference only compares them for equality. */
+ * Chromosome names are interned (ids < n_targets are header names).  CIGAR strings are only compared for equality by the
+ * reference, so they travel as 64-bit codes: a text of the form <n><M|S><n><M|S> (every text that can reach a tuple: both
+ * sides pass the ([0-9]+[MS]){2} gate, CigarRoller.cc:326) is encoded EXACTLY (bit 63 set; counts < 2^28, up to 3 leading
+ * zeros per count), anything else as a 63-bit hash of the text (bit 63 clear). */
 typedef struct bk_split {
   uint32_t rec;
   int32_t tid, pos, endpos;  /* of the record itself: 0-based pos, bam_endpos (sam.c:344-350) */
@@ -82,7 +91,7 @@ typedef struct bk_split {
   uint32_t prim_start, prim_end, prim_bp, sec_start, sec_end, sec_bp;
   uint64_t prim_cigar, sec_cigar;
   uint32_t flags;            /* bit0 = secondary (flag & 0x100); bit1 = "error cigar" record */
-  uint32_t pad;
+  uint32_t qcheck;           /* bk_qname_check of the read name (0 when the table has no qcheck column) */
 } bk_split;
 
 #define BK_TYPE_DIFF_CHR 1u
@@ -180,7 +189,7 @@ typedef struct bk_shard_stats {
   uint32_t vmax, max_span;
   uint64_t n_cand, n_split;
 } bk_shard_stats;
-#define BK_BUF_CANDIDATES 0 /* 32-byte candidates of the discordant filter */
+#define BK_BUF_CANDIDATES 0 /* 40-byte candidates of the discordant filter */
 #define BK_BUF_TUPLES 1     /* bk_split, unsorted */
 #define BK_BUF_CLUSTERS 2   /* bk_cluster of the groups this rank owns */
 int bk_shard_begin(bk_ctx *ctx, uint64_t rec_base, int mapq_min);
@@ -199,7 +208,7 @@ int bk_shard_own_groups(bk_ctx *ctx, const uint8_t *own, uint32_t n_groups);
  *   bk_shard_group_keys + bk_shard_group_sizes -> all-gather of (key, size) -> owner per chr-pair key (LPT on the totals)
  *   bk_shard_route_pairs -> all-to-all -> bk_shard_group_pairs: the table of exactly the groups this rank owns, `group`
  *     ordinals global; then bk_mask_and_cluster, bk_cluster_summary and the gathers / reductions as above. */
-int bk_shard_route_candidates(bk_ctx *ctx, uint32_t world, void **dev, const uint64_t **counts); /* 32-byte candidates ordered by destination; counts[world] */
+int bk_shard_route_candidates(bk_ctx *ctx, uint32_t world, void **dev, const uint64_t **counts); /* 40-byte candidates ordered by destination; counts[world] */
 int bk_shard_group_keys(bk_ctx *ctx, const uint32_t **keys, uint32_t *n_groups);                /* (p1_tid+1)*(n_targets+1)+(p2_tid+1) per group */
 int bk_shard_route_pairs(bk_ctx *ctx, const uint32_t *dest_of_group, uint32_t n_groups, uint32_t world, void **dev, const uint64_t **counts); /* bk_pair rows ordered by destination */
 int bk_shard_group_pairs(bk_ctx *ctx, const void *pairs_dev, uint64_t n, const uint32_t *all_keys, uint32_t n_all_keys);
@@ -243,6 +252,7 @@ int bk_debug_region(bk_ctx *ctx, int32_t tid, uint32_t start, uint32_t end, uint
 /* ---- host feed (C++ BGZF/BAM decoder -> pinned SoA); replaces htslib's reader for this path --- */
 typedef struct bk_bam bk_bam;
 uint64_t bk_qname_hash(const char *name, size_t len);
+uint32_t bk_qname_check(const char *name, size_t len); /* the qcheck column: independent of bk_qname_hash, folds the length in, never 0 */
 int bk_bam_open(const char *path, bk_bam **out, char *err, size_t errlen);
 int bk_bam_header(const bk_bam *b, int *n_targets, const char *const **names, const uint32_t **lens);
 /* decode all records into a SoA owned by the bk_bam (pinned when a GPU is present) */

@@ -170,7 +170,32 @@ bool is_complementary(const Roller &c1, const char *c2, size_t c2len, int e)
   return (c1_m <= c2_s + e && c1_m >= c2_s - e) && (c1_m + c1_s == c2_m + c2_s);
 }
 
-uint64_t text_hash(const char *s, size_t len)  // same function as the product's cigar-text hash
+// 64-bit code of a CIGAR text as the bk_split fields carry it (include/breakid_hip.h): texts of the form <n><M|S><n><M|S>
+// are encoded exactly (bit 63 set), anything else as a 63-bit FNV-1a of the text.  The reference compares the strings.
+uint64_t cigar_code(const char *t, size_t len)
+{
+  const unsigned char *s = (const unsigned char *) t;
+  size_t i = 0;
+  uint64_t code = 1ull << 63;
+  bool exact = true;
+  for (int k = 0; k < 2 && exact; ++k)
+  {
+    uint32_t z = 0, d = 0;
+    while (i < len && s[i] == '0') { ++z; ++i; }
+    uint64_t v = 0;
+    while (i < len && s[i] >= '0' && s[i] <= '9' && d < 10) { v = v * 10 + (uint64_t) (s[i] - '0'); ++i; ++d; }
+    if ((z == 0 && d == 0) || z > 3 || v >= (1ull << 28) || i >= len || (s[i] != 'M' && s[i] != 'S')) { exact = false; break; }
+    const uint64_t op = s[i] == 'S' ? 1ull : 0ull;
+    ++i;
+    code |= k == 0 ? ((uint64_t) z << 60) | (op << 57) | (v << 28) : ((uint64_t) z << 58) | (op << 56) | v;
+  }
+  if (exact && i == len) return code;
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (size_t j = 0; j < len; ++j) { h ^= s[j]; h *= 0x100000001B3ull; }
+  return h & ~(1ull << 63);
+}
+
+uint64_t text_hash(const char *s, size_t len)  // FNV-1a 64: ids of contig names that are not in the header
 {
   uint64_t h = 0xCBF29CE484222325ull;
   for (size_t i = 0; i < len; ++i)
@@ -621,6 +646,7 @@ bool record_split(Oracle &o, uint64_t i, bk_split &t)
   t.pos = s.pos[i];
   t.endpos = o.endpos(i);
   t.qhash = s.qhash[i];
+  t.qcheck = s.qcheck ? s.qcheck[i] : 0u;
   bool secondary = (flag & 0x100) != 0;
   t.flags = secondary ? 1u : 0u;
   uint32_t sa_start = (uint32_t) atoi(f[1].c_str());  // stoi
@@ -636,12 +662,12 @@ bool record_split(Oracle &o, uint64_t i, bk_split &t)
   bool poison = false;
   if (!oc.empty())
   {
-    own_cig = text_hash(oc.data(), oc.size());
+    own_cig = cigar_code(oc.data(), oc.size());
     own_end_val = (uint32_t) ((uint32_t) a_start + (uint32_t) tmp.reflen() - 1);
   }
   else
   {
-    own_cig = text_hash(own_str.data(), own_str.size());
+    own_cig = cigar_code(own_str.data(), own_str.size());
     own_end_val = (uint32_t) a_end;
   }
   if (tmp.begin_clips() != 0)
@@ -656,7 +682,7 @@ bool record_split(Oracle &o, uint64_t i, bk_split &t)
     sa_bp = sa_end;
   else
     poison = true;
-  uint64_t sa_cig = text_hash(f[3].data(), f[3].size());
+  uint64_t sa_cig = cigar_code(f[3].data(), f[3].size());
   if (!secondary)
   {
     t.prim_chr = own_chr;
@@ -1256,7 +1282,7 @@ void ora_sort_stats(uint64_t out[4])
   out[0] = g_sort_stats.sorts; out[1] = g_sort_stats.heap_segments; out[2] = g_sort_stats.heap_elems; out[3] = g_sort_stats.max_heap;
 }
 
-uint64_t ora_text_hash(const char *s, size_t len) { return text_hash(s, len); }
+uint64_t ora_text_hash(const char *s, size_t len) { return cigar_code(s, len); }  // code of a CIGAR text (bk_split.prim_cigar / sec_cigar)
 int ora_name_id(ora *o, const char *name) { return o->intern(name); }
 
 }  // extern "C"

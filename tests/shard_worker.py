@@ -40,7 +40,7 @@ def main():
     counts = comm.all_gather_scalars([cols["n"]])[:, 0].tolist()
     rec_base = int(sum(counts[:rank]))
     ctx = capi.Context(contigs, device=0)
-    ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
     run = sharded.ShardedRun(ctx, comm, routed=routed)
     w = run.run(rec_base, qual=20, fast=(mode == "fast"))
     got, _ = ctx.fetch(abi.STAGE_CLUSTERS)

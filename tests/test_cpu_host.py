@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "breakid_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|void|uint64_t|const char \*)\s*(bk_[a-z_0-9]+)\s*\(", txt, re.M)))
+    return sorted(set(re.findall(r"^(?:int|void|uint64_t|uint32_t|const char \*)\s*(bk_[a-z_0-9]+)\s*\(", txt, re.M)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -46,7 +46,7 @@ def test_bam_decoder_matches_generator():
         contigs, cols = capi.decode_bam(p)
     ref = ds.to_soa()
     assert contigs == ds.contigs
-    for k, _ in abi.SOA_COLS:
+    for k, _ in abi.SOA_COLS_ALL:
         assert np.array_equal(cols[k], ref[k]), k
 
 
@@ -73,7 +73,7 @@ def test_bam_decoder_threads_and_chunks_agree(monkeypatch):
             capi.decode_bam(p)
         assert e.value.code == abi.BK_ERR_IO
     assert len(ref["tid"]) > 2 * 65536
-    for k, _ in abi.SOA_COLS:
+    for k, _ in abi.SOA_COLS_ALL:
         assert np.array_equal(out["1"][k], ref[k]), k
         assert np.array_equal(out["5"][k], ref[k]), k
 

@@ -23,7 +23,7 @@ def _device_cols(table):
     n = s.n
     sizes = {"cigar_off": n + 1, "aux_off": n + 1, "cigar": s.n_cigar_words, "aux": s.n_aux_bytes}
     out = {}
-    for name, dt in abi.SOA_COLS:
+    for name, dt in abi.SOA_COLS_ALL:
         cnt = sizes.get(name, n)
         nb = cnt * np.dtype(dt).itemsize
         out[name] = tensor_from_ptr(getattr(s, name), nb, dev).cpu().numpy().view(dt).copy() if nb else np.zeros(0, dt)
@@ -50,7 +50,7 @@ def test_device_decode_matches_generator_and_pipeline():
         host_contigs, host_cols = capi.decode_bam(p)
     assert table.contigs == contigs == host_contigs
     got = _device_cols(table)
-    for k, _ in abi.SOA_COLS:
+    for k, _ in abi.SOA_COLS_ALL:
         assert np.array_equal(got[k], ref[k]), k
         assert np.array_equal(got[k], host_cols[k]), k
     # the device table feeds the pipeline in place
@@ -76,7 +76,7 @@ def test_device_decode_of_records_across_blocks_and_of_the_golden_shapes():
         table = capi.decode_bam_device(p)   # one batch: record boundaries guessed per block, verified to chain
         got = _device_cols(table)
         assert table.contigs == contigs
-        for k, _ in abi.SOA_COLS:
+        for k, _ in abi.SOA_COLS_ALL:
             assert np.array_equal(got[k], ref[k]), k
         table.close()
         # a cut in the middle of the stream / a file that is no BAM: an error, not a table
@@ -96,7 +96,7 @@ def test_device_decode_of_records_across_blocks_and_of_the_golden_shapes():
             g.write_bam(up)
             ut = capi.decode_bam_device(up)     # records across blocks
             ugot = _device_cols(ut)
-            for k, _ in abi.SOA_COLS:
+            for k, _ in abi.SOA_COLS_ALL:
                 assert np.array_equal(ugot[k], ref[k]), (make.__name__, "across blocks", k)
             ut.close()
             raw = b"".join(_inflate_blocks(open(up, "rb").read()))
@@ -105,7 +105,7 @@ def test_device_decode_of_records_across_blocks_and_of_the_golden_shapes():
             table = capi.decode_bam_device(ap)
             got = _device_cols(table)
             assert table.contigs == g.contigs
-            for k, _ in abi.SOA_COLS:
+            for k, _ in abi.SOA_COLS_ALL:
                 assert np.array_equal(got[k], ref[k]), (make.__name__, k)
             table.close()
 
@@ -262,7 +262,7 @@ def test_device_decode_in_chunks_equals_one_chunk():
                 os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
             got = _device_cols(table)
             assert table.contigs == contigs
-            for k, _ in abi.SOA_COLS:
+            for k, _ in abi.SOA_COLS_ALL:
                 assert np.array_equal(got[k], ref[k]), (mb, k)
             table.close()
 
@@ -288,7 +288,7 @@ def test_device_decode_of_records_longer_than_a_block():
         table = capi.decode_bam_device(p)
         got = _device_cols(table)
         assert table.contigs == contigs == host_contigs
-        for k, _ in abi.SOA_COLS:
+        for k, _ in abi.SOA_COLS_ALL:
             assert np.array_equal(got[k], ref[k]), k
             assert np.array_equal(got[k], host_cols[k]), k
         table.close()
@@ -325,7 +325,7 @@ def test_device_decode_of_records_across_blocks_in_chunks():
                 table = capi.decode_bam_device(p)
                 got = _device_cols(table)
                 assert table.contigs == contigs
-                for k, _ in abi.SOA_COLS:
+                for k, _ in abi.SOA_COLS_ALL:
                     assert np.array_equal(got[k], ref[k]), (long_every, mb, k)
                 table.close()
     finally:

@@ -1,0 +1,115 @@
+"""Documented limits and the hash-collision detection: each case ends in the documented error code, never in a call the
+reference would not make.  (The reference compares read names and CIGAR texts as strings: BreakID.cc:1424, :627-637.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from breakid_amd import abi, capi, synth
+from tests import refdump
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forged_read_name_collision_in_the_mate_join_is_detected(golden_dir):
+    """two DIFFERENT read names given the same 64-bit qhash: their second hashes (qcheck) differ -> BK_ERR_COLLISION"""
+    contigs, cols = refdump.load_soa(golden_dir, "edge")
+    cols = {k: v.copy() for k, v in cols.items()}
+    f = cols["flag"]
+    cand = np.nonzero((cols["mapq"] >= 20) & ((f & 0x400) == 0) & ((f & 0x100) == 0) & ((f & 1) != 0) & ((f & 2) == 0))[0]
+    a = int(cand[0])
+    b = int(next(i for i in cand if cols["qhash"][i] != cols["qhash"][a]))
+    assert cols["qcheck"][a] != cols["qcheck"][b]
+    cols["qhash"][b] = cols["qhash"][a]
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.run(qual=20, fast=True)
+    assert e.value.code == abi.BK_ERR_COLLISION and "read names" in str(e.value)
+    # without the qcheck column the same table cannot be checked: the collision goes through (the declared behaviour of
+    # tables that carry no names, e.g. generated ones)
+    del cols["qcheck"]
+    ctx.upload(cols)
+    ctx.run(qual=20, fast=True)
+    ctx.close()
+
+
+def test_forged_read_name_collision_in_the_breakpoint_vote_is_detected(golden_dir):
+    contigs, cols = refdump.load_soa(golden_dir, "g1")
+    cols = {k: v.copy() for k, v in cols.items()}
+    sa = np.nonzero(np.diff(cols["aux_off"].astype(np.int64)) > 0)[0]
+    hashes = sorted(set(int(cols["qhash"][i]) for i in sa))
+    assert len(hashes) >= 2
+    victim = cols["qhash"] == np.uint64(hashes[1])
+    cols["qhash"][victim] = np.uint64(hashes[0])   # split read s1 now "is" s0 by its 64-bit hash; qcheck still tells them apart
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.run(qual=20, fast=True)
+    assert e.value.code == abi.BK_ERR_COLLISION
+    ctx.close()
+
+
+def test_cigar_text_codes_are_exact_for_gate_passing_texts():
+    """bk_split.prim_cigar / sec_cigar: <n><M|S><n><M|S> texts are encoded exactly (bit 63), so two different texts that can
+    reach a tuple never compare equal; anything else is a 63-bit hash with bit 63 clear"""
+    from oracle import pyoracle
+    L = pyoracle.lib()
+    texts = ["60M40S", "60S40M", "060M40S", "60M040S", "0060M40S", "6M040S", "60M4S", "604M0S", "0M1S", "00M1S", "268435455M1S"]
+    codes = [L.ora_text_hash(t.encode(), len(t)) for t in texts]
+    assert all(c >> 63 for c in codes) and len(set(codes)) == len(codes)
+    for t in ["00000M1S", "268435456M1S", "60M40S1M", "60M", "", "6X4S", "60M40H"]:
+        assert (L.ora_text_hash(t.encode(), len(t)) >> 63) == 0, t
+
+
+def test_more_than_2_32_records_is_refused():
+    ctx = capi.Context([("chr1", 1000)])
+    s = abi.Soa()
+    s.n = 0xFFFFFFF1
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx._check(ctx.L.bk_upload_records(ctx.h, C.byref(s), abi.BK_MEM_HOST))
+    assert e.value.code == abi.BK_ERR_LIMIT and "2^32" in str(e.value)
+    ctx.close()
+
+
+def test_read_name_run_longer_than_4096_candidates_is_refused():
+    contigs = [("chr1", 10_000_000), ("chr2", 10_000_000)]
+    ds = synth.Dataset(contigs)
+    rng = np.random.default_rng(3)
+    for i in range(400):
+        ds.recs += synth._proper_pair(rng, i, 0, 1000, 9_000_000, 100, 350, 40)
+    for i in range(2100):  # 4200 discordant records under ONE read name (the reference pairs them up in arrival order)
+        ds.recs += synth._discordant_pair("same", 0, 100_000 + 7 * i, 1, 200_000 + 5 * i, 100)
+    ds.sort()
+    ctx = capi.Context(contigs)
+    ctx.upload(ds.to_soa())
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.run(qual=20, fast=True)
+    assert e.value.code == abi.BK_ERR_LIMIT and "4096" in str(e.value)
+    ctx.close()
+
+
+def test_read_name_run_of_4096_candidates_matches_the_oracle():
+    from oracle import pyoracle
+    contigs = [("chr1", 20_000_000), ("chr2", 20_000_000)]
+    ds = synth.Dataset(contigs)
+    rng = np.random.default_rng(4)
+    for i in range(400):
+        ds.recs += synth._proper_pair(rng, i, 0, 1000, 9_000_000, 100, 350, 40)
+    for i in range(2048):
+        ds.recs += synth._discordant_pair("same", 0, 100_000 + 5000 * i, 1, 200_000 + 5000 * i, 100)
+    ds.sort()
+    cols = ds.to_soa()
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    w, _ = ctx.run(qual=20, fast=True)
+    o = pyoracle.Oracle(contigs, cols)
+    ow, rc = o.run(20, fast=True)
+    assert rc == 0 and w == ow
+    for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_CLUSTERS):
+        a, _ = ctx.fetch(st)
+        b, _ = o.fetch(st)
+        assert np.array_equal(a, b), st
+    assert len(ctx.fetch(abi.STAGE_SCAN)[0]) == 2048  # arrival order pairs neighbours on one chromosome, 5 kb apart
+    ctx.close()
+    o.close()

@@ -134,7 +134,7 @@ def test_wgs_shape_device_resident_vs_oracle():
     contigs, cols = synth_gpu.make_wgs(2_000_000, 12346, dev)
     host = synth_gpu.to_numpy_cols(cols)
     ctx = capi.Context(contigs)
-    ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
     w, n_valid = ctx.run(qual=20, fast=True)
     o = pyoracle.Oracle(contigs, host)
     ow, rc = o.run(20, fast=True)
@@ -154,7 +154,7 @@ def test_wgs_shape_100M_oracle_determinism_and_invariants():
     from breakid_amd import sharded, synth_gpu
     dev = torch.device("cuda", 0)
     contigs, cols = synth_gpu.make_wgs(100_000_000, 2024, dev)
-    ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+    ptrs = abi.device_ptrs(cols)
     ctx = capi.Context(contigs)
     crcs = []
     for rep in range(2):
@@ -194,7 +194,7 @@ def test_panel_shape_vs_oracle(fast):
     contigs, cols = synth_gpu.make_panel(77, dev, n_loci=40, depth=600, window=600)
     host = synth_gpu.to_numpy_cols(cols)
     ctx = capi.Context(contigs)
-    ctx.attach_device({k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
     w, n_valid = ctx.run(qual=20, fast=fast)
     o = pyoracle.Oracle(contigs, host)
     ow, rc = o.run(20, fast=fast)

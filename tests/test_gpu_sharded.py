@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_world1_sharded_equals_plain_run():
     dev = torch.device("cuda", 0)
     contigs, cols = synth_gpu.make_wgs(1_500_000, 4242, dev)
-    ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+    ptrs = abi.device_ptrs(cols)
     a = capi.Context(contigs)
     a.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
     w, _ = a.run(qual=20, fast=True)

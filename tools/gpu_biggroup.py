@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 n = int(sys.argv[1]); nc = int(sys.argv[2])
 contigs = synth_gpu.HG19[:nc]
 contigs2, cols = synth_gpu.make_wgs(n, 11, dev, contigs=contigs)
-ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+ptrs = abi.device_ptrs(cols)
 ctx = capi.Context(contigs2)
 for rep in range(2):
     ctx.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])

@@ -10,7 +10,7 @@ from breakid_amd.sharded import lpt_owner
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 620_000_000
 dev = torch.device("cuda", 0)
 contigs, cols = synth_gpu.make_wgs(n, 12346, dev)
-ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+ptrs = abi.device_ptrs(cols)
 
 
 def prep():

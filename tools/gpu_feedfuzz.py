@@ -14,7 +14,7 @@ def device_cols(table):
     n = s.n
     sizes = {"cigar_off": n + 1, "aux_off": n + 1, "cigar": s.n_cigar_words, "aux": s.n_aux_bytes}
     out = {}
-    for name, dt in abi.SOA_COLS:
+    for name, dt in abi.SOA_COLS_ALL:
         cnt = sizes.get(name, n)
         nb = cnt * np.dtype(dt).itemsize
         out[name] = tensor_from_ptr(getattr(s, name), nb, dev).cpu().numpy().view(dt).copy() if nb else np.zeros(0, dt)
@@ -117,7 +117,7 @@ def one(case, seed):
         table = capi.decode_bam_device(p)
         got = device_cols(table)
         ok = table.contigs == contigs == hc
-        for k, _ in abi.SOA_COLS:
+        for k, _ in abi.SOA_COLS_ALL:
             ok = ok and np.array_equal(got[k], ref[k]) and np.array_equal(got[k], hcols[k])
         table.close()
         if not ok:

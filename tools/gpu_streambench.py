@@ -8,7 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000_000
 dev = torch.device("cuda", 0)
 contigs, cols = synth_gpu.make_wgs(n, 12346, dev)
 ctx = capi.Context(contigs)
-ptrs = {k: cols[k].data_ptr() for k, _ in abi.SOA_COLS}
+ptrs = abi.device_ptrs(cols)
 ctx.timing_enable(True)
 for it in range(4):
     ctx.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
