@@ -389,6 +389,13 @@ int bk_set_stream(bk_ctx *ctx, void *hip_stream)
     ctx->own_stream = false;
   });
 }
+int bk_get_stream(bk_ctx *ctx, void **hip_stream)
+{
+  return guarded(ctx, [&] {
+    if (!hip_stream) throw bk_error(BK_ERR_ARG, "bk_get_stream: null output");
+    *hip_stream = (void *) ctx->st;
+  });
+}
 int bk_sync(bk_ctx *ctx)
 {
   return guarded(ctx, [&] { HIP_CHECK(hipStreamSynchronize(ctx->st)); });

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/breakid_hip.h"
+#include "../../include/breakid_multi.h"
 
 #ifndef BREAKID_INSTALLDIR
 #define BREAKID_INSTALLDIR "."
@@ -277,9 +278,10 @@ int main(int argc, char *argv[])
 {
   clock_t start = clock();
   static struct option longopts[] = {{"help", 0, 0, 'h'}, {"i", 1, 0, 1}, {"o", 1, 0, 2}, {"q", 1, 0, 3}, {"n", 1, 0, 4},
-                                     {"fast", 0, 0, 5},   {"t", 0, 0, 6}, {"all", 0, 0, 7}, {"gpu", 1, 0, 8}, {0, 0, 0, 0}};
+                                     {"fast", 0, 0, 5},   {"t", 0, 0, 6}, {"all", 0, 0, 7}, {"gpu", 1, 0, 8}, {"gpus", 1, 0, 9},
+                                     {"comm", 1, 0, 10},  {0, 0, 0, 0}};
   string inp_file, out_file, nib_dir, build = "hg19";
-  int qual = 20, device = 0;
+  int qual = 20, device = 0, n_gpus = 0, transport = BK_TRANSPORT_AUTO;  // -gpus N: one sample over N GPUs (include/breakid_multi.h)
   bool fast = false, filter = true;
   int opt, li;
   optind = 0;
@@ -296,6 +298,8 @@ int main(int argc, char *argv[])
     case 6: break;  // the reference dereferences a NULL optarg here (has_arg = 0); `times` is effectively always 2
     case 7: filter = false; break;
     case 8: device = atoi(optarg); break;
+    case 9: n_gpus = atoi(optarg); break;
+    case 10: transport = !strcmp(optarg, "rccl") ? BK_TRANSPORT_RCCL : !strcmp(optarg, "local") ? BK_TRANSPORT_LOCAL : BK_TRANSPORT_AUTO; break;
     default: std::cerr << "Error: cannot parse arguments.\n"; exit(1);
     }
   }
@@ -330,7 +334,8 @@ int main(int argc, char *argv[])
     }
     fclose(probe);
   }
-  if (!getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device(inp_file.c_str(), device, &dbam, &soa, &nt, &names, &lens, err, sizeof err) == BK_OK)
+  const bool multi = n_gpus >= 1;  // the sharded run takes the host table and splits it over the ranks
+  if (!multi && !getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device(inp_file.c_str(), device, &dbam, &soa, &nt, &names, &lens, err, sizeof err) == BK_OK)
     soa_where = BK_MEM_DEVICE;
   else
   {
@@ -356,52 +361,74 @@ int main(int argc, char *argv[])
     }
   }
   bk_ctx *ctx = nullptr;
-  if (bk_init(device, lens, names, nt, &ctx) != BK_OK)
-  {
-    std::cerr << "Error: " << bk_last_error(nullptr) << std::endl;
-    exit(1);
-  }
   auto die = [&](int rc) {
     std::cerr << (rc == BK_ERR_CIGAR ? "error cigar: " : bk_last_error(ctx)) << std::endl;
     exit(rc == BK_ERR_CIGAR ? -1 : 1);
   };
   int rc;
-  if ((rc = bk_upload_records(ctx, &soa, soa_where)) != BK_OK) die(rc);
-  double mean = 0, sd = 0;
-  if ((rc = bk_isize_stats(ctx, &mean, &sd)) != BK_OK) die(rc);
-  std::cout << "the insert size mean: " << mean << ", the insert size sd:" << sd << " .\n";
-  const int times = 2;
-  const double w = times * std::sqrt(times) * (mean + 3 * sd);
-  std::cout << "cluster_dist = span_dist = mask_dist = scan_dist = " << w << " .\n";
-  clock_t scan_start = clock();
+  double w = 0;
+  clock_t scan_start = clock(), scan_end = scan_start, cluster_start = scan_start, cluster_end = scan_start, bp_start = scan_start, bp_end = scan_start;
   uint64_t n_pairs = 0, n_clustered = 0, n_valid = 0, n_clusters = 0;
   uint32_t n_groups = 0;
-  std::cout << "Scanning discordant read pairs ...\n";
-  if ((rc = bk_discordant_pairs(ctx, qual, w, &n_pairs, &n_groups)) != BK_OK) die(rc);
-  std::cout << "Scanning discordant read pairs done.\n";
-  clock_t scan_end = clock();
-  clock_t cluster_start = clock();
-  if ((rc = bk_mask_and_cluster(ctx, w, fast ? 1 : 0, &n_clustered)) != BK_OK) die(rc);
-  clock_t cluster_end = clock();
-  clock_t bp_start = clock();
-  if ((rc = bk_split_evidence(ctx, nullptr)) != BK_OK) die(rc);
-  if ((rc = bk_cluster_summary(ctx, w, &n_clusters)) != BK_OK) die(rc);
-  if (n_clustered)  // findEncompassingReadsAndBreakPointInfo opens the index for every group that reaches it (:405-416)
-  {
+  auto need_index = [&] {  // findEncompassingReadsAndBreakPointInfo opens the index for every group that reaches it (:405-416)
     std::ifstream bai((inp_file + ".bai").c_str());
     if (!bai.is_open())
     {
       std::cerr << "Error: please index bam-file first:\t" << inp_file << std::endl;
       exit(1);
     }
+  };
+  if (multi)
+  {
+    // one sample over n_gpus GPUs: record ranges per rank, RCCL (or in-process) exchange of the small tables
+    rc = bk_multi_run(&soa, lens, names, nt, n_gpus, transport, qual, fast ? 1 : 0, &w, &n_clustered, &ctx, err, sizeof err);
+    if (rc != BK_OK)
+    {
+      std::cerr << (rc == BK_ERR_CIGAR ? "error cigar: " : err) << std::endl;
+      exit(rc == BK_ERR_CIGAR ? -1 : 1);
+    }
+    std::cout << "cluster_dist = span_dist = mask_dist = scan_dist = " << w << " .\n";
+    if (n_clustered) need_index();
   }
-  if ((rc = bk_split_breakpoints(ctx, w, &n_valid)) != BK_OK) die(rc);
-  clock_t bp_end = clock();
-  std::cout << "valid cluster count: " << n_valid << std::endl;
+  else
+  {
+    if (bk_init(device, lens, names, nt, &ctx) != BK_OK)
+    {
+      std::cerr << "Error: " << bk_last_error(nullptr) << std::endl;
+      exit(1);
+    }
+    if ((rc = bk_upload_records(ctx, &soa, soa_where)) != BK_OK) die(rc);
+    double mean = 0, sd = 0;
+    if ((rc = bk_isize_stats(ctx, &mean, &sd)) != BK_OK) die(rc);
+    std::cout << "the insert size mean: " << mean << ", the insert size sd:" << sd << " .\n";
+    const int times = 2;
+    w = times * std::sqrt(times) * (mean + 3 * sd);
+    std::cout << "cluster_dist = span_dist = mask_dist = scan_dist = " << w << " .\n";
+    scan_start = clock();
+    std::cout << "Scanning discordant read pairs ...\n";
+    if ((rc = bk_discordant_pairs(ctx, qual, w, &n_pairs, &n_groups)) != BK_OK) die(rc);
+    std::cout << "Scanning discordant read pairs done.\n";
+    scan_end = clock();
+    cluster_start = clock();
+    if ((rc = bk_mask_and_cluster(ctx, w, fast ? 1 : 0, &n_clustered)) != BK_OK) die(rc);
+    cluster_end = clock();
+    bp_start = clock();
+    if ((rc = bk_split_evidence(ctx, nullptr)) != BK_OK) die(rc);
+    if ((rc = bk_cluster_summary(ctx, w, &n_clusters)) != BK_OK) die(rc);
+    if (n_clustered) need_index();
+    if ((rc = bk_split_breakpoints(ctx, w, &n_valid)) != BK_OK) die(rc);
+    bp_end = clock();
+  }
   const void *data = nullptr;
   uint64_t cnt = 0;
   if ((rc = bk_fetch(ctx, BK_STAGE_CLUSTERS, &data, &cnt, nullptr, nullptr)) != BK_OK) die(rc);
   const bk_cluster *cl = (const bk_cluster *) data;
+  if (multi)
+  {
+    n_valid = 0;
+    for (uint64_t i = 0; i < cnt; ++i) n_valid += (cl[i].flags & 2u) != 0;
+  }
+  std::cout << "valid cluster count: " << n_valid << std::endl;
   // annotate_cluster_for_sa_tag (BreakID.cc:492-567)
   vector<OutRow> rows;
   vector<Txpt> txpts;
@@ -471,7 +498,7 @@ int main(int argc, char *argv[])
     // LAST such group returned (:131-136; the reference leaves it uninitialised when no group qualifies - 0 here)
     const bk_group_stat *gs = nullptr;
     uint32_t ngs = 0;
-    if ((rc = bk_group_stats(ctx, &gs, &ngs)) != BK_OK) die(rc);
+    if (!multi && (rc = bk_group_stats(ctx, &gs, &ngs)) != BK_OK) die(rc);  // (a sharded run keeps these per rank: the counters stay 0)
     int removed_isolated_pair_count = 0, root_cluster_num = 0;
     for (uint32_t g = 0; g < ngs; ++g)
       if (gs[g].n_isolated_removed >= 2)

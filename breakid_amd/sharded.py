@@ -47,6 +47,7 @@ class Comm:
         self.world = dist.get_world_size(group) if self.on else 1
         self.host_staged = self.on and dist.get_backend(group) == "gloo"
         self.before = None  # set by ShardedRun: waits for the library's own stream before a buffer of it is sent
+        self.same_stream = False  # ShardedRun: the library runs on torch's current stream (device-side ordering)
 
     def _to_comm(self, t):
         if self.before is not None:
@@ -54,9 +55,10 @@ class Comm:
         return t.cpu() if self.host_staged else t
 
     def _done(self, t):
-        """RCCL collectives are queued on the process group's own stream and only the current torch stream waits for
-        them; the library reads the result on ITS stream, so the host waits here (a few per step, microseconds each)."""
-        if not self.host_staged and t.is_cuda:
+        """RCCL collectives are queued on the process group's own stream and torch makes the CURRENT stream wait for them
+        (event, no host round trip).  ShardedRun puts the library on that same stream (bk_set_stream), so kernels and
+        collectives are ordered on the device; only when the library keeps its own stream does the host wait here."""
+        if not self.host_staged and t.is_cuda and not self.same_stream:
             torch.cuda.current_stream(t.device).synchronize()
         return t
 
@@ -82,15 +84,22 @@ class Comm:
         if not self.on or self.world == 1:
             return t
         sizes = self.all_gather_scalars([t.numel()])[:, 0].tolist()
-        mx = max(sizes)
-        if mx == 0:
+        if max(sizes) == 0:
             return t
-        pad = torch.zeros(mx, dtype=torch.uint8, device=t.device)
-        pad[: t.numel()] = t
-        x = self._to_comm(pad)
-        out = [torch.empty_like(x) for _ in range(self.world)]
-        dist.all_gather(out, x, group=self.group)
-        return self._done(torch.cat([o[:s] for o, s in zip(out, sizes)]).to(t.device))
+        # one broadcast per rank straight into its slice of the result: no padding to the largest rank, no concatenation
+        x = self._to_comm(t)
+        out = torch.empty(sum(sizes), dtype=torch.uint8, device=x.device)
+        off, works = 0, []
+        for r, s in enumerate(sizes):
+            if s:
+                piece = out[off: off + s]
+                if r == self.rank:
+                    piece.copy_(x)
+                works.append(dist.broadcast(piece, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group, async_op=True))
+            off += s
+        for wk in works:
+            wk.wait()
+        return self._done(out.to(t.device))
 
 
     def all_to_all_var(self, t, send_bytes):
@@ -128,7 +137,13 @@ class ShardedRun:
         self.ctx, self.comm = ctx, comm
         self.routed = routed  # False: the simpler replicated join (all-gather of every candidate to every rank)
         self._keep = []
-        comm.before = ctx.sync
+        if comm.on and not comm.host_staged:
+            # RCCL: the library runs on torch's current stream, so a collective is ordered behind the kernel that produced its
+            # input and the next kernel behind the collective - on the device, without host synchronisation
+            ctx.set_stream(torch.cuda.current_stream(comm.device).cuda_stream)
+            comm.same_stream = True
+        else:
+            comm.before = ctx.sync
 
     def _buffer(self, which):
         L, h = self.ctx.L, self.ctx.h

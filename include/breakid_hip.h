@@ -128,6 +128,7 @@ void bk_free(bk_ctx *ctx);
 const char *bk_last_error(const bk_ctx *ctx); /* ctx may be NULL: error of the failed bk_init */
 int bk_set_stream(bk_ctx *ctx, void *hip_stream); /* optional: run on the caller's hipStream_t */
 int bk_sync(bk_ctx *ctx);
+int bk_get_stream(bk_ctx *ctx, void **hip_stream); /* the hipStream_t the context runs on (collectives of a sharded run are queued on it) */
 
 /* Replaces: the two sequential BAM passes' record access (BreakID.cc:1414, :1929). */
 int bk_upload_records(bk_ctx *ctx, const bk_soa *cols, int mem_space);

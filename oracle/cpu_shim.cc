@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../include/breakid_hip.h"
+#include "../include/breakid_multi.h"
 
 extern "C" {
 struct Oracle;
@@ -154,5 +155,10 @@ int bk_bam_decode_device(const char *, int, bk_bam_dev **, bk_soa *, int *, cons
   return BK_ERR_NO_DEVICE;
 }
 void bk_bam_dev_free(bk_bam_dev *) {}
+int bk_multi_run(const bk_soa *, const uint32_t *, const char *const *, int, int, int, int, int, double *, uint64_t *, bk_ctx **, char *err, size_t errlen)
+{
+  if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
+  return BK_ERR_NO_DEVICE;
+}
 
 }  // extern "C"

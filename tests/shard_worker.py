@@ -14,7 +14,7 @@ from breakid_amd import abi, capi, sharded, synth_gpu  # noqa: E402
 
 
 def concat_shards(hosts):
-    full = {k: np.concatenate([h[k] for h in hosts]) for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "qhash")}
+    full = {k: np.concatenate([h[k] for h in hosts]) for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq", "qhash", "qcheck")}
     cb = ab = 0
     co, ao = [], []
     for h in hosts:
@@ -32,9 +32,14 @@ def concat_shards(hosts):
 def main():
     n_per_rank, seed, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     routed = (sys.argv[4] if len(sys.argv) > 4 else "routed") == "routed"
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"  # "nccl" = RCCL: one rank per GPU (world size 1 on a one-GPU box)
     dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     contigs, cols = synth_gpu.make_wgs_shard(n_per_rank, seed, dev, rank, world)
     comm = sharded.Comm(dev)
     counts = comm.all_gather_scalars([cols["n"]])[:, 0].tolist()
@@ -60,6 +65,9 @@ def main():
     import zlib
     h = torch.tensor([zlib.crc32(got.tobytes())], dtype=torch.int64)
     hs = [torch.zeros_like(h) for _ in range(world)]
+    if backend == "nccl":
+        h = h.to(dev)
+        hs = [torch.zeros_like(h) for _ in range(world)]
     dist.all_gather(hs, h)
     same = all(int(x) == int(hs[0]) for x in hs)
     if rank == 0:

@@ -70,3 +70,27 @@ def test_cli_fatal_paths_match_the_reference_messages():
     :411-416, RefSeqTranscript.cc:212-216), same table as the CPU build of the host code (tests/test_cpu_cli.py)"""
     from tests.test_cpu_cli import check_fatal_paths
     check_fatal_paths(BIN)
+
+
+@pytest.mark.parametrize("name,mode,ranks,comm", [("small", "fast", 1, "rccl"), ("edge", "ahc", 1, "rccl"), ("small", "fast", 2, "local"), ("ties", "ahc", 2, "local"),
+                                                   ("edge", "fast", 3, "local"), ("g1", "fast", 4, "local")])
+def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, ranks, comm):
+    """`BreakID -gpus N`: one sample over N contexts, orchestrated in C++ (csrc/multi_gpu.hip, include/breakid_multi.h).
+    -comm rccl issues the collectives through librccl directly (world size 1 on this one-GPU box: ncclAllGather / grouped
+    ncclBroadcast / ncclSend+ncclRecv / ncclAllReduce all run); -comm local puts N contexts on one GPU and moves the same
+    tables by device-to-device copies - the N-rank code path (record ranges, routed all-to-alls, LPT group ownership, vote
+    slices) against the reference's txt files."""
+    ds, refgene = _dataset(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        bam = os.path.join(tmp, name + ".bam")
+        ds.write_bam(bam, aligned=True)
+        open(bam + ".bai", "wb").close()
+        side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
+        prefix = os.path.join(tmp, "out")
+        cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all", "-gpus", str(ranks), "-comm", comm] + (["-fast"] if mode == "fast" else [])
+        r = subprocess.run(cmd, env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for suffix in ("_fusion.txt", "_fusion_all.txt"):
+            got = open(prefix + suffix).read()
+            exp = open(os.path.join(golden_dir, "%s.%s%s" % (name, mode, suffix))).read()
+            assert got == exp, (suffix, got[:600], exp[:600])

@@ -43,3 +43,27 @@ def test_two_rank_sharded_sample_matches_oracle(mode, exchange):
            "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "shard_worker.py"), n, "77", mode, exchange]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("exchange", ["routed", "replicated"])
+def test_rccl_backend_world_size_1(exchange):
+    """backend "nccl" (= RCCL) at world size 1: the device-tensor branch of the exchange layer - collectives on device buffers
+    of the library, the library running on torch's current stream (device-side ordering, no host sync), unpadded all-gather by
+    per-rank broadcasts, all_to_all_single - against the CPU oracle.  More RCCL ranks need one GPU each (driver's scaling run)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621" if exchange == "routed" else "29622")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "shard_worker.py"), "600000", "78", "fast", exchange, "nccl"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+def test_bench_sharded_path_runs_over_rccl():
+    """bench.py --gpus 1 --sharded 1: the multi-GPU bench path (RCCL process group, sharded generator, ShardedRun) on one GPU"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29623", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sharded", "1", "--records", "3000000", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["valid_clusters"] > 100 and "RCCL" in line["config"]["sharding"]
+    assert line["roofline"]["path_frac"] > 0 and any(s["stage"] == "k_stream" for s in line["roofline"]["stages"])
