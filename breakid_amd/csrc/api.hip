@@ -11,6 +11,7 @@
 #include "cluster.h"
 #include "bp.h"
 #include "ahc.h"
+#include "bgzf_gpu.h"
 
 namespace
 {
@@ -236,49 +237,62 @@ void build_name_tables(bk_ctx *c)
 
 std::string rname(const bk_ctx *c, int tid) { return tid < 0 ? "*" : c->tname[tid]; }
 
-void run_stream(bk_ctx *c)
+// ---- stream pass (A1 sums, A2 filter, A12 gate) ------------------------------------------------------------------
+// Three steps so that the table may arrive in pieces (bk_bam_decode_device_ctx: the pass runs on the records of a feed chunk
+// while the next chunks are still being copied and inflated): prepare (outputs sized, counters cleared), any number of
+// launches over consecutive record ranges (the counters accumulate, candidates / SA-bearing record indices append), finish
+// (counters read back, rare-path kernel over the SA-bearing records).
+StreamArgs stream_args(bk_ctx *c, uint64_t n)
 {
-  if (!c->have_records) throw bk_error(BK_ERR_ARG, "no records uploaded");
-  const uint64_t n = c->rec.n;
-  if (c->cand_cap == 0) c->cand_cap = std::max<uint64_t>(1u << 16, n / 8 + 1024);
-  if (c->split_cap == 0) c->split_cap = std::max<uint64_t>(1u << 14, n / 32 + 1024);
-  if (c->sa_cap == 0) c->sa_cap = std::max<uint64_t>(1u << 14, n / 16 + 1024);
   StreamArgs a{};
-  for (int attempt = 0; attempt < 3; ++attempt)
+  a.n = n;
+  a.q_begin = 0;
+  a.rec_base = c->rec_base;
+  a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
+  a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash; a.qcheck = c->rec.qcheck;
+  a.cigar_off = c->rec.cigar_off; a.cigar = c->rec.cigar; a.aux_off = c->rec.aux_off; a.aux = c->rec.aux;
+  a.mapq_min = c->mapq_min;
+  a.names = c->names;
+  a.counters = c->d_counters.get<StreamCounters>();
+  a.sd = c->d_sd.get<SdState>();
+  a.cand = c->d_cand.get<Cand>();
+  a.cand_cap = c->cand_cap;
+  a.split = c->d_split_raw.get<bk_split>();
+  a.split_cap = c->split_cap;
+  a.sa_list = c->d_sa_list.get<uint32_t>();
+  a.sa_cap = c->sa_cap;
+  return a;
+}
+void stream_prepare(bk_ctx *c, uint64_t n_expected)
+{
+  c->cand_cap = std::max<uint64_t>(c->cand_cap, std::max<uint64_t>(1u << 16, n_expected / 8 + 1024));
+  c->split_cap = std::max<uint64_t>(c->split_cap, std::max<uint64_t>(1u << 14, n_expected / 32 + 1024));
+  c->sa_cap = std::max<uint64_t>(c->sa_cap, std::max<uint64_t>(1u << 14, n_expected / 16 + 1024));
+  StreamCounters *dc = c->d_counters.as<StreamCounters>(1);
+  SdState *dsd = c->d_sd.as<SdState>(1);
+  HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(StreamCounters), c->st));
+  HIP_CHECK(hipMemsetAsync(dsd, 0, sizeof(SdState), c->st));
+  (void) c->d_cand.as<Cand>(c->cand_cap);
+  (void) c->d_split_raw.as<bk_split>(c->split_cap);
+  (void) c->d_sa_list.as<uint32_t>(c->sa_cap);
+}
+// returns false when an output capacity was exceeded (the caller enlarges and repeats the pass)
+bool stream_finish(bk_ctx *c)
+{
+  HIP_CHECK(hipMemcpyAsync(&c->hc, c->d_counters.get<StreamCounters>(), sizeof(StreamCounters), hipMemcpyDeviceToHost, c->st));
+  HIP_CHECK(hipMemcpyAsync(&c->hsd, c->d_sd.get<SdState>(), sizeof(SdState), hipMemcpyDeviceToHost, c->st));
+  HIP_CHECK(hipStreamSynchronize(c->st));
+  if (c->hc.n_cand > c->cand_cap || c->hc.n_sa > c->sa_cap)
   {
-    StreamCounters *dc = c->d_counters.as<StreamCounters>(1);
-    SdState *dsd = c->d_sd.as<SdState>(1);
-    HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(StreamCounters), c->st));
-    HIP_CHECK(hipMemsetAsync(dsd, 0, sizeof(SdState), c->st));
-    a.n = n;
-    a.rec_base = c->rec_base;
-    a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
-    a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash; a.qcheck = c->rec.qcheck;
-    a.cigar_off = c->rec.cigar_off; a.cigar = c->rec.cigar; a.aux_off = c->rec.aux_off; a.aux = c->rec.aux;
-    a.mapq_min = c->mapq_min;
-    a.names = c->names;
-    a.counters = dc;
-    a.sd = dsd;
-    a.cand = c->d_cand.as<Cand>(c->cand_cap);
-    a.cand_cap = c->cand_cap;
-    a.split = c->d_split_raw.as<bk_split>(c->split_cap);
-    a.split_cap = c->split_cap;
-    a.sa_list = c->d_sa_list.as<uint32_t>(c->sa_cap);
-    a.sa_cap = c->sa_cap;
-    {
-      // algorithmic bytes of this pass (SURVEY 8(d)): 39 B/record + 4 B per CIGAR op (+ 32 B per candidate, added below)
-      Scope s(c, "k_stream", 39ull * n + 4ull * c->rec.n_cigar_words);
-      launch_stream(a, c->st);
-    }
-    HIP_CHECK(hipMemcpyAsync(&c->hc, dc, sizeof(StreamCounters), hipMemcpyDeviceToHost, c->st));
-    HIP_CHECK(hipMemcpyAsync(&c->hsd, dsd, sizeof(SdState), hipMemcpyDeviceToHost, c->st));
-    HIP_CHECK(hipStreamSynchronize(c->st));
-    if (c->hc.n_cand <= c->cand_cap && c->hc.n_sa <= c->sa_cap) break;
-    if (c->timing && !c->timers.empty()) c->timers.pop_back();  // overflowed attempt is not a measured pass
     c->cand_cap = std::max<uint64_t>(c->cand_cap, c->hc.n_cand + 1024);
     c->sa_cap = std::max<uint64_t>(c->sa_cap, c->hc.n_sa + 1024);
-    if (attempt == 2) throw bk_error(BK_ERR_LIMIT, "stream pass: output capacity");
+    return false;
   }
+  return true;
+}
+void stream_rare_path(bk_ctx *c)
+{
+  const uint64_t n = c->rec.n;
   if (c->timing && !c->timers.empty())
   {
     c->timers.back().bytes += 32ull * c->hc.n_cand + 4ull * c->hc.n_sa;
@@ -291,9 +305,9 @@ void run_stream(bk_ctx *c)
   if (c->hc.n_sa > c->split_cap)
   {
     c->split_cap = c->hc.n_sa + 1024;
-    a.split = c->d_split_raw.as<bk_split>(c->split_cap);
-    a.split_cap = c->split_cap;
+    (void) c->d_split_raw.as<bk_split>(c->split_cap);
   }
+  StreamArgs a = stream_args(c, n);
   {
     Scope s(c, "k_split_records", c->rec.n_aux_bytes + 4ull * c->hc.n_sa);
     launch_split_records(a, c->hc.n_sa, c->st);
@@ -309,6 +323,25 @@ void run_stream(bk_ctx *c)
   c->stream_mapq = c->mapq_min;
   c->splits_sorted = false;
   c->stats_done = false;
+}
+
+void run_stream(bk_ctx *c)
+{
+  if (!c->have_records) throw bk_error(BK_ERR_ARG, "no records uploaded");
+  const uint64_t n = c->rec.n;
+  for (int attempt = 0; attempt < 3; ++attempt)
+  {
+    stream_prepare(c, n);
+    {
+      // algorithmic bytes of this pass (SURVEY 8(d)): 39 B/record + 4 B per CIGAR op (+ 32 B per candidate, added below)
+      Scope s(c, "k_stream", 39ull * n + 4ull * c->rec.n_cigar_words);
+      launch_stream(stream_args(c, n), c->st);
+    }
+    if (stream_finish(c)) break;
+    if (c->timing && !c->timers.empty()) c->timers.pop_back();  // overflowed attempt is not a measured pass
+    if (attempt == 2) throw bk_error(BK_ERR_LIMIT, "stream pass: output capacity");
+  }
+  stream_rare_path(c);
 }
 
 void ensure_splits_sorted(bk_ctx *c)
@@ -1014,6 +1047,156 @@ int bk_debug_ahc(bk_ctx *ctx, const uint32_t *x, const uint32_t *y, uint32_t n, 
     }
     HIP_CHECK(hipStreamSynchronize(ctx->st));
   });
+}
+
+}  // extern "C"
+
+// ---- feed and stream pass overlapped: the reference's two sequential BAM passes (BreakID.cc:1929, :1414)
+// become one read of the file, and the record-level kernel of the hot path runs while the file is still arriving -------------
+namespace
+{
+struct FeedLink
+{
+  int device = 0, mapq_min = 20;
+  bk_ctx *ctx = nullptr;
+  int rc = BK_OK;
+  std::string err;
+  uint64_t done = 0;      // records [0, done) have been through k_stream (a multiple of 4)
+  bool prepared = false, overflow = false;
+  hipEvent_t t0 = nullptr, t1 = nullptr;  // timing: first and last k_stream piece
+  template <class F> void guard(F &&f)
+  {
+    if (rc != BK_OK) return;
+    try
+    {
+      f();
+    }
+    catch (const bk_error &e)
+    {
+      rc = e.code;
+      err = e.msg;
+    }
+  }
+};
+void link_header(void *u, int nt, const char *const *names, const uint32_t *lens)
+{
+  FeedLink *L = (FeedLink *) u;
+  if (L->ctx || L->rc != BK_OK) return;
+  L->rc = bk_init(L->device, lens, names, nt, &L->ctx);
+  if (L->rc != BK_OK) L->err = bk_last_error(nullptr);
+}
+void link_reset(void *u)
+{
+  FeedLink *L = (FeedLink *) u;
+  L->guard([&] {
+    if (L->ctx) HIP_CHECK(hipStreamSynchronize(L->ctx->st));
+    L->done = 0;
+    L->prepared = false;
+    L->overflow = false;
+  });
+}
+void link_before_move(void *u)
+{
+  FeedLink *L = (FeedLink *) u;
+  L->guard([&] {
+    if (L->ctx) HIP_CHECK(hipStreamSynchronize(L->ctx->st));
+  });
+}
+void link_chunk(void *u, const bk_soa *cols, uint64_t n_ready, uint64_t n_est, hipEvent_t ready)
+{
+  FeedLink *L = (FeedLink *) u;
+  L->guard([&] {
+    bk_ctx *c = L->ctx;
+    if (!c || n_ready < 5) return;
+    c->rec = *cols;  // device pointers of the columns as they stand now
+    c->have_records = true;
+    c->mapq_min = L->mapq_min;
+    if (!L->prepared)
+    {
+      stream_prepare(c, n_est + n_est / 4);
+      L->prepared = true;
+    }
+    // the last ready record stays for the next piece: its quad reads the offset entry that follows it
+    const uint64_t lim = (n_ready - 1) / 4 * 4;
+    if (lim <= L->done) return;
+    HIP_CHECK(hipStreamWaitEvent(c->st, ready, 0));
+    StreamArgs a = stream_args(c, lim);
+    a.q_begin = L->done / 4;
+    launch_stream(a, c->st);
+    L->done = lim;
+  });
+}
+}  // namespace
+
+
+extern "C" {
+
+int bk_bam_decode_device_ctx(const char *path, int device, int mapq_min, bk_bam_dev **bam_out, bk_ctx **ctx_out, int *n_targets, const char *const **names,
+                             const uint32_t **lens, char *err, size_t errlen)
+{
+  auto fail = [&](int code, const std::string &m) {
+    if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
+    return code;
+  };
+  if (!path || !bam_out || !ctx_out) return fail(BK_ERR_ARG, "bk_bam_decode_device_ctx: null argument");
+  *bam_out = nullptr;
+  *ctx_out = nullptr;
+  FeedLink L;
+  L.device = device;
+  L.mapq_min = mapq_min;
+  FeedConsumer fc;
+  fc.user = &L;
+  fc.on_header = link_header;
+  fc.on_chunk = link_chunk;
+  fc.before_move = link_before_move;
+  fc.on_reset = link_reset;
+  bk_soa cols;
+  bk_bam_dev *bam = nullptr;
+  int rc = bam_decode_device_impl(path, device, &bam, &cols, n_targets, names, lens, err, errlen, &fc);
+  if (rc == BK_OK && L.rc != BK_OK) rc = fail(L.rc, L.err);
+  if (rc == BK_OK && !L.ctx) rc = fail(BK_ERR_IO, "bk_bam_decode_device_ctx: no header");
+  if (rc != BK_OK)
+  {
+    if (L.ctx) bk_free(L.ctx);
+    if (bam) bk_bam_dev_free(bam);
+    return rc;
+  }
+  bk_ctx *c = L.ctx;
+  rc = guarded(c, [&] {
+    // the complete table (final pointers, end entries of the offset columns written), then the records the pieces left
+    const uint64_t done = L.prepared ? L.done : 0;
+    c->stream_done = c->stats_done = c->clustered = false;
+    c->rec = cols;
+    c->have_records = true;
+    c->mapq_min = mapq_min;
+    c->rec_base = 0;
+    bool ok = false;
+    if (L.prepared)
+    {
+      Scope s(c, "k_stream", 39ull * cols.n + 4ull * cols.n_cigar_words);
+      StreamArgs a = stream_args(c, cols.n);
+      a.q_begin = done / 4;
+      launch_stream(a, c->st);
+      ok = stream_finish(c);
+    }
+    if (ok)
+      stream_rare_path(c);
+    else
+      run_stream(c);  // file without chunked feed (records across BGZF blocks), or an output capacity estimated too small
+    if (getenv("BREAKID_FEED_STATS"))
+      fprintf(stderr, "[feed/stream] stream pass %s: %llu of %llu records went through k_stream while the file was still arriving\n", ok ? "overlapped" : "after the feed",
+              (unsigned long long) (ok ? done : 0), (unsigned long long) cols.n);
+  });
+  if (rc != BK_OK)
+  {
+    fail(rc, c->err);
+    bk_free(c);
+    bk_bam_dev_free(bam);
+    return rc;
+  }
+  *bam_out = bam;
+  *ctx_out = c;
+  return BK_OK;
 }
 
 int bk_group_stats(bk_ctx *ctx, const bk_group_stat **out, uint32_t *n_groups)

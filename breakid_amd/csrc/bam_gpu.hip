@@ -768,7 +768,7 @@ void grow_keep(DevBuf &b, size_t used, size_t need)
 // fill each other's tails, and device memory holds four chunks plus the columns whatever the size of the file.  The
 // columns are sized from the first chunk (records per compressed byte x file size) and grow by copying when that was
 // too small.
-static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols)
+static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols, const FeedConsumer *fc = nullptr)
 {
   {
     const double t0 = now_s2();
@@ -794,6 +794,8 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     uint64_t first_in_off = 0;
     uint32_t hdr_first_off = 0, n_ref = 0;
     parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, hdr_first_off);
+    if (fc && fc->on_header) fc->on_header(fc->user, (int) h->names.size(), h->name_ptrs.data(), h->lens.data());
+    uint64_t est_total = 0;
     StagePool pool(file.data(), file.size(), chunk_bytes, copy_threads, device);
     uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
     double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0;
@@ -806,6 +808,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     auto reserve = [&](uint64_t r, uint64_t g, uint64_t a) {
       if (r <= cap_rec && g <= cap_cig && a <= cap_aux) return;
       sync_all();
+      if (fc && fc->before_move) fc->before_move(fc->user);
       if (r > cap_rec)
       {
         const uint64_t nc = std::max(r, cap_rec + cap_rec / 2) + 1024;
@@ -920,6 +923,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
         // the rest of the file at the first chunk's densities, 5 % on top
         const double scale = 1.05 * (double) file.size() / (double) std::max<uint64_t>(first_bytes, 1);
         reserve((uint64_t) (r * scale), (uint64_t) (g * scale), (uint64_t) (a * scale));
+        est_total = (uint64_t) (r * scale);
       }
       reserve(r, g, a);
       t_reserve += now_s2() - tw0;
@@ -929,6 +933,17 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       n_rec = r;
       n_cig = g;
       n_aux = a;
+      if (fc && fc->on_chunk)
+      {
+        bk_soa v;
+        memset(&v, 0, sizeof v);
+        v.n = n_rec;
+        v.tid = c.tid; v.pos = c.pos; v.mtid = c.mtid; v.mpos = c.mpos; v.isize = c.isize; v.flag = c.flag; v.mapq = c.mapq; v.qhash = c.qhash; v.qcheck = c.qcheck;
+        v.cigar_off = c.cigar_off; v.cigar = c.cigar; v.aux_off = c.aux_off; v.aux = c.aux;
+        v.n_cigar_words = n_cig;
+        v.n_aux_bytes = n_aux;
+        fc->on_chunk(fc->user, &v, n_rec, std::max(est_total, n_rec), s.ev_emit);
+      }
     };
     // the driver thread stages chunk ci, then takes the totals of chunk ci - LAG
     const uint64_t nchunk = pool.nchunks;
@@ -1330,6 +1345,12 @@ static bool first_block_is_record_aligned(const MappedFile &file)
 extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                                     char *err, size_t errlen)
 {
+  return bam_decode_device_impl(path, device, out, cols, n_targets, names, lens, err, errlen, nullptr);
+}
+
+int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens, char *err,
+                           size_t errlen, const FeedConsumer *fc)
+{
   bk_bam_dev *h = nullptr;
   try
   {
@@ -1343,11 +1364,12 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
     {
       try
       {
-        decode_chunked(file, device, h, cols);
+        decode_chunked(file, device, h, cols, fc);
       }
       catch (const not_block_aligned &)
       {
         HIP_CHECK(hipDeviceSynchronize());
+        if (fc && fc->on_reset) fc->on_reset(fc->user);
         delete h;
         h = new bk_bam_dev();
         packed = true;
@@ -1374,6 +1396,7 @@ extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **o
       }
       if (in_chunks) decode_packed_chunked(file, device, h, cols);
     }
+    if (packed && fc && fc->on_header) fc->on_header(fc->user, (int) h->names.size(), h->name_ptrs.data(), h->lens.data());
     if (n_targets) *n_targets = (int) h->names.size();
     if (names) *names = h->name_ptrs.data();
     if (lens) *lens = h->lens.data();

@@ -20,3 +20,21 @@ inline uint64_t bgzf_scratch_bytes(uint32_t nblk) { return (uint64_t) bgzf_scrat
 // file_dev must be 4-byte aligned with >= 4 readable bytes after the last block; *err_dev |= 1 when a block is malformed
 // or does not produce isize bytes
 void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st);
+
+// A consumer of the chunked GPU feed (bam_gpu.hip: decode_chunked): the stream pass of a context runs on the records of a
+// chunk while the next chunks are still being copied and inflated (bk_bam_decode_device_ctx, api.hip).
+struct FeedConsumer
+{
+  void *user = nullptr;
+  // the reference list is known (before the first record): the consumer creates its context
+  void (*on_header)(void *user, int n_targets, const char *const *names, const uint32_t *lens) = nullptr;
+  // records [0, n_ready) of the device columns are final once `ready` (recorded on the producing stream) has completed;
+  // n_est_total = the decoder's estimate of the file's record count (sizes the consumer's outputs)
+  void (*on_chunk)(void *user, const bk_soa *cols_dev, uint64_t n_ready, uint64_t n_est_total, hipEvent_t ready) = nullptr;
+  // the columns are about to move (they grow by copying): the consumer stops reading them before this returns
+  void (*before_move)(void *user) = nullptr;
+  // the decode starts over with another strategy (records across BGZF blocks): forget everything consumed so far
+  void (*on_reset)(void *user) = nullptr;
+};
+int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens, char *err,
+                           size_t errlen, const FeedConsumer *fc);

@@ -335,7 +335,10 @@ int main(int argc, char *argv[])
     fclose(probe);
   }
   const bool multi = n_gpus >= 1;  // the sharded run takes the host table and splits it over the ranks
-  if (!multi && !getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device(inp_file.c_str(), device, &dbam, &soa, &nt, &names, &lens, err, sizeof err) == BK_OK)
+  bk_ctx *ctx = nullptr;
+  // one read of the file: BGZF inflate + record decode on the device, the stream pass of the hot path running on the chunks
+  // already decoded while the rest of the file is still arriving (the reference reads the BAM twice, BreakID.cc:1929, :1414)
+  if (!multi && !getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device_ctx(inp_file.c_str(), device, qual, &dbam, &ctx, &nt, &names, &lens, err, sizeof err) == BK_OK)
     soa_where = BK_MEM_DEVICE;
   else
   {
@@ -360,7 +363,6 @@ int main(int argc, char *argv[])
       exit(1);
     }
   }
-  bk_ctx *ctx = nullptr;
   auto die = [&](int rc) {
     std::cerr << (rc == BK_ERR_CIGAR ? "error cigar: " : bk_last_error(ctx)) << std::endl;
     exit(rc == BK_ERR_CIGAR ? -1 : 1);
@@ -392,12 +394,15 @@ int main(int argc, char *argv[])
   }
   else
   {
-    if (bk_init(device, lens, names, nt, &ctx) != BK_OK)
+    if (!ctx)  // host decoder: the table is uploaded now (the GPU feed has attached it and run the stream pass already)
     {
-      std::cerr << "Error: " << bk_last_error(nullptr) << std::endl;
-      exit(1);
+      if (bk_init(device, lens, names, nt, &ctx) != BK_OK)
+      {
+        std::cerr << "Error: " << bk_last_error(nullptr) << std::endl;
+        exit(1);
+      }
+      if ((rc = bk_upload_records(ctx, &soa, soa_where)) != BK_OK) die(rc);
     }
-    if ((rc = bk_upload_records(ctx, &soa, soa_where)) != BK_OK) die(rc);
     double mean = 0, sd = 0;
     if ((rc = bk_isize_stats(ctx, &mean, &sd)) != BK_OK) die(rc);
     std::cout << "the insert size mean: " << mean << ", the insert size sd:" << sd << " .\n";

@@ -34,7 +34,8 @@ struct NameTableDev
 
 struct StreamArgs
 {
-  uint64_t n;
+  uint64_t n;        // records [4 * q_begin, n) are processed by this launch
+  uint64_t q_begin;  // first quad (4 records) of this launch; 0 unless the table arrives in pieces
   uint64_t rec_base;  // index of record 0 of this table in the whole sample (0 unless the sample is sharded)
   const int32_t *tid, *pos, *mtid, *mpos, *isize;
   const uint16_t *flag;

@@ -406,9 +406,10 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
   acc.unsorted = 0;
   const uint64_t nq = a.n / ST_V;  // full quads
   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-  const uint64_t q_round = ((nq + stride - 1) / stride) * stride;  // whole blocks stay in the loop (barriers inside)
+  // this launch covers the quads [a.q_begin, nq): the feed hands the table over in pieces (bk_bam_decode_device_ctx)
+  const uint64_t q_round = a.q_begin + ((nq - a.q_begin + stride - 1) / stride) * stride;  // whole blocks stay in the loop (barriers inside)
   unsigned int iter_no = 0;
-  for (uint64_t q = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; q < q_round; q += stride)
+  for (uint64_t q = a.q_begin + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; q < q_round; q += stride)
   {
     const bool live = q < nq;
     const uint64_t i0 = q * ST_V;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     }
   }
   // ---- tail records (n % 4) : block 0, first lanes, straight to global ----
-  if (blockIdx.x == 0 && threadIdx.x < (a.n - nq * ST_V))
+  if (blockIdx.x == 0 && threadIdx.x < (a.n - nq * ST_V))  // (a piece that is not the last one ends on a quad: no tail)
   {
     const uint64_t i = nq * ST_V + threadIdx.x;
     bool cand, sa;
@@ -803,8 +804,8 @@ __global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ 
 // ---- host side ----------------------------------------------------------------------------------------
 void launch_stream(const StreamArgs &a, hipStream_t st)
 {
-  if (a.n == 0) return;
-  unsigned blocks = cdiv(a.n / 4 + 1, 256);
+  if (a.n <= 4 * a.q_begin) return;
+  unsigned blocks = cdiv(a.n / 4 - a.q_begin + 1, 256);
   // exactly one resident set of blocks (grid-stride loop inside): a block more than fits leaves a tail that runs at
   // a fraction of the occupancy (measured 4.7 vs 6.1 TB/s at 6 vs 5 blocks per CU, LDS bins ~29 KiB per block)
   static unsigned resident = 0;

@@ -272,6 +272,14 @@ typedef struct bk_bam_dev bk_bam_dev;
 int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                          char *err, size_t errlen);
 void bk_bam_dev_free(bk_bam_dev *h);
+/* Feed and hot path overlapped: the reference reads the BAM twice, one pass after the other (BreakID.cc:1929,
+ * :1414); here the file is read once, and the record-level kernel of the hot path (insert-size sums, discordant filter,
+ * SA gate: k_stream) runs on the records of a feed chunk while the following chunks are still being copied and inflated.
+ * Creates the context itself (the reference list comes out of the file), attaches the device table (BK_MEM_DEVICE) and
+ * returns with the stream pass complete: continue with bk_isize_stats / bk_discordant_pairs(mapq_min) / ...  *bam_out owns
+ * the columns and must outlive the context.  Same file support and errors as bk_bam_decode_device. */
+int bk_bam_decode_device_ctx(const char *path, int device, int mapq_min, bk_bam_dev **bam_out, bk_ctx **ctx_out, int *n_targets, const char *const **names,
+                             const uint32_t **lens, char *err, size_t errlen);
 /* test / measurement hook: inflates a whole BGZF file image on the GPU, bytes back to the host */
 int bk_debug_bgzf_inflate(const void *file, uint64_t n, void *out, uint64_t out_cap, uint64_t *out_len, float *kernel_ms, char *err, size_t errlen);
 

@@ -331,3 +331,43 @@ def test_device_decode_of_records_across_blocks_in_chunks():
     finally:
         os.environ.pop("BREAKID_FEED_PACKED_CHUNKS", None)
         os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
+
+
+@pytest.mark.parametrize("chunk_mb", ["0.25", "64"])
+def test_stream_pass_overlapped_with_the_feed_matches_oracle(monkeypatch, capfd, chunk_mb):
+    """bk_bam_decode_device_ctx: one read of the file, k_stream running on the chunks already decoded while the rest of the file
+    arrives (the reference makes two sequential passes, BreakID.cc:1929, :1414).  Many small chunks: most records
+    go through k_stream piecewise, over column buffers that grow (and move) meanwhile; the calls must equal the oracle's."""
+    from oracle import pyoracle
+    contigs = [("chr1", 6_000_000), ("chr2", 5_000_000), ("chrX", 3_000_000)]
+    ds = synth.make_cfg(31, contigs, 400_000, 60, 40, 600, jitter=250, read_len=100)
+    ref = ds.to_soa()
+    monkeypatch.setenv("BREAKID_FEED_CHUNK_MB", chunk_mb)
+    monkeypatch.setenv("BREAKID_FEED_STATS", "1")
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "a.bam")
+        ds.write_bam(p, aligned=True)
+        ctx, table = capi.decode_bam_device_ctx(p, qual=20)
+    err = capfd.readouterr().err
+    assert "[feed/stream] stream pass overlapped" in err, err[-600:]
+    done, total = [int(v) for v in err.split("[feed/stream] stream pass overlapped:")[1].split("records")[0].replace("of", " ").split()]
+    assert total == len(ref["tid"]) and (done > total // 2 if chunk_mb == "0.25" else True), (done, total)
+    assert ctx.contigs == contigs
+    w, n_valid = ctx.run(qual=20, fast=True)
+    o = pyoracle.Oracle(contigs, ref)
+    ow, rc = o.run(20, fast=True)
+    assert rc == 0 and w == ow
+    for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_SPLITS, abi.STAGE_CLUSTERS):
+        a, _ = ctx.fetch(st)
+        b, _ = o.fetch(st)
+        assert np.array_equal(a, b), st
+    assert n_valid > 0
+    # a second run with another mapq threshold on the same context re-filters the candidates (full pass)
+    w2, _ = ctx.run(qual=30, fast=True)
+    o.run(30, fast=True)
+    a, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+    b, _ = o.fetch(abi.STAGE_CLUSTERS)
+    assert np.array_equal(a, b)
+    ctx.close()
+    table.close()
+    o.close()
