@@ -24,6 +24,44 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def from_bam_side_line(n_pairs, device, fast):
+    """File -> calls, end to end (SURVEY 8(f2/f3)): the metric of the headline line is defined on the resident table; this is
+    what a user of the command line sees.  Three timings of the same block-aligned BAM (page cache warm, best of 3): the GPU feed
+    alone (file -> device table), the feed with the stream pass overlapped (file -> table + candidates + sums), and the rest
+    of the hot path on the resident table."""
+    import torch
+    from breakid_amd import capi
+    from tools import gpu_feedbench
+    path = "/tmp/bench_from_bam_%d.bam" % n_pairs
+    n, raw, comp = gpu_feedbench.write_bam(path, n_pairs)
+    feed, over, rest, total = [], [], [], []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        table = capi.decode_bam_device(path, device)
+        t1 = time.perf_counter()
+        table.close()
+        feed.append(t1 - t0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx, table = capi.decode_bam_device_ctx(path, 20, device)
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.run(qual=20, fast=fast)
+        ctx.sync()
+        t2 = time.perf_counter()
+        over.append(t1 - t0)
+        rest.append(t2 - t1)
+        total.append(t2 - t0)
+        ctx.close()
+        table.close()
+    os.remove(path)
+    return {"records": n, "bam_MB": round(comp / 1e6, 1), "inflated_MB": round(raw / 1e6, 1),
+            "feed_only_s": round(min(feed), 4), "feed_only_M_records_per_s": round(n / min(feed) / 1e6, 1),
+            "feed_plus_stream_pass_overlapped_s": round(min(over), 4), "feed_plus_stream_pass_M_records_per_s": round(n / min(over) / 1e6, 1),
+            "rest_of_hot_path_s": round(min(rest), 4), "file_to_calls_s": round(min(total), 4), "file_to_calls_M_records_per_s": round(n / min(total) / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,6 +73,9 @@ def main():
     ap.add_argument("--seed", type=int, default=12346)
     ap.add_argument("--workload", default="wgs", choices=["wgs", "panel"],
                     help="wgs = configs[1] (the headline line); panel = configs[3] targeted-panel shape (500 loci x 2000x, single GPU, side measurement)")
+    ap.add_argument("--from-bam", type=int, default=0, metavar="PAIRS",
+                    help="side measurement (N=1): write a synthetic BAM of PAIRS read pairs and time file -> calls end to end: GPU feed alone, feed with the "
+                         "stream pass overlapped (bk_bam_decode_device_ctx), rest of the hot path")
     ap.add_argument("--sharded", type=int, default=-1, help="1: one sample sharded over the ranks (default when --gpus > 1), 0: plain single-table run")
     args = ap.parse_args()
 
@@ -211,6 +252,8 @@ def main():
                                              "GPU result on the sample bit-identical: %s" % (scols["n"], cpu_s, exact)}
             sctx.close()
             o.close()
+        if world == 1 and args.from_bam > 0:
+            out["from_bam"] = from_bam_side_line(args.from_bam, local_rank, fast)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist.is_initialized():

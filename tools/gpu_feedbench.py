@@ -102,6 +102,20 @@ if __name__ == "__main__":
         print("GPU decoder: file -> device table %.3f s = %.1f M records/s, %.0f MB/s of BAM; run %.1f ms" % (t1 - t0, n / (t1 - t0) / 1e6, comp / (t1 - t0) / 1e6, (t2 - t1) * 1e3), flush=True)
         ctx.close()
         table.close()
+    # feed and stream pass overlapped (bk_bam_decode_device_ctx): k_stream runs on the chunks already decoded
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx, table = capi.decode_bam_device_ctx(path, qual=20)
+        ctx.sync()
+        t1 = time.perf_counter()
+        w, nv = ctx.run(qual=20, fast=True)
+        ctx.sync()
+        t2 = time.perf_counter()
+        print("GPU decoder + stream pass overlapped: file -> device table AND candidates/sums %.3f s = %.1f M records/s, %.0f MB/s of BAM; rest of the hot path %.1f ms; "
+              "file -> calls %.3f s = %.1f M records/s" % (t1 - t0, n / (t1 - t0) / 1e6, comp / (t1 - t0) / 1e6, (t2 - t1) * 1e3, t2 - t0, n / (t2 - t0) / 1e6), flush=True)
+        ctx.close()
+        table.close()
     # the same records in fixed-size blocks (records across BGZF blocks, as htsjdk / Picard write them): one-batch variant
     path2 = "/tmp/feed_%d_across.bam" % n_pairs
     n2, raw2, comp2 = write_bam(path2, n_pairs, aligned=False)
