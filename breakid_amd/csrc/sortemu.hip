@@ -708,10 +708,121 @@ template <bool GLB, bool PIPE = false> __device__ __forceinline__ void sort_heap
   }
 }
 
+// ---- third form of the pop pipeline: ranked entries in LDS, no existence masks ------------------------------------------
+// Entries are ((rank + 1) << 16 | local index), never 0.  The heap lives in LDS slots 1..m (slot s at base - 4 + 4 s, so the
+// children of hole h are the adjacent slots 2h, 2h + 1); slot 0 is scratch, slots m + 1, m + 2 hold zeros and child
+// addresses beyond them are clamped onto them.  A detached leaf slot is ZEROED and the popped root goes straight to the
+// output array in global memory (a store nobody waits for) instead of into the freed slot.  A zero reads as "rank below
+// every value": the sift stops in front of a child that does not exist (any more) without a per-lane heap length, so the
+// two existence masks of the loops above, their SALU round trips and the key extraction are gone:
+//   right >= left by rank  <=>  (right | 0xffff) >= left          child >= value by rank  <=>  (child | 0xffff) >= value
+// An idle lane sits on hole 0 with value 0xffffffff: it reads slots 0 / 1, never descends, stores into slot 0, and can
+// never look like an ancestor of the leaf to detach.  Same lag-2 launch rule and ancestor stall as above (a slot is only
+// zeroed when no pop in flight can still reach it).  17 instructions per sift step (was 21 + 2 SALU).
+// Per-lane: hole v40, value v42.  Uniform: next_t s41, L s43, clz(L) s44, budget s45, t_end s46, clamp address s42.
+#define BK_HEAP32Z_STEP                                                                                                   \
+  "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
+  "v_lshl_add_u32 v45, v44, 2, s40\n"                                                                                      \
+  "v_min_u32 v45, s42, v45\n"                                                                                              \
+  "ds_read2_b32 v[46:47], v45 offset1:1\n"                                                                                 \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "v_mov_b32 v54, v40\n"                                                                                                   \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+  "v_or_b32 v48, 0xffff, v47\n"                                                                                            \
+  "v_cmp_ge_u32 vcc, v48, v46\n"                                                                                           \
+  "v_cndmask_b32 v50, v46, v47, vcc\n"                                                                                     \
+  "v_addc_co_u32 v53, vcc, 0, v44, vcc\n"                                                                                  \
+  "v_or_b32 v49, 0xffff, v50\n"                                                                                            \
+  "v_cmp_ge_u32 vcc, v49, v42\n"                                                                                           \
+  "v_cndmask_b32 v51, v42, v50, vcc\n"                                                                                     \
+  "ds_write_b32 v52, v51\n"                                                                                                \
+  "v_cndmask_b32 v40, v55, v53, vcc\n"                                                                                     \
+  "v_cndmask_b32 v42, v59, v42, vcc\n"
+#define BK_HEAP32Z_ASM                                                                                                    \
+  "v_mov_b32 v62, %[lane]\n"                                                                                               \
+  "s_mov_b32 s62, %[olo]\n s_mov_b32 s63, %[ohi]\n"                                                                        \
+  "s_sub_u32 s40, %[base], 4\n"                                                                                            \
+  "v_mov_b32 v60, %[base]\n"                                                                                               \
+  "s_mov_b32 s46, %[tend]\n s_mov_b32 s41, 1\n s_mov_b32 s43, %[m]\n"                                                     \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "s_lshl_b32 s47, s43, 2\n s_add_u32 s42, s47, %[base]\n"                                                                 \
+  "s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                                         \
+  "s_lshl_b32 s47, s43, 2\n s_sub_u32 s47, s47, 4\n v_mov_b32 v57, s47\n"                                                  \
+  "s_mov_b32 s45, %[budget]\n"                                                                                             \
+  "v_mov_b32 v55, 0\n v_mov_b32 v59, -1\n v_mov_b32 v40, 0\n v_mov_b32 v42, -1\n"                                          \
+  "s_branch BK_ZB_%=\n"                                                                                                    \
+  "BK_ZA_%=:\n"                                                                                                           \
+  BK_HEAP32Z_STEP                                                                                                         \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc1 BK_ZDONE_%=\n"                                                                                           \
+  "BK_ZB_%=:\n"                                                                                                           \
+  "ds_read_b32 v56, v60\n"                                                                                                 \
+  "ds_read_b32 v58, v61\n"                                                                                                 \
+  BK_HEAP32Z_STEP                                                                                                         \
+  "s_cmp_ge_u32 s41, s46\n"                                                                                                \
+  "s_cbranch_scc1 BK_ZNOMORE_%=\n"                                                                                         \
+  "v_ffbh_u32 v63, v40\n"                                                                                                  \
+  "v_subrev_u32 v63, s44, v63\n"                                                                                           \
+  "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
+  "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
+  "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
+  "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
+  "s_cbranch_vccnz BK_ZBNEXT_%=\n"                                                                                         \
+  "s_and_b32 s47, s41, 63\n"                                                                                               \
+  "v_cmp_eq_u32 vcc, s47, v62\n"                                                                                           \
+  "s_and_saveexec_b64 s[56:57], vcc\n"                                                                                     \
+  "ds_write_b32 v61, v55\n"                                                                                                \
+  "global_store_dword v57, v56, s[62:63]\n"                                                                                \
+  "v_mov_b32 v42, v58\n v_mov_b32 v40, 1\n"                                                                                \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "s_add_u32 s41, s41, 1\n"                                                                                                \
+  "s_sub_u32 s43, s43, 1\n"                                                                                                \
+  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
+  "v_add_u32 v61, -4, v61\n"                                                                                               \
+  "v_add_u32 v57, -4, v57\n"                                                                                               \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_ZA_%=\n"                                                                                              \
+  "s_branch BK_ZDONE_%=\n"                                                                                                 \
+  "BK_ZNOMORE_%=:\n"                                                                                                      \
+  "v_cmp_ne_u32 vcc, 0, v40\n"                                                                                             \
+  "s_cbranch_vccz BK_ZDONE_%=\n"                                                                                           \
+  "BK_ZBNEXT_%=:\n"                                                                                                       \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_ZB_%=\n"                                                                                              \
+  "BK_ZDONE_%=:\n"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+  "s_mov_b32 %[left], s45\n"
+
+// slot1 = LDS address of slot 1 (slot 0 in front of it and the two zero slots behind slot m belong to the caller); pops
+// t = 1 .. m - 1 store the popped roots to out[m - 1] .. out[1]; the last element stays in slot 1
+__device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32_t m, uint32_t *out)
+{
+  if (m < 2) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t_end = __builtin_amdgcn_readfirstlane(m);
+  const uint32_t budget = __builtin_amdgcn_readfirstlane(64u * m + 4096u);
+  const uint32_t mm = __builtin_amdgcn_readfirstlane(m);
+  const unsigned long long o = (unsigned long long) out;
+  const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t) o), ohi = __builtin_amdgcn_readfirstlane((uint32_t) (o >> 32));
+  const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t) (unsigned long long) slot1);  // low half of a flat LDS address = byte offset inside LDS
+  uint32_t left;
+  asm volatile(BK_HEAP32Z_ASM
+               : [left] "=s"(left)
+               : [lane] "v"(lane), [olo] "s"(olo), [ohi] "s"(ohi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
+               : BK_HEAP_CLOBBERS);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0)
+  {
+    atomicAdd(&g_heap_iters[0], (unsigned long long) (budget - left));
+    atomicAdd(&g_heap_iters[1], (unsigned long long) (t_end - 1));
+  }
+}
+
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
-constexpr uint32_t HEAP_LARGE32 = 40000; // the same LDS in 4-byte ranked entries
-constexpr uint32_t HEAP_RANKED_MAX = 65536;
+constexpr uint32_t HEAP_LARGE32 = 40000; // the same LDS in 4-byte ranked entries (+ slot 0 and two zero slots)
+constexpr uint32_t HEAP_RANKED_MIN = 4096;   // level-loop heaps above this size run on ranked entries (sort_heap_lds_zero)
+constexpr uint32_t HEAP_RANKED_MAX = 65535;  // rank + 1 must fit 16 bits
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
 // (lo, hi]: the sizes this launch takes (CLS 1 is launched once per LDS footprint so that small heaps share a CU)
@@ -732,39 +843,44 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
   __syncthreads();
   if (CLS == 2 && ASM && rank32 != nullptr && m <= HEAP_RANKED_MAX)
   {
-    // ranked 4-byte entries (see E32): up to HEAP_LARGE32 of them fit LDS.  buf keeps the packed originals.
+    // ranked 4-byte entries ((rank + 1) << 16 | local index, never 0): up to HEAP_LARGE32 of them fit LDS (slots 1..m of l32,
+    // slot 0 scratch, two zero slots behind).  buf keeps the packed originals; the sorted entries end up in g32.
     const unsigned long long tp0 = wall_clock64();
     uint32_t *l32 = reinterpret_cast<uint32_t *>(dyn);
     uint32_t *g32 = scratch32 + sg.first;
     const bool fits = m <= HEAP_LARGE32;
-    uint32_t *e32 = fits ? l32 : g32;
-    for (uint32_t i = threadIdx.x; i < m; i += 64) e32[i] = (rank32[sg.first + i] << 16) | i;
-    __syncthreads();
-    const unsigned long long tp1 = wall_clock64();
-    unsigned long long tp2 = tp1, tp3 = tp1;
+    unsigned long long tp1, tp2, tp3;
     if (fits)
     {
-      LdsMemT<E32> mem{l32};
+      for (uint32_t i = threadIdx.x; i < m; i += 64) l32[1 + i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : m + threadIdx.x] = 0;
+      __syncthreads();
+      tp1 = wall_clock64();
+      LdsMemT<E32> mem{l32 + 1};
       make_heap_wave(mem, m);
       tp2 = tp3 = wall_clock64();
-      sort_heap_asm32<false, true>(l32, m, 1);  // (the pipelined loop measured 3.5 % faster here, 2.5 % slower behind a global-memory phase)
+      sort_heap_lds_zero(l32 + 1, m, g32);
     }
     else
     {
+      for (uint32_t i = threadIdx.x; i < m; i += 64) g32[i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      __syncthreads();
+      tp1 = wall_clock64();
       GlbMemT<E32> gmem{g32};
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       make_heap_wave(gmem, m);
       tp2 = wall_clock64();
-      sort_heap_asm32<true>(g32, m, HEAP_LARGE32);
+      sort_heap_asm32<true>(g32, m, HEAP_LARGE32);  // pops in global memory until the heap fits LDS
       tp3 = wall_clock64();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) l32[i] = g32[i];
+      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) l32[1 + i] = g32[i];
+      if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
       __syncthreads();
-      sort_heap_asm32<false>(l32, HEAP_LARGE32, 1);
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) g32[i] = l32[i];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      sort_heap_lds_zero(l32 + 1, HEAP_LARGE32, g32);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) g32[0] = l32[1];  // the last element never leaves the root
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long tp4 = wall_clock64();
     if (threadIdx.x == 0 && m > 36000)
@@ -777,7 +893,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
     }
     for (uint32_t i = threadIdx.x; i < m; i += 64)
     {
-      const hent e = buf[e32[i] & 0xFFFFu];
+      const hent e = buf[g32[i] & 0xFFFFu];
       gk[i] = hkey(e);
       gx[i] = (uint32_t) e;
     }
@@ -814,13 +930,13 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
   }
 }
 
-// ---- dense key ranks inside the heap segments of the ranked class (HEAP_LARGE < m <= HEAP_RANKED_MAX) ----------------
+// ---- dense key ranks inside the heap segments of the ranked class (HEAP_RANKED_MIN < m <= HEAP_RANKED_MAX) ----------
 __global__ void k_hr_count(const HeapSeg *__restrict__ hs, uint32_t nh, unsigned long long *__restrict__ cnt)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nh) return;
   const uint32_t m = hs[s].last - hs[s].first;
-  cnt[s] = (m > HEAP_LARGE && m <= HEAP_RANKED_MAX) ? (1ull | ((unsigned long long) m << 32)) : 0ull;
+  cnt[s] = (m > HEAP_RANKED_MIN && m <= HEAP_RANKED_MAX) ? (1ull | ((unsigned long long) m << 32)) : 0ull;
 }
 // one block per heap segment: (ordinal << 32 | key, position) of every element of a ranked-class segment
 __global__ __launch_bounds__(256) void k_hr_gather(const HeapSeg *__restrict__ hs, uint32_t nh, const unsigned long long *__restrict__ off, const uint32_t *__restrict__ key,
@@ -828,7 +944,7 @@ __global__ __launch_bounds__(256) void k_hr_gather(const HeapSeg *__restrict__ h
 {
   const uint32_t s = blockIdx.x;
   const uint32_t first = hs[s].first, m = hs[s].last - first;
-  if (!(m > HEAP_LARGE && m <= HEAP_RANKED_MAX)) return;
+  if (!(m > HEAP_RANKED_MIN && m <= HEAP_RANKED_MAX)) return;
   const uint32_t ord = (uint32_t) off[s], base = (uint32_t) (off[s] >> 32);
   if (threadIdx.x == 0) ordbase[ord] = base;
   for (uint32_t i = threadIdx.x; i < m; i += 256)
@@ -1664,7 +1780,9 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     }
     // heaps of HEAP_LARGE+1 .. HEAP_RANKED_MAX elements run on ranked 4-byte entries: rank their keys first
     static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
-    if (max1 > HEAP_LARGE && use_asm && !no_ranked)
+    const bool ranked_on = use_asm && !no_ranked;
+    const uint32_t big_lo = ranked_on ? HEAP_RANKED_MIN : HEAP_LARGE;  // heaps above this size go to the one-per-CU kernel
+    if (max1 > HEAP_RANKED_MIN && ranked_on)
     {
       unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
       hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
@@ -1694,18 +1812,18 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     auto big = [&](auto k1, auto k2) {
       // largest class first
       HIP_CHECK(hipEventRecord(b.fork, st));
-      if (max1 > HEAP_LARGE)
+      if (max1 > big_lo)
       {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        side(k2, dyn, hl, nh1, HEAP_LARGE, 0xFFFFFFFFu);
+        side(k2, dyn, hl, nh1, big_lo, 0xFFFFFFFFu);
       }
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
       const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
       // one launch per LDS footprint (BK_HEAP_CLASSES=1) packs more mid-size heaps per CU but measured slower
       // end to end (197 vs 187 ms per step): the extra activity slows the lone wave on the critical path
       static const bool split = getenv("BK_HEAP_CLASSES") != nullptr;
-      if (!split)
-        side(k1, dyn, hl, nh1, HEAP_SMALL, HEAP_LARGE);
+      if (!split || ranked_on)
+        side(k1, ((size_t) big_lo + HEAP_PAD) * 8, hl, nh1, HEAP_SMALL, big_lo);
       else
         for (int c = 0; c < 4; ++c)
           if (max1 > bounds[c + 1]) side(k1, ((size_t) bounds[c] + HEAP_PAD) * 8, hl, nh1, bounds[c + 1], bounds[c]);
