@@ -18,6 +18,8 @@ struct RecView
   const uint16_t *flag;
   const uint8_t *mapq;
   const uint32_t *cigar_off, *cigar;
+  const unsigned long long *samp = nullptr;  // search keys of every 1024th record (bp.hip: rec_lower), or null
+  uint64_t n_samp = 0;
 };
 
 struct BpWork
@@ -28,7 +30,7 @@ struct BpWork
 
 struct BpBufs
 {
-  DevBuf key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted, nvalid;
+  DevBuf samp, key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted, nvalid;
   prims::RadixBufs radix;
 };
 

@@ -159,10 +159,27 @@ __device__ __forceinline__ int32_t rec_endpos(const RecView &r, uint64_t i)
   }
   return pos + 1;
 }
-// first record index with (tid,pos) >= (T,P) in coordinate order (unmapped tid=-1 sorts last)
+// first record index with (tid,pos) >= (T,P) in coordinate order (unmapped tid=-1 sorts last).  A search over the whole table
+// is ~30 dependent HBM round trips per region; with the sampled keys of every REC_SAMPLE-th record (5 MB for 620 M records:
+// cache resident) the first ~20 steps stay in the cache and only the last 10 touch the record columns.
+constexpr uint32_t REC_SAMPLE_SHIFT = 10;
+__device__ __forceinline__ unsigned long long rec_key(int32_t tid, long long pos) { return ((unsigned long long) (uint32_t) tid << 32) | (uint32_t) (pos + 0x80000000ll); }
 __device__ uint64_t rec_lower(const RecView &r, int32_t T, long long P)
 {
   uint64_t lo = 0, hi = r.n;
+  if (r.samp)
+  {
+    // samp[j] = key of record j << REC_SAMPLE_SHIFT; first sample >= target bounds the answer to one stride
+    const unsigned long long want = rec_key(T, P < -0x80000000ll ? -0x80000000ll : P);
+    uint64_t a = 0, b = r.n_samp;
+    while (a < b)
+    {
+      const uint64_t m = (a + b) >> 1;
+      if (r.samp[m] < want) a = m + 1; else b = m;
+    }
+    lo = a ? ((a - 1) << REC_SAMPLE_SHIFT) + 1 : 0;  // record (a-1)<<shift is < target, record a<<shift is >= target
+    hi = a < r.n_samp ? (a << REC_SAMPLE_SHIFT) : r.n;
+  }
   const uint32_t Tu = (uint32_t) T;
   while (lo < hi)
   {
@@ -172,6 +189,11 @@ __device__ uint64_t rec_lower(const RecView &r, int32_t T, long long P)
     if (lt) lo = m + 1; else hi = m;
   }
   return lo;
+}
+__global__ __launch_bounds__(256) void k_rec_sample(const int32_t *__restrict__ tid, const int32_t *__restrict__ pos, uint64_t n_samp, unsigned long long *__restrict__ samp)
+{
+  const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_samp) samp[j] = rec_key(tid[j << REC_SAMPLE_SHIFT], (long long) pos[j << REC_SAMPLE_SHIFT]);
 }
 __device__ uint64_t split_lower(const bk_split *__restrict__ sp, uint64_t ns, uint64_t rec)
 {
@@ -390,6 +412,27 @@ __device__ bool key_less(int32_t a1, int32_t a2, int32_t b1, int32_t b2)
   return la < lb;
 }
 
+// The same order without building the texts: the decimal text of one int32 ("-" and up to 10 digits) as 11 four-bit codes,
+// first character in the highest nibble ('-' = 2, digits = 3..12), the unused low nibbles filled with `pad`.  With pad = 1
+// for the first number (the ',' that follows it: below '-' and the digits, as in ASCII) and pad = 0 for the second (end of
+// text), "p1,p2" < "q1,q2" as std::string  <=>  (code(p1), code(p2)) < (code(q1), code(q2)) as integers.
+__device__ __forceinline__ unsigned long long key_code(int32_t v, unsigned long long pad)
+{
+  const bool neg = v < 0;
+  uint32_t u = neg ? (uint32_t) (-(long long) v) : (uint32_t) v;
+  unsigned long long code = 0;
+  int len = 0;
+  do
+  {
+    code |= (unsigned long long) (3u + u % 10u) << (4 * len);
+    u /= 10u;
+    ++len;
+  } while (u);
+  if (neg) code |= 2ull << (4 * len++);
+  const int sh = 4 * (11 - len);
+  return (code << sh) | ((0x11111111111ull * pad) & ((1ull << sh) - 1ull));
+}
+
 constexpr uint32_t VOTE_LDS = 256;
 // phase 3: emit (p1_bp, p2_bp) for every match and vote (find_bp_pair); voted[c] = 1 when encompass_num >= 2 (:446)
 __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp, bk_cluster *__restrict__ cl, uint32_t ncl, int wi, const BpWork *__restrict__ work,
@@ -458,6 +501,7 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
   // arithmetic, :820-821); first strict maximum in std::map<string> order wins
   int best_cnt = 0;
   int32_t best1 = 0, best2 = 0;
+  unsigned long long bk1 = 0, bk2 = 0;  // key_code of (best1, best2): the text order of the keys as an integer order
   for (uint32_t q = lane; q < K; q += 64)
   {
     const int2 e = E[q];
@@ -468,22 +512,31 @@ __global__ __launch_bounds__(256) void k_bp_vote(const bk_split *__restrict__ sp
       const int2 u = E[m];
       if (((uint32_t) u.x <= t1 + 2u && (uint32_t) u.x >= t1 - 2u) && ((uint32_t) u.y <= t2 + 2u && (uint32_t) u.y >= t2 - 2u)) ++cnt;
     }
-    if (cnt > best_cnt || (cnt == best_cnt && cnt > 0 && key_less(e.x, e.y, best1, best2)))
+    if (cnt >= best_cnt && cnt > 0)
     {
-      best_cnt = cnt;
-      best1 = e.x;
-      best2 = e.y;
+      const unsigned long long k1 = key_code(e.x, 1ull), k2 = key_code(e.y, 0ull);
+      if (cnt > best_cnt || k1 < bk1 || (k1 == bk1 && k2 < bk2))
+      {
+        best_cnt = cnt;
+        best1 = e.x;
+        best2 = e.y;
+        bk1 = k1;
+        bk2 = k2;
+      }
     }
   }
   for (int d = 32; d; d >>= 1)
   {
-    int oc = __shfl_xor(best_cnt, d, 64);
-    int32_t o1 = __shfl_xor(best1, d, 64), o2 = __shfl_xor(best2, d, 64);
-    if (oc > best_cnt || (oc == best_cnt && oc > 0 && key_less(o1, o2, best1, best2)))
+    const int oc = __shfl_xor(best_cnt, d, 64);
+    const int32_t o1 = __shfl_xor(best1, d, 64), o2 = __shfl_xor(best2, d, 64);
+    const unsigned long long ok1 = __shfl_xor(bk1, d, 64), ok2 = __shfl_xor(bk2, d, 64);
+    if (oc > best_cnt || (oc == best_cnt && oc > 0 && (ok1 < bk1 || (ok1 == bk1 && ok2 < bk2))))
     {
       best_cnt = oc;
       best1 = o1;
       best2 = o2;
+      bk1 = ok1;
+      bk2 = ok2;
     }
   }
   if (best_cnt >= 2 && lane == 0)  // :446
@@ -655,8 +708,24 @@ uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32
   return nk;
 }
 
-uint32_t *bp_cov_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl, double w, int maxspan, BpBufs &b, hipStream_t st)
+// the record view with the sampled search keys behind it (rebuilt per call: the table may have been replaced)
+static RecView sampled(const RecView &r, BpBufs &b, hipStream_t st)
 {
+  RecView v = r;
+  v.n_samp = (r.n + (1ull << REC_SAMPLE_SHIFT) - 1) >> REC_SAMPLE_SHIFT;
+  v.samp = nullptr;
+  if (r.n >= (64ull << REC_SAMPLE_SHIFT))
+  {
+    unsigned long long *sp = b.samp.as<unsigned long long>(v.n_samp + 1);
+    hipLaunchKernelGGL(k_rec_sample, dim3(cdiv(v.n_samp, 256)), dim3(256), 0, st, r.tid, r.pos, v.n_samp, sp);
+    v.samp = sp;
+  }
+  return v;
+}
+
+uint32_t *bp_cov_partial(const RecView &r0, const bk_cluster *cl, uint64_t ncl, double w, int maxspan, BpBufs &b, hipStream_t st)
+{
+  const RecView r = sampled(r0, b, st);
   uint32_t *cov = b.cov.as<uint32_t>(2 * ncl + 2);
   if (ncl) hipLaunchKernelGGL(k_bp_cov, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, cl, (uint32_t) ncl, (int) w, maxspan, cov);
   return cov;
@@ -708,8 +777,9 @@ void bp_vote(const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, dou
   hipLaunchKernelGGL(k_bp_vote, dim3(cdiv(ncl, 4)), dim3(256), 0, st, sp, cl, (uint32_t) ncl, wi, work, moff, emit, ecount, hdr_id, voted);
 }
 
-uint32_t *bp_depth_partial(const RecView &r, const bk_cluster *cl, uint64_t ncl, int maxspan, BpBufs &b, hipStream_t st)
+uint32_t *bp_depth_partial(const RecView &r0, const bk_cluster *cl, uint64_t ncl, int maxspan, BpBufs &b, hipStream_t st)
 {
+  const RecView r = sampled(r0, b, st);
   uint32_t *depth = b.depth.as<uint32_t>(2 * ncl + 2);
   if (ncl) hipLaunchKernelGGL(k_bp_depth, dim3(cdiv(ncl, 4)), dim3(256), 0, st, r, cl, (uint32_t) ncl, maxspan, b.voted.get<uint32_t>(), depth);
   return depth;
