@@ -826,7 +826,11 @@ constexpr uint32_t HEAP_RANKED_MAX = 65535;  // rank + 1 must fit 16 bits
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
 // (lo, hi]: the sizes this launch takes (CLS 1 is launched once per LDS footprint so that small heaps share a CU)
-template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+// CLS 2 runs with HEAP_BIG_THREADS threads: the loads, the ranking and the final gather of a 40 000-element segment are
+// 700 dependent round trips for a lone wave (0.9 ms) and a fraction of that for four; the heap itself belongs to wave 0,
+// the other waves sleep at the barriers meanwhile.
+constexpr uint32_t HEAP_BIG_THREADS = 256;
+template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                                        hent *__restrict__ scratch, uint32_t lo, uint32_t hi,
                                                                        const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32)
 {
@@ -839,7 +843,9 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
   if (m <= lo || m > hi) return;
   uint32_t *gk = key + sg.first, *gx = idx + sg.first;
   hent *buf = CLS == 0 ? stat : (CLS == 1 ? dyn : scratch + sg.first);
-  for (uint32_t i = threadIdx.x; i < m; i += 64) buf[i] = ((hent) gk[i] << 32) | gx[i];
+  const uint32_t NT = CLS == 2 ? HEAP_BIG_THREADS : 64;  // = blockDim.x
+  const bool w0 = threadIdx.x < 64;                       // the wave that owns the heap
+  for (uint32_t i = threadIdx.x; i < m; i += NT) buf[i] = ((hent) gk[i] << 32) | gx[i];
   __syncthreads();
   if (CLS == 2 && ASM && rank32 != nullptr && m <= HEAP_RANKED_MAX)
   {
@@ -852,31 +858,41 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
     unsigned long long tp1, tp2, tp3;
     if (fits)
     {
-      for (uint32_t i = threadIdx.x; i < m; i += 64) l32[1 + i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      for (uint32_t i = threadIdx.x; i < m; i += NT) l32[1 + i] = ((rank32[sg.first + i] + 1u) << 16) | i;
       if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : m + threadIdx.x] = 0;
       __syncthreads();
       tp1 = wall_clock64();
-      LdsMemT<E32> mem{l32 + 1};
-      make_heap_wave(mem, m);
+      if (w0)
+      {
+        LdsMemT<E32> mem{l32 + 1};
+        make_heap_wave(mem, m);
+      }
       tp2 = tp3 = wall_clock64();
-      sort_heap_lds_zero(l32 + 1, m, g32);
+      if (w0) sort_heap_lds_zero(l32 + 1, m, g32);
     }
     else
     {
-      for (uint32_t i = threadIdx.x; i < m; i += 64) g32[i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      for (uint32_t i = threadIdx.x; i < m; i += NT) g32[i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       tp1 = wall_clock64();
-      GlbMemT<E32> gmem{g32};
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      make_heap_wave(gmem, m);
+      if (w0)
+      {
+        GlbMemT<E32> gmem{g32};
+        make_heap_wave(gmem, m);
+      }
       tp2 = wall_clock64();
-      sort_heap_asm32<true>(g32, m, HEAP_LARGE32);  // pops in global memory until the heap fits LDS
+      if (w0)
+      {
+        sort_heap_asm32<true>(g32, m, HEAP_LARGE32);  // pops in global memory until the heap fits LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       tp3 = wall_clock64();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += 64) l32[1 + i] = g32[i];
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += NT) l32[1 + i] = g32[i];
       if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
       __syncthreads();
-      sort_heap_lds_zero(l32 + 1, HEAP_LARGE32, g32);
+      if (w0) sort_heap_lds_zero(l32 + 1, HEAP_LARGE32, g32);
     }
     __syncthreads();
     if (threadIdx.x == 0) g32[0] = l32[1];  // the last element never leaves the root
@@ -891,7 +907,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
       g_heap_phase[3] = tp3 - tp2;
       g_heap_phase[4] = tp4 - tp3;
     }
-    for (uint32_t i = threadIdx.x; i < m; i += 64)
+    for (uint32_t i = threadIdx.x; i < m; i += NT)
     {
       const hent e = buf[g32[i] & 0xFFFFu];
       gk[i] = hkey(e);
@@ -902,17 +918,24 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
   if (CLS == 2)
   {
     // too large for LDS: heapify and pop in global memory until the heap fits, then finish in LDS
-    GlbMem gmem{buf};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    make_heap_wave(gmem, m);
-    if (ASM) sort_heap_asm<true>(buf, m, HEAP_LARGE); else sort_heap_lag2(gmem, m, HEAP_LARGE);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) dyn[i] = buf[i];
+    if (w0)
+    {
+      GlbMem gmem{buf};
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      make_heap_wave(gmem, m);
+      if (ASM) sort_heap_asm<true>(buf, m, HEAP_LARGE); else sort_heap_lag2(gmem, m, HEAP_LARGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    LdsMem lmem{dyn};
-    if (ASM) sort_heap_asm<false>(dyn, HEAP_LARGE, 1); else sort_heap_lag2(lmem, HEAP_LARGE, 1);
+    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += NT) dyn[i] = buf[i];
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += 64) buf[i] = dyn[i];
+    if (w0)
+    {
+      LdsMem lmem{dyn};
+      if (ASM) sort_heap_asm<false>(dyn, HEAP_LARGE, 1); else sort_heap_lag2(lmem, HEAP_LARGE, 1);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += NT) buf[i] = dyn[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   else
@@ -922,7 +945,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(64) void k_se_heapsort
     if (ASM) sort_heap_asm<false>(buf, m, 1); else sort_heap_lag2(mem, m, 1);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < m; i += 64)
+  for (uint32_t i = threadIdx.x; i < m; i += NT)
   {
     const hent e = buf[i];
     gk[i] = hkey(e);
@@ -1736,9 +1759,9 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       }
     }
   }
-  auto side = [&](auto k, size_t lds, const HeapSeg *list, uint32_t count, uint32_t lo, uint32_t hi) {
+  auto side = [&](auto k, size_t lds, const HeapSeg *list, uint32_t count, uint32_t lo, uint32_t hi, uint32_t threads = 64) {
     HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-    hipLaunchKernelGGL(k, dim3(count), dim3(64), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32);
+    hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32);
     HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
     ++used;
   };
@@ -1815,7 +1838,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (max1 > big_lo)
       {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        side(k2, dyn, hl, nh1, big_lo, 0xFFFFFFFFu);
+        side(k2, dyn, hl, nh1, big_lo, 0xFFFFFFFFu, HEAP_BIG_THREADS);
       }
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
       const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
