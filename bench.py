@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# two lanes of chromosome-pair groups in bk_mask_and_cluster (csrc/api.hip) need more hardware queues than ROCm's default of 4
+# (the heap kernels of both lanes sit on side streams); the runtime reads this when it starts, i.e. before torch touches the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("BREAKID_GROUP_LANES", "2")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

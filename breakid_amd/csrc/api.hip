@@ -2,7 +2,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <numeric>
+#include <thread>
 
 #include "bk_common.h"
 #include "prims.h"
@@ -97,6 +99,21 @@ struct bk_ctx
   ClusterBufs cb;
   PairList list;
   DevBuf iso_idx, iso_goff, d_cluster;
+  // second lane of chromosome-pair groups (bk_mask_and_cluster): its own buffers, stream and host thread
+  struct Lane
+  {
+    ClusterBufs cb;
+    PairList list, iso;
+    DevBuf d_cluster, d_drop;
+    hipStream_t st = nullptr;
+    ~Lane()
+    {
+      if (st) (void) hipStreamDestroy(st);
+    }
+  };
+  std::unique_ptr<Lane> lane2;
+  PairList listA, isoA;  // first lane's lists before the merge
+  DevBuf d_clusterA, d_dropA;
   uint64_t iso_n = 0;
   bool clustered = false;
   AhcBufs ab;
@@ -578,9 +595,113 @@ int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, 
   });
 }
 
+// Two lanes.  The reference clusters its chromosome-pair groups one after the other and independently of each other
+// (BreakID.cc:119-167).  All groups in one pass pay, in each of the five sorts, the longest heapsort segment of ANY group; two
+// disjoint sets of groups on two streams, each driven by its own host thread, overlap the lone-wave heaps of one set with the
+// bandwidth- and launch-bound partition levels of the other.  Needs more hardware queues than ROCm's default of 4 (the heap
+// kernels of both lanes sit on side streams that must not share a queue): enabled by BREAKID_GROUP_LANES=2 (bench.py and the
+// command line set it together with GPU_MAX_HW_QUEUES before the runtime starts).  Results are identical by construction:
+// the groups never interact, the lanes' lists are merged back into group order.
+static void run_lane(const bk_pair *pairs, const uint32_t *gof, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, int fast, const uint32_t *drop, PairList &L, PairList &iso,
+                     DevBuf &d_cluster, ClusterBufs &cb, AhcBufs &ab, hipStream_t st)
+{
+  remove_isolated_all(pairs, gof, gstart, ng, n, w, L, cb, st, drop);
+  iso.n = L.n;
+  iso.ng = L.ng;
+  uint32_t *ii = iso.idx.as<uint32_t>(L.n + 1), *ig = iso.gof.as<uint32_t>(L.n + 1);
+  uint64_t *io = iso.goff.as<uint64_t>((uint64_t) L.ng + 1);
+  if (L.n) HIP_CHECK(hipMemcpyAsync(ii, L.idx.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToDevice, st));
+  if (L.n) HIP_CHECK(hipMemcpyAsync(ig, L.gof.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(io, L.goff.get<uint64_t>(), ((uint64_t) L.ng + 1) * 8, hipMemcpyDeviceToDevice, st));
+  if (fast)
+    fast_cluster_all(pairs, L, w, d_cluster, cb, st);
+  else
+    ahc_cluster_all(pairs, L, w, d_cluster, ab, cb, st);
+}
+
+static bool lanes_apply(const bk_ctx *ctx, int fast)
+{
+  static const int want = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 1;
+  static const uint64_t min_pairs = getenv("BREAKID_LANES_MIN_PAIRS") ? strtoull(getenv("BREAKID_LANES_MIN_PAIRS"), nullptr, 10) : (1ull << 20);  // below: launch-bound anyway
+  return want >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->own_groups.empty() && ctx->jr.n_pairs >= min_pairs;
+}
+
+static void two_lanes(bk_ctx *ctx, double w, int fast)
+{
+  const uint32_t ng = ctx->jr.n_groups;
+  // lanes by longest-processing-time on the pair counts (the heavy same-chromosome groups alternate between the lanes)
+  std::vector<uint32_t> order(ng);
+  std::iota(order.begin(), order.end(), 0u);
+  auto size_of = [&](uint32_t g) { return ctx->gstart_host[g + 1] - ctx->gstart_host[g]; };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size_of(a) > size_of(b); });
+  std::vector<uint32_t> dropA(ng, 0), dropB(ng, 0);
+  uint64_t load[2] = {0, 0};
+  for (uint32_t g : order)
+  {
+    const int l = load[1] < load[0] ? 1 : 0;
+    load[l] += size_of(g);
+    (l ? dropA : dropB)[g] = 1;  // lane A drops what lane B owns and the other way round
+  }
+  if (!ctx->lane2)
+  {
+    ctx->lane2.reset(new bk_ctx::Lane());
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->lane2->st, hipStreamNonBlocking));
+  }
+  bk_ctx::Lane &B = *ctx->lane2;
+  uint32_t *da = ctx->d_dropA.as<uint32_t>((uint64_t) ng + 1), *db = B.d_drop.as<uint32_t>((uint64_t) ng + 1);
+  HIP_CHECK(hipMemcpyAsync(da, dropA.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
+  HIP_CHECK(hipMemcpyAsync(db, dropB.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
+  HIP_CHECK(hipStreamSynchronize(ctx->st));  // the pair table and the masks are ready for both lanes
+  std::string errA, errB;
+  int codeA = BK_OK, codeB = BK_OK;
+  std::thread tb([&] {
+    try
+    {
+      HIP_CHECK(hipSetDevice(ctx->device));
+      run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, db, B.list, B.iso, B.d_cluster, B.cb, ctx->ab, B.st);
+      HIP_CHECK(hipStreamSynchronize(B.st));
+    }
+    catch (const bk_error &e)
+    {
+      codeB = e.code;
+      errB = e.msg;
+    }
+  });
+  try
+  {
+    run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, da, ctx->listA, ctx->isoA, ctx->d_clusterA, ctx->cb, ctx->ab, ctx->st);
+  }
+  catch (const bk_error &e)
+  {
+    codeA = e.code;
+    errA = e.msg;
+  }
+  tb.join();
+  if (codeA != BK_OK) throw bk_error(codeA, errA);
+  if (codeB != BK_OK) throw bk_error(codeB, errB);
+  // one list in group order again (lane B has finished: its stream was synchronised by its thread)
+  PairList iso_m;
+  merge_lists(ctx->isoA, nullptr, B.iso, nullptr, iso_m, nullptr, ctx->st);
+  ctx->iso_n = iso_m.n;
+  merge_lists(ctx->listA, ctx->d_clusterA.get<uint32_t>(), B.list, B.d_cluster.get<uint32_t>(), ctx->list, &ctx->d_cluster, ctx->st);
+  HIP_CHECK(hipStreamSynchronize(ctx->st));
+  std::swap(ctx->iso_idx, iso_m.idx);
+  std::swap(ctx->iso_goff, iso_m.goff);
+}
+
 int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
 {
   return guarded(ctx, [&] {
+    if (lanes_apply(ctx, fast))
+    {
+      {
+        Scope s(ctx, "mask_and_cluster_2lanes");
+        two_lanes(ctx, w, fast);
+      }
+      ctx->clustered = true;
+      if (n_clustered) *n_clustered = ctx->list.n;
+      return;
+    }
     {
       Scope s(ctx, "remove_isolated");
       const uint32_t *drop = nullptr;

@@ -29,5 +29,8 @@ void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint6
 void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st);
 // find_cluster_pairs_enspan_fast for every group with >= 2 pairs; L becomes the clustered list, cluster_out[p] its cluster number
 void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluster_out, ClusterBufs &b, hipStream_t st);
+// two lists over disjoint sets of groups (both with offsets for all ng groups) -> one list in group order; cl_* = the cluster
+// numbers that travel with the elements (may be null)
+void merge_lists(const PairList &A, const uint32_t *clA, const PairList &B, const uint32_t *clB, PairList &out, DevBuf *cl_out, hipStream_t st);
 // test hook: mask_pairs_chr_pos on the list in its current order
 void debug_mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs &b, hipStream_t st);

@@ -433,3 +433,38 @@ void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &clust
 
 // test hook: mask_pairs_chr_pos (BreakID.cc:1813-1877) on the list in its current order
 void debug_mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs &b, hipStream_t st) { mask_list(pairs, L, dist, b, st); }
+
+// ---- two lanes of chromosome-pair groups (api.hip: bk_mask_and_cluster) -> one list in group order --------------------
+namespace
+{
+__global__ __launch_bounds__(256) void k_merge_goff(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, uint32_t ng, uint64_t *__restrict__ out)
+{
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= ng) out[g] = a[g] + b[g];  // the lanes own disjoint groups: the offsets add
+}
+__global__ __launch_bounds__(256) void k_merge_copy(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ gof, const uint32_t *__restrict__ cl, const uint64_t *__restrict__ goff,
+                                                    uint64_t n, const uint64_t *__restrict__ mgoff, uint32_t *__restrict__ oidx, uint32_t *__restrict__ ogof, uint32_t *__restrict__ ocl)
+{
+  uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t g = gof[p];
+  // a group belongs to one lane, so inside the merged list it starts where the merged offsets say and keeps its order
+  const uint64_t d = mgoff[g] + (p - goff[g]);
+  oidx[d] = idx[p];
+  ogof[d] = g;
+  if (cl) ocl[d] = cl[p];
+}
+}  // namespace
+
+void merge_lists(const PairList &A, const uint32_t *clA, const PairList &B, const uint32_t *clB, PairList &out, DevBuf *cl_out, hipStream_t st)
+{
+  const uint32_t ng = A.ng;
+  out.ng = ng;
+  out.n = A.n + B.n;
+  uint32_t *oidx = out.idx.as<uint32_t>(out.n + 1), *ogof = out.gof.as<uint32_t>(out.n + 1);
+  uint64_t *ogoff = out.goff.as<uint64_t>((uint64_t) ng + 1);
+  uint32_t *ocl = cl_out ? cl_out->as<uint32_t>(out.n + 1) : nullptr;
+  hipLaunchKernelGGL(k_merge_goff, dim3(cdiv(ng + 1, 256)), dim3(256), 0, st, A.goff.get<uint64_t>(), B.goff.get<uint64_t>(), ng, ogoff);
+  if (A.n) hipLaunchKernelGGL(k_merge_copy, dim3(nb(A.n)), dim3(256), 0, st, A.idx.get<uint32_t>(), A.gof.get<uint32_t>(), clA, A.goff.get<uint64_t>(), A.n, ogoff, oidx, ogof, ocl);
+  if (B.n) hipLaunchKernelGGL(k_merge_copy, dim3(nb(B.n)), dim3(256), 0, st, B.idx.get<uint32_t>(), B.gof.get<uint32_t>(), clB, B.goff.get<uint64_t>(), B.n, ogoff, oidx, ogof, ocl);
+}

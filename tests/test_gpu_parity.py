@@ -10,6 +10,7 @@ from oracle import pyoracle
 from tests import refdump
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 DATASETS = ["g1", "g2", "small", "ties", "edge"]
 
@@ -332,3 +333,38 @@ def test_other_mapq_thresholds(golden_dir, qual):
     _compare_stages(ctx, o)
     ctx.close()
     o.close()
+
+
+def test_two_lanes_of_groups_match_the_single_pass_and_the_oracle():
+    """BREAKID_GROUP_LANES=2 (what bench.py and the command line run with): the chromosome-pair groups are masked and clustered
+    in two disjoint sets on two streams / host threads and merged back into group order - every stage array must be the same
+    as the oracle's.  Own process: the runtime reads GPU_MAX_HW_QUEUES when it starts."""
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from breakid_amd import abi, capi, synth_gpu
+from oracle import pyoracle
+dev = torch.device("cuda", 0)
+contigs, cols = synth_gpu.make_wgs(6_000_000, 4711, dev, disc_frac=0.3)
+ctx = capi.Context(contigs)
+ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+ctx.timing_enable(True)
+w, nv = ctx.run(qual=20, fast=True)
+names = [t[0] for t in ctx.timing()]
+assert "mask_and_cluster_2lanes" in names, names
+o = pyoracle.Oracle(contigs, synth_gpu.to_numpy_cols(cols))
+ow, rc = o.run(20, fast=True)
+assert rc == 0 and w == ow
+for st in (abi.STAGE_GROUP_KEYS, abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_SPLITS, abi.STAGE_CLUSTERS):
+    a, ao = ctx.fetch(st)
+    b, bo = o.fetch(st)
+    assert np.array_equal(a, b), st
+    if ao is not None: assert np.array_equal(ao, bo), st
+print("LANES_OK", nv)
+""" % ROOT_DIR
+    env = dict(os.environ, BREAKID_GROUP_LANES="2", GPU_MAX_HW_QUEUES="16", BREAKID_LANES_MIN_PAIRS="1000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LANES_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

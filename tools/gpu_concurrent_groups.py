@@ -22,7 +22,8 @@ def prep():
     return ctx, w
 
 
-for K in (1, 2, 4):
+KS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4)
+for K in KS:
     ctxs = [prep() for _ in range(K)]
     L = ctxs[0][0].L
     starts, ng = C.POINTER(C.c_uint64)(), C.c_uint32()
