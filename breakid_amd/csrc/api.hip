@@ -635,11 +635,14 @@ static void two_lanes(bk_ctx *ctx, double w, int fast)
   auto size_of = [&](uint32_t g) { return ctx->gstart_host[g + 1] - ctx->gstart_host[g]; };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size_of(a) > size_of(b); });
   std::vector<uint32_t> dropA(ng, 0), dropB(ng, 0);
-  uint64_t load[2] = {0, 0};
+  // a lane's time is its partition levels plus, per sort, its LONGEST heapsort segment, and those grow faster than the group:
+  // the weight of a group is size^e, e > 1, so that the biggest same-chromosome groups do not share a lane
+  static const double wexp = getenv("BREAKID_LANE_WEIGHT_EXP") ? atof(getenv("BREAKID_LANE_WEIGHT_EXP")) : 2.0;
+  double load[2] = {0, 0};
   for (uint32_t g : order)
   {
     const int l = load[1] < load[0] ? 1 : 0;
-    load[l] += size_of(g);
+    load[l] += std::pow((double) size_of(g), wexp);
     (l ? dropA : dropB)[g] = 1;  // lane A drops what lane B owns and the other way round
   }
   if (!ctx->lane2)
