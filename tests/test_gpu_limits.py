@@ -113,3 +113,42 @@ def test_read_name_run_of_4096_candidates_matches_the_oracle():
     assert len(ctx.fetch(abi.STAGE_SCAN)[0]) == 2048  # arrival order pairs neighbours on one chromosome, 5 kb apart
     ctx.close()
     o.close()
+
+
+def test_ahc_component_beyond_the_pool_budget_is_refused():
+    """the reference needs an N x N matrix of doubles for such a group (80 GB at 100 000 points) and hours of insert_sorted;
+    the exact replay refuses it instead of running on"""
+    n = 100_000
+    x = np.full(n, 5000, np.uint32)
+    y = np.full(n, 7000, np.uint32)
+    ctx = capi.Context([("chr1", 1_000_000)])
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.debug_ahc(x, y, 10.5)
+    assert e.value.code == abi.BK_ERR_LIMIT and "component" in str(e.value)
+    ctx.close()
+
+
+def test_record_longer_than_8_MiB_across_a_feed_chunk_takes_the_host_decoder(monkeypatch):
+    """GPU feed: a BAM record longer than 8 MiB that crosses a feed chunk is refused (BK_ERR_LIMIT, records across BGZF blocks in
+    chunks); the host decoder reads the same file, which is what the command line falls back to"""
+    import tempfile
+    from breakid_amd import bamio
+    contigs = [("chr1", 50_000_000)]
+    recs = []
+    for i in range(200):
+        recs.append(bamio.encode_record("r%d" % i, 0x63, 0, 1000 + 10 * i, 60, [100 << 4], 0, 1300 + 10 * i, 400, seq_len=100))
+    huge = bytearray(bamio.encode_record("huge", 0x63, 0, 5000, 60, [100 << 4], 0, 5300, 400, seq_len=9_000_000))   # 13.5 MB record
+    huge[-9_000_000:] = np.random.default_rng(1).integers(0, 64, 9_000_000, dtype=np.uint8).tobytes()  # qualities that do not compress away
+    recs.append(bytes(huge))
+    for i in range(200):
+        recs.append(bamio.encode_record("s%d" % i, 0x63, 0, 6000 + 10 * i, 60, [100 << 4], 0, 6300 + 10 * i, 400, seq_len=100))
+    with tempfile.TemporaryDirectory() as t:
+        p = t + "/huge.bam"
+        bamio.write_bam(p, contigs, recs, aligned=False)   # fixed-size blocks: the records run across BGZF blocks
+        monkeypatch.setenv("BREAKID_FEED_PACKED_CHUNKS", "1")
+        monkeypatch.setenv("BREAKID_FEED_CHUNK_MB", "1")
+        with pytest.raises(capi.BreakIDError) as e:
+            capi.decode_bam_device(p)
+        assert e.value.code == abi.BK_ERR_LIMIT and "8 MiB" in str(e.value)
+        contigs2, cols = capi.decode_bam(p)
+    assert contigs2 == contigs and len(cols["tid"]) == 401 and int(cols["pos"][200]) == 5000
