@@ -111,7 +111,7 @@ struct bk_ctx
       if (st) (void) hipStreamDestroy(st);
     }
   };
-  std::unique_ptr<Lane> lane2;
+  std::vector<std::unique_ptr<Lane>> lanes;  // lanes 1 .. K-1 (lane 0 uses the context's own stream and buffers)
   PairList listA, isoA;  // first lane's lists before the merge
   DevBuf d_clusterA, d_dropA;
   uint64_t iso_n = 0;
@@ -619,75 +619,116 @@ static void run_lane(const bk_pair *pairs, const uint32_t *gof, const uint64_t *
     ahc_cluster_all(pairs, L, w, d_cluster, ab, cb, st);
 }
 
-static bool lanes_apply(const bk_ctx *ctx, int fast)
+static int lanes_wanted()
 {
   static const int want = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 1;
+  return want < 1 ? 1 : (want > 8 ? 8 : want);
+}
+static bool lanes_apply(const bk_ctx *ctx, int fast)
+{
   static const uint64_t min_pairs = getenv("BREAKID_LANES_MIN_PAIRS") ? strtoull(getenv("BREAKID_LANES_MIN_PAIRS"), nullptr, 10) : (1ull << 20);  // below: launch-bound anyway
-  return want >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->own_groups.empty() && ctx->jr.n_pairs >= min_pairs;
+  return lanes_wanted() >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->own_groups.empty() && ctx->jr.n_pairs >= min_pairs;
 }
 
-static void two_lanes(bk_ctx *ctx, double w, int fast)
+// K lanes of groups.  A lane's time is (a) per sort the LONGEST heapsort segment of any of its groups - a serial chain of one wave
+// that belongs, in practice, to its largest same-chromosome group - plus (b) partition levels and masks in proportion to its
+// pairs plus (c) a fixed number of launch-bound late levels.  The largest group's chain is the critical path of the whole
+// stage, so BREAKID_LANE_SOLO (default 1) of the largest groups get a lane of their own - nothing else waits in front of
+// their sorts - and the remaining groups are spread over the remaining lanes by longest-processing-time on size^e.
+static void group_lanes(bk_ctx *ctx, double w, int fast)
 {
   const uint32_t ng = ctx->jr.n_groups;
-  // lanes by longest-processing-time on the pair counts (the heavy same-chromosome groups alternate between the lanes)
+  const int K = lanes_wanted();
   std::vector<uint32_t> order(ng);
   std::iota(order.begin(), order.end(), 0u);
   auto size_of = [&](uint32_t g) { return ctx->gstart_host[g + 1] - ctx->gstart_host[g]; };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size_of(a) > size_of(b); });
-  std::vector<uint32_t> dropA(ng, 0), dropB(ng, 0);
-  // a lane's time is its partition levels plus, per sort, its LONGEST heapsort segment, and those grow faster than the group:
-  // the weight of a group is size^e, e > 1, so that the biggest same-chromosome groups do not share a lane
   static const double wexp = getenv("BREAKID_LANE_WEIGHT_EXP") ? atof(getenv("BREAKID_LANE_WEIGHT_EXP")) : 2.0;
-  double load[2] = {0, 0};
-  for (uint32_t g : order)
+  static const int solo_env = getenv("BREAKID_LANE_SOLO") ? atoi(getenv("BREAKID_LANE_SOLO")) : 1;
+  const int solo = std::max(0, std::min(solo_env, K - 1));
+  std::vector<int> lane_of(ng, 0);
+  std::vector<double> load(K, 0.0);
+  for (uint32_t i = 0; i < ng; ++i)
   {
-    const int l = load[1] < load[0] ? 1 : 0;
-    load[l] += std::pow((double) size_of(g), wexp);
-    (l ? dropA : dropB)[g] = 1;  // lane A drops what lane B owns and the other way round
+    const uint32_t g = order[i];
+    int l;
+    if ((int) i < solo)
+      l = (int) i;
+    else
+    {
+      l = solo;
+      for (int k = solo + 1; k < K; ++k)
+        if (load[k] < load[l]) l = k;
+      load[l] += std::pow((double) size_of(g), wexp);
+    }
+    lane_of[g] = l;
   }
-  if (!ctx->lane2)
+  while ((int) ctx->lanes.size() < K - 1)
   {
-    ctx->lane2.reset(new bk_ctx::Lane());
-    HIP_CHECK(hipStreamCreateWithFlags(&ctx->lane2->st, hipStreamNonBlocking));
+    ctx->lanes.emplace_back(new bk_ctx::Lane());
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes.back()->st, hipStreamNonBlocking));
   }
-  bk_ctx::Lane &B = *ctx->lane2;
-  uint32_t *da = ctx->d_dropA.as<uint32_t>((uint64_t) ng + 1), *db = B.d_drop.as<uint32_t>((uint64_t) ng + 1);
-  HIP_CHECK(hipMemcpyAsync(da, dropA.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
-  HIP_CHECK(hipMemcpyAsync(db, dropB.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
-  HIP_CHECK(hipStreamSynchronize(ctx->st));  // the pair table and the masks are ready for both lanes
-  std::string errA, errB;
-  int codeA = BK_OK, codeB = BK_OK;
-  std::thread tb([&] {
-    try
-    {
-      HIP_CHECK(hipSetDevice(ctx->device));
-      run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, db, B.list, B.iso, B.d_cluster, B.cb, ctx->ab, B.st);
-      HIP_CHECK(hipStreamSynchronize(B.st));
-    }
-    catch (const bk_error &e)
-    {
-      codeB = e.code;
-      errB = e.msg;
-    }
-  });
+  std::vector<uint32_t> drop(ng);
+  for (int l = 0; l < K; ++l)
+  {
+    for (uint32_t g = 0; g < ng; ++g) drop[g] = lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
+    uint32_t *d = (l == 0 ? ctx->d_dropA : ctx->lanes[l - 1]->d_drop).as<uint32_t>((uint64_t) ng + 1);
+    HIP_CHECK(hipMemcpyAsync(d, drop.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));  // (drop is reused)
+  }
+  // the pair table and the masks are ready for all lanes
+  std::vector<std::string> err(K);
+  std::vector<int> code(K, BK_OK);
+  std::vector<std::thread> th;
+  for (int l = 1; l < K; ++l)
+    th.emplace_back([&, l] {
+      bk_ctx::Lane &B = *ctx->lanes[l - 1];
+      try
+      {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, B.d_drop.get<uint32_t>(), B.list, B.iso, B.d_cluster, B.cb, ctx->ab, B.st);
+        HIP_CHECK(hipStreamSynchronize(B.st));
+      }
+      catch (const bk_error &e)
+      {
+        code[l] = e.code;
+        err[l] = e.msg;
+      }
+    });
   try
   {
-    run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, da, ctx->listA, ctx->isoA, ctx->d_clusterA, ctx->cb, ctx->ab, ctx->st);
+    run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, ctx->d_dropA.get<uint32_t>(), ctx->listA, ctx->isoA, ctx->d_clusterA, ctx->cb, ctx->ab, ctx->st);
   }
   catch (const bk_error &e)
   {
-    codeA = e.code;
-    errA = e.msg;
+    code[0] = e.code;
+    err[0] = e.msg;
   }
-  tb.join();
-  if (codeA != BK_OK) throw bk_error(codeA, errA);
-  if (codeB != BK_OK) throw bk_error(codeB, errB);
-  // one list in group order again (lane B has finished: its stream was synchronised by its thread)
-  PairList iso_m;
-  merge_lists(ctx->isoA, nullptr, B.iso, nullptr, iso_m, nullptr, ctx->st);
-  ctx->iso_n = iso_m.n;
-  merge_lists(ctx->listA, ctx->d_clusterA.get<uint32_t>(), B.list, B.d_cluster.get<uint32_t>(), ctx->list, &ctx->d_cluster, ctx->st);
+  for (std::thread &t : th) t.join();
+  for (int l = 0; l < K; ++l)
+    if (code[l] != BK_OK) throw bk_error(code[l], err[l]);
+  // one list in group order again (the other lanes have finished: their streams were synchronised by their threads); the lanes
+  // own disjoint groups, so they fold into the result one after the other
+  PairList iso_acc[2], list_acc[2];
+  DevBuf cl_acc[2];
+  const PairList *iso_cur = &ctx->isoA, *list_cur = &ctx->listA;
+  const uint32_t *cl_cur = ctx->d_clusterA.get<uint32_t>();
+  for (int l = 1; l < K; ++l)
+  {
+    bk_ctx::Lane &B = *ctx->lanes[l - 1];
+    const bool last = l == K - 1;
+    PairList &io = iso_acc[l & 1];
+    merge_lists(*iso_cur, nullptr, B.iso, nullptr, io, nullptr, ctx->st);
+    iso_cur = &io;
+    PairList &lo = last ? ctx->list : list_acc[l & 1];
+    DevBuf &co = last ? ctx->d_cluster : cl_acc[l & 1];
+    merge_lists(*list_cur, cl_cur, B.list, B.d_cluster.get<uint32_t>(), lo, &co, ctx->st);
+    list_cur = &lo;
+    cl_cur = co.get<uint32_t>();
+  }
   HIP_CHECK(hipStreamSynchronize(ctx->st));
+  PairList &iso_m = iso_acc[(K - 1) & 1];
+  ctx->iso_n = iso_m.n;
   std::swap(ctx->iso_idx, iso_m.idx);
   std::swap(ctx->iso_goff, iso_m.goff);
 }
@@ -698,8 +739,8 @@ int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
     if (lanes_apply(ctx, fast))
     {
       {
-        Scope s(ctx, "mask_and_cluster_2lanes");
-        two_lanes(ctx, w, fast);
+        Scope s(ctx, "mask_and_cluster_lanes");
+        group_lanes(ctx, w, fast);
       }
       ctx->clustered = true;
       if (n_clustered) *n_clustered = ctx->list.n;

@@ -818,11 +818,135 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
   }
 }
 
+// ---- fourth form: the zero-slot loop above, scheduled for a lone wave ------------------------------------------------------
+// A wave that is alone on its SIMD issues one instruction every 4 cycles whatever it is, so a pop costs its instruction
+// count plus whatever LDS latency is left exposed.  Same data layout, launch rule and ancestor stall as sort_heap_lds_zero:
+//   * rank compares on the high halves directly (SDWA WORD_1 selects) instead of `or 0xffff` + compare;
+//   * the children of the NEXT step's hole are requested as soon as this step's hole is known (behind this step's store in
+//     program order, so they see it); the launch decision, the launch and the bookkeeping of a launch (which moves into the
+//     following iteration) run while that read is in flight;
+//   * the ancestor test is prepared from the holes BEFORE the step while the children are still on their way: a lane that
+//     descends ends one level deeper, so the only ancestor of L it can reach is L >> (clz(hole) - 1 - clz(L)); after the
+//     step one compare against the new hole is left;
+//   * the launching lane is a rotating one-hot mask in SGPRs; launches are counted by L itself.
+// 20 instructions in the iteration after a launch, 36 in a launching one (was 21 and 42, with two exposed LDS round trips).
+// Per-lane: hole v40 (0 = idle), value v42 (-1 = idle).  Uniform: L s43, clz(L) + 1 s47, budget s45, clamp address s42,
+// launch mask s[58:59].
+#define BK_HEAP32Q_STEP                                                                                                   \
+  "v_cmp_ge_u32_sdwa vcc, v47, v46 src0_sel:WORD_1 src1_sel:WORD_1\n"                                                      \
+  "v_cndmask_b32 v50, v46, v47, vcc\n"                                                                                     \
+  "v_addc_co_u32_e32 v53, vcc, v40, v40, vcc\n"                                                                            \
+  "v_cmp_ge_u32_sdwa vcc, v50, v42 src0_sel:WORD_1 src1_sel:WORD_1\n"                                                      \
+  "v_cndmask_b32 v51, v42, v50, vcc\n"                                                                                     \
+  "ds_write_b32 v52, v51\n"                                                                                                \
+  "v_cndmask_b32 v40, v55, v53, vcc\n"                                                                                     \
+  "v_cndmask_b32 v42, v59, v42, vcc\n"                                                                                     \
+  "v_lshl_add_u32 v45, v40, 3, s40\n"                                                                                      \
+  "v_min_u32 v45, s42, v45\n"                                                                                              \
+  "ds_read2_b32 v[46:47], v45 offset1:1\n"
+#define BK_HEAP32Q_ASM                                                                                                    \
+  "s_setprio 3\n"                                                                                                          \
+  "s_mov_b64 s[56:57], exec\n"                                                                                             \
+  "s_mov_b32 s62, %[olo]\n s_mov_b32 s63, %[ohi]\n"                                                                        \
+  "s_sub_u32 s40, %[base], 4\n"                                                                                            \
+  "v_mov_b32 v60, %[base]\n"                                                                                               \
+  "s_mov_b32 s43, %[m]\n"                                                                                                  \
+  "s_flbit_i32_b32 s47, s43\n s_add_u32 s47, s47, 1\n"                                                                     \
+  "s_lshl_b32 s48, s43, 2\n s_add_u32 s42, s48, %[base]\n"                                                                 \
+  "s_add_u32 s48, s48, s40\n v_mov_b32 v61, s48\n"                                                                         \
+  "s_lshl_b32 s48, s43, 2\n s_sub_u32 s48, s48, 4\n v_mov_b32 v57, s48\n"                                                  \
+  "s_mov_b32 s45, %[budget]\n"                                                                                             \
+  "v_mov_b32 v55, 0\n v_mov_b32 v59, -1\n v_mov_b32 v40, 0\n v_mov_b32 v42, -1\n"                                          \
+  "s_mov_b64 s[58:59], 1\n"                                                                                                \
+  "v_mov_b32 v45, s40\n"                                                                                                   \
+  "ds_read2_b32 v[46:47], v45 offset1:1\n"                                                                                 \
+  "s_branch BK_QB_%=\n"                                                                                                    \
+  "BK_QA_%=:\n"                                                                                                           \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "s_sub_u32 s43, s43, 1\n"                                                                                                \
+  "s_flbit_i32_b32 s47, s43\n"                                                                                             \
+  "s_add_u32 s47, s47, 1\n"                                                                                                \
+  "v_add_u32 v61, -4, v61\n"                                                                                               \
+  "v_add_u32 v57, -4, v57\n"                                                                                               \
+  "s_lshl_b64 s[58:59], s[58:59], 1\n"                                                                                     \
+  "s_cselect_b64 s[58:59], s[58:59], 1\n"                                                                                  \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+  BK_HEAP32Q_STEP                                                                                                         \
+  "BK_QB_%=:\n"                                                                                                           \
+  "ds_read_b32 v56, v60\n"                                                                                                 \
+  "ds_read_b32 v58, v61\n"                                                                                                 \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "v_ffbh_u32 v63, v40\n"                                                                                                  \
+  "v_subrev_u32 v63, s47, v63\n"                                                                                           \
+  "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
+  "v_cmp_le_i32_e64 s[52:53], 0, v63\n"                                                                                    \
+  "v_cmp_eq_u32_e64 s[60:61], s43, v40\n"                                                                                  \
+  "s_waitcnt lgkmcnt(2)\n"                                                                                                 \
+  BK_HEAP32Q_STEP                                                                                                         \
+  "s_cmp_lt_u32 s43, 2\n"                                                                                                  \
+  "s_cbranch_scc1 BK_QNOMORE_%=\n"                                                                                         \
+  "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
+  "s_and_b64 vcc, vcc, s[52:53]\n"                                                                                         \
+  "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
+  "s_cbranch_vccnz BK_QBNEXT_%=\n"                                                                                         \
+  "s_waitcnt lgkmcnt(2)\n"                                                                                                 \
+  "s_mov_b64 exec, s[58:59]\n"                                                                                             \
+  "ds_write_b32 v61, v55\n"                                                                                                \
+  "global_store_dword v57, v56, s[62:63]\n"                                                                                \
+  "v_mov_b32 v42, v58\n"                                                                                                   \
+  "v_mov_b32 v40, 1\n"                                                                                                     \
+  "ds_read2_b32 v[46:47], v60 offset0:1 offset1:2\n"                                                                       \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                                   \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_QA_%=\n"                                                                                              \
+  "s_branch BK_QDONE_%=\n"                                                                                                 \
+  "BK_QNOMORE_%=:\n"                                                                                                      \
+  "v_cmp_ne_u32 vcc, 0, v40\n"                                                                                             \
+  "s_cbranch_vccz BK_QDONE_%=\n"                                                                                           \
+  "BK_QBNEXT_%=:\n"                                                                                                       \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_QB_%=\n"                                                                                              \
+  "BK_QDONE_%=:\n"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+  "s_setprio 0\n"                                                                                                          \
+  "s_mov_b32 %[left], s45\n"
+
+__device__ int g_heap_no_q = 0;  // BK_HEAP_NO_Q=1: sort_heap_lds_zero instead of sort_heap_lds_q (debugging / comparison)
+
+// same contract as sort_heap_lds_zero
+__device__ __forceinline__ void sort_heap_lds_q(uint32_t *slot1, const uint32_t m, uint32_t *out)
+{
+  if (m < 2) return;
+  if (g_heap_no_q)
+  {
+    sort_heap_lds_zero(slot1, m, out);
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t budget = __builtin_amdgcn_readfirstlane(64u * m + 4096u);
+  const uint32_t mm = __builtin_amdgcn_readfirstlane(m);
+  const unsigned long long o = (unsigned long long) out;
+  const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t) o), ohi = __builtin_amdgcn_readfirstlane((uint32_t) (o >> 32));
+  const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t) (unsigned long long) slot1);
+  uint32_t left;
+  asm volatile(BK_HEAP32Q_ASM
+               : [left] "=s"(left)
+               : [olo] "s"(olo), [ohi] "s"(ohi), [base] "s"(base), [m] "s"(mm), [budget] "s"(budget)
+               : BK_HEAP_CLOBBERS);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0)
+  {
+    // the budget counts the iterations that may launch; every pop adds one iteration that may not
+    atomicAdd(&g_heap_iters[0], (unsigned long long) (budget - left) + (m - 1));
+    atomicAdd(&g_heap_iters[1], (unsigned long long) (m - 1));
+  }
+}
+
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
 constexpr uint32_t HEAP_LARGE32 = 40000; // the same LDS in 4-byte ranked entries (+ slot 0 and two zero slots)
 constexpr uint32_t HEAP_RANKED_MIN = 4096;   // level-loop heaps above this size run on ranked entries (sort_heap_lds_zero)
-constexpr uint32_t HEAP_RANKED_MAX = 65535;  // rank + 1 must fit 16 bits
+constexpr uint32_t HEAP_RANKED_MAX = 65534;  // rank + 1 must fit 16 bits and stay below the idle marker's 0xffff
 
 // cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_LARGE (dynamic LDS), 2: larger (global scratch of packed entries)
 // (lo, hi]: the sizes this launch takes (CLS 1 is launched once per LDS footprint so that small heaps share a CU)
@@ -868,7 +992,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
         make_heap_wave(mem, m);
       }
       tp2 = tp3 = wall_clock64();
-      if (w0) sort_heap_lds_zero(l32 + 1, m, g32);
+      if (w0) sort_heap_lds_q(l32 + 1, m, g32);
     }
     else
     {
@@ -892,7 +1016,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
       for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += NT) l32[1 + i] = g32[i];
       if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
       __syncthreads();
-      if (w0) sort_heap_lds_zero(l32 + 1, HEAP_LARGE32, g32);
+      if (w0) sort_heap_lds_q(l32 + 1, HEAP_LARGE32, g32);
     }
     __syncthreads();
     if (threadIdx.x == 0) g32[0] = l32[1];  // the last element never leaves the root
@@ -1165,11 +1289,14 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
                                                                      uint2 *__restrict__ heap_list)
 {
   __shared__ unsigned long long wsum[CHILD_THREADS / 64];
+  __shared__ uint32_t s_max;
+  if (threadIdx.x == 0) s_max = 0;
   const uint32_t ns = lvl[0];
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
   // thread t takes segments [t * per, (t + 1) * per): one each while they are few
   const uint32_t per = (ns + CHILD_THREADS - 1) / CHILD_THREADS;
   unsigned long long v = 0;
+  uint32_t lmax = 0;  // largest live child (lvl[2]: the host hands the tail of the loop to k_se_tail once it is small)
   for (uint32_t k = 0; k < per; ++k)
   {
     const uint32_t s = t * per + k;
@@ -1179,6 +1306,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
     const uint32_t a = sg.cut - sg.first, b = sg.last - sg.cut;
     if (a > FIN_MAX) v += 1ull | ((unsigned long long) a << 32);
     if (b > FIN_MAX) v += 1ull | ((unsigned long long) b << 32);
+    lmax = max(lmax, max(a > FIN_MAX ? a : 0u, b > FIN_MAX ? b : 0u));
   }
   // exclusive scan of (count | elements << 32) over the workgroup
   unsigned long long inc = v;
@@ -1188,6 +1316,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
     if ((int) lane >= d) inc += o;
   }
   if (lane == 63) wsum[w] = inc;
+  if (lmax) atomicMax(&s_max, lmax);
   __syncthreads();  // (every thread has read lvl[0] by now)
   unsigned long long base = 0, tot = 0;
   for (uint32_t i = 0; i < CHILD_THREADS / 64; ++i)
@@ -1200,6 +1329,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
   {
     lvl[0] = (uint32_t) tot;
     lvl[1] = (uint32_t) (tot >> 32);
+    lvl[2] = s_max;
   }
   const unsigned long long off = base + inc - v;
   uint32_t o = (uint32_t) off, cb = (uint32_t) (off >> 32);
@@ -1583,6 +1713,8 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   {
     const int v = getenv("BK_HEAP_NO_PIPE") != nullptr;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_pipe), &v, sizeof v));
+    const int nq = getenv("BK_HEAP_NO_Q") != nullptr;
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_q), &nq, sizeof nq));
     pipe_flag_set = true;
   }
   const uint32_t n = (uint32_t) n64;
@@ -1646,6 +1778,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       t_loop0 = now_ms();
     }
     uint32_t *lvl = b.lvl.as<uint32_t>(4);
+    uint32_t max_live = 0xFFFFFFFFu;  // largest live segment (known after a batch of levels)
     bool pivoted = false;  // the live segments already carry their pivots (the fused child kernel picked them)
     while (ns)
     {
@@ -1704,16 +1837,17 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
           ++level;
         }
         pivoted = true;
-        uint32_t now[2] = {0, 0};
-        HIP_CHECK(hipMemcpyAsync(now, lvl, 8, hipMemcpyDeviceToHost, st));
+        uint32_t now[3] = {0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(now, lvl, 12, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         tot = (unsigned long long) now[0] | ((unsigned long long) now[1] << 32);
+        max_live = now[2];
       }
       const uint32_t ns2 = (uint32_t) tot;
       if (dbg_levels && (level % 4 == 0 || ns2 == 0))
       {
         HIP_CHECK(hipStreamSynchronize(st));
-        fprintf(stderr, "[sortemu]   level %d: %u segments -> %u (%u live elements), %.3f ms so far\n", level, ns, ns2, (uint32_t) (tot >> 32), now_ms() - t_loop0);
+        fprintf(stderr, "[sortemu]   level %d: %u segments -> %u (%u live elements, largest %u), %.3f ms so far\n", level, ns, ns2, (uint32_t) (tot >> 32), max_live, now_ms() - t_loop0);
       }
       ns = ns2;
       na = (uint32_t) (tot >> 32);
