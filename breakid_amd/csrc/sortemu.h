@@ -5,7 +5,7 @@
 
 struct SortEmuBufs
 {
-  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, fin_list, fin_cnt, lvl;
+  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, fin_list, fin_cnt, lvl, lv_tile, lv_segbase;
   prims::RadixBufs radix;
   // the three size classes of the heapsort branch run side by side (fork/join around the caller's stream)
   static constexpr int N_AUX = 5;

@@ -1234,6 +1234,227 @@ __global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const u
   }
 }
 
+// ---- the same partition level in three passes over the keys instead of seven launches over five arrays ----------------
+// k_se_flags / scan / k_se_lists / k_se_swap materialise the stopper flags (8 B), their prefix sums (8 B read + 8 B written
+// twice), the owner of every compact index (4 B) and two position lists indexed per segment: ~96 B per live element and level.
+// Here a tile of LV_TILE compact indices recomputes its flags from the keys wherever it needs them:
+//   k_lv_count   tile totals (#L-stoppers | #R-stoppers << 32)
+//   k_lv_sums    one workgroup: exclusive scan of the tile totals, grand total -> segbase[ns]
+//   k_lv_lists   running counts inside the tile -> the j-th L-stopper of the whole level goes to posL[j], the j-th R-stopper
+//                (in forward order) to posR[j]; the thread that owns a segment's first index leaves the running counts
+//                there in segbase[s], so a segment's stoppers are posL[segbase[s] ..), posR[segbase[s] >> 32 ..)
+//   k_lv_swap    pair j of segment s = (posL[bL + j], posR[bR + nR - 1 - j]): swap while l_j < r_j, then the cut
+// ~27 B per element and level, five launches with the children kernel.  A live segment holds more than FIN_MAX = LV_TILE
+// elements, so a tile touches at most two segments: one binary search per tile, no owner array.
+constexpr uint32_t LV_TILE = 2048, LV_EPT = LV_TILE / 256;
+static_assert(LV_TILE <= FIN_MAX, "a tile must not span more than one segment boundary");
+struct LvTile
+{
+  uint32_t s0;
+  Seg a, b;
+};
+// executed by every thread of the block after a barrier; c0 = first compact index of the tile
+__device__ __forceinline__ void lv_tile_setup(const Seg *__restrict__ segs, uint32_t ns, uint32_t c0, LvTile *sh)
+{
+  if (threadIdx.x == 0)
+  {
+    const uint32_t s = find_seg(segs, ns, c0);
+    sh->s0 = s;
+    sh->a = segs[s];
+    Seg z = {};
+    z.cbase = 0xFFFFFFFFu;
+    z.depth = -1;
+    sh->b = s + 1 < ns ? segs[s + 1] : z;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t lv_flags(const Seg &sg, uint32_t c, uint32_t k)
+{
+  uint32_t v = 0;
+  if (sg.depth >= 0 && c > sg.cbase)
+  {
+    if (k >= sg.pivot) v |= 1u;         // !(key < pivot): the left scan stops here
+    if (k <= sg.pivot) v |= 1u << 16;   // !(pivot < key): the right scan stops here
+  }
+  return v;
+}
+__global__ __launch_bounds__(256) void k_lv_count(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na, unsigned long long *__restrict__ tile_cnt,
+                                                  const uint32_t *__restrict__ lvl)
+{
+  __shared__ LvTile sh;
+  __shared__ uint32_t s_scan[prims::WAVES];
+  if (lvl)
+  {
+    ns = lvl[0];
+    na = lvl[1];
+  }
+  const uint32_t c0 = blockIdx.x * LV_TILE;
+  if (c0 >= na) return;
+  lv_tile_setup(segs, ns, c0, &sh);
+  const Seg A = sh.a, B = sh.b;
+  uint32_t acc = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < LV_EPT; ++k)
+  {
+    const uint32_t c = c0 + k * 256 + threadIdx.x;
+    if (c < na)
+    {
+      const Seg &sg = c >= B.cbase ? B : A;
+      acc += lv_flags(sg, c, key[sg.first + (c - sg.cbase)]);
+    }
+  }
+  uint32_t tot;
+  (void) prims::block_exclusive_scan(acc, s_scan, tot);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (unsigned long long) (tot & 0xFFFFu) | ((unsigned long long) (tot >> 16) << 32);
+}
+constexpr uint32_t LV_SUM_THREADS = 1024;
+__global__ __launch_bounds__(LV_SUM_THREADS) void k_lv_sums(unsigned long long *__restrict__ tile_cnt, uint32_t ns, uint32_t na, unsigned long long *__restrict__ segbase,
+                                                            const uint32_t *__restrict__ lvl)
+{
+  __shared__ unsigned long long wsum[LV_SUM_THREADS / 64];
+  if (lvl)
+  {
+    ns = lvl[0];
+    na = lvl[1];
+  }
+  const uint32_t nt = (na + LV_TILE - 1) / LV_TILE, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  unsigned long long carry = 0;
+  for (uint32_t base = 0; base < nt; base += LV_SUM_THREADS)
+  {
+    const uint32_t i = base + t;
+    const unsigned long long v = i < nt ? tile_cnt[i] : 0ull;
+    const unsigned long long inc = prims::wave_inclusive_scan(v);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+    for (uint32_t j = 0; j < LV_SUM_THREADS / 64; ++j)
+    {
+      const unsigned long long x = wsum[j];
+      if (j < w) pre += x;
+      tot += x;
+    }
+    __syncthreads();
+    if (i < nt) tile_cnt[i] = carry + pre + inc - v;
+    carry += tot;
+  }
+  if (t == 0) segbase[ns] = carry;
+}
+__global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
+                                                  const unsigned long long *__restrict__ tile_base, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR,
+                                                  unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ lvl)
+{
+  __shared__ LvTile sh;
+  __shared__ uint32_t s_scan[prims::WAVES];
+  __shared__ uint32_t s_key[LV_TILE + LV_TILE / 32];  // one pad word per 32: a thread's LV_EPT consecutive keys spread over the banks
+  if (lvl)
+  {
+    ns = lvl[0];
+    na = lvl[1];
+  }
+  const uint32_t c0 = blockIdx.x * LV_TILE;
+  if (c0 >= na) return;
+  lv_tile_setup(segs, ns, c0, &sh);
+  const Seg A = sh.a, B = sh.b;
+  const uint32_t s0 = sh.s0;
+#pragma unroll
+  for (uint32_t k = 0; k < LV_EPT; ++k)
+  {
+    const uint32_t e = k * 256 + threadIdx.x, c = c0 + e;
+    if (c < na)
+    {
+      const Seg &sg = c >= B.cbase ? B : A;
+      s_key[e + (e >> 5)] = key[sg.first + (c - sg.cbase)];
+    }
+  }
+  __syncthreads();
+  uint32_t f[LV_EPT], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < LV_EPT; ++k)
+  {
+    const uint32_t e = threadIdx.x * LV_EPT + k, c = c0 + e;
+    uint32_t v = 0;
+    if (c < na) v = lv_flags(c >= B.cbase ? B : A, c, s_key[e + (e >> 5)]);
+    f[k] = v;
+    sum += v;
+  }
+  uint32_t tot;
+  const uint32_t ex = prims::block_exclusive_scan(sum, s_scan, tot);
+  const unsigned long long tb = tile_base[blockIdx.x];
+  uint32_t runL = (uint32_t) tb + (ex & 0xFFFFu), runR = (uint32_t) (tb >> 32) + (ex >> 16);
+#pragma unroll
+  for (uint32_t k = 0; k < LV_EPT; ++k)
+  {
+    const uint32_t e = threadIdx.x * LV_EPT + k, c = c0 + e;
+    if (c >= na) break;
+    const bool second = c >= B.cbase;
+    const Seg &sg = second ? B : A;
+    if (c == sg.cbase) segbase[s0 + (second ? 1u : 0u)] = (unsigned long long) runL | ((unsigned long long) runR << 32);
+    const uint32_t p = sg.first + (c - sg.cbase);
+    if (f[k] & 1u) posL[runL++] = p;
+    if (f[k] >> 16) posR[runR++] = p;
+  }
+}
+__global__ __launch_bounds__(256) void k_lv_swap(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
+                                                 const unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR,
+                                                 const uint32_t *__restrict__ lvl)
+{
+  __shared__ LvTile sh;
+  __shared__ unsigned long long s_base[3];
+  if (lvl)
+  {
+    ns = lvl[0];
+    na = lvl[1];
+  }
+  const uint32_t c0 = blockIdx.x * LV_TILE;
+  if (c0 >= na) return;
+  lv_tile_setup(segs, ns, c0, &sh);
+  const Seg A = sh.a, B = sh.b;
+  const uint32_t s0 = sh.s0;
+  if (threadIdx.x < 3) s_base[threadIdx.x] = s0 + threadIdx.x <= ns ? segbase[s0 + threadIdx.x] : 0ull;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < LV_EPT; ++k)
+  {
+    const uint32_t c = c0 + k * 256 + threadIdx.x;
+    if (c >= na) break;
+    const uint32_t second = c >= B.cbase ? 1u : 0u;
+    const Seg &sg = second ? B : A;
+    if (sg.depth < 0) continue;
+    const uint32_t first = sg.first, s = s0 + second;
+    const unsigned long long base = s_base[second], end = s_base[second + 1];
+    const uint32_t bL = (uint32_t) base, bR = (uint32_t) (base >> 32);
+    const uint32_t nL = (uint32_t) end - bL, nR = (uint32_t) (end >> 32) - bR;
+    const uint32_t m = nL < nR ? nL : nR, j = c - sg.cbase;
+    if (j > m) continue;
+    const uint32_t INF = 0xFFFFFFFFu;
+    const uint32_t lj = j < nL ? posL[bL + j] : INF;
+    const uint32_t rj = j < nR ? posR[bR + (nR - 1 - j)] : first;
+    if ((j < nL) && (j < nR) && (lj < rj))
+    {
+      const uint32_t k1 = key[lj], k2 = key[rj], x1 = idx[lj], x2 = idx[rj];
+      key[lj] = k2;
+      key[rj] = k1;
+      idx[lj] = x2;
+      idx[rj] = x1;
+    }
+    else
+    {
+      bool prev_cont = false;
+      uint32_t rprev = 0;
+      if (j > 0)
+      {
+        const uint32_t lp = posL[bL + j - 1];  // j - 1 < m <= nL, nR
+        rprev = posR[bR + (nR - j)];
+        prev_cont = lp < rprev;
+      }
+      if (j == 0)
+        segs[s].cut = lj;  // J = 0: the left scan's first stop (exists: median-of-3 sentinel)
+      else if (prev_cont)
+        segs[s].cut = lj < rprev ? lj : rprev;  // cut = min(l_J, r_{J-1})
+    }
+  }
+}
+
 __global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, unsigned long long *__restrict__ cnt)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1766,8 +1987,12 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   if (ns)
   {
     hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs);
-    unsigned long long *lr = b.lr.as<unsigned long long>((uint64_t) n + 1);
-    uint32_t *segof = b.segof.as<uint32_t>(n);
+    // BK_SORT_OLD_LEVELS=1: the seven-launch partition level over materialised flags (debugging / comparison)
+    static const bool old_levels = getenv("BK_SORT_OLD_LEVELS") != nullptr;
+    unsigned long long *lr = old_levels ? b.lr.as<unsigned long long>((uint64_t) n + 1) : nullptr;
+    uint32_t *segof = old_levels ? b.segof.as<uint32_t>(n) : nullptr;
+    unsigned long long *tile_cnt = b.lv_tile.as<unsigned long long>((uint64_t) n / LV_TILE + 2);
+    unsigned long long *segbase = b.lv_segbase.as<unsigned long long>(max_segs + 1);
     uint32_t *posL = b.posL.as<uint32_t>((uint64_t) n + 2), *posR = b.posR.as<uint32_t>((uint64_t) n + 2);
     int level = 0;
     static const bool dbg_levels = getenv("BK_DEBUG_SORT") != nullptr;
@@ -1801,11 +2026,22 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       {
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
         pivoted = false;
-        const unsigned nbk = cdiv(na, 256);
-        hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, na, lr, segof, (const uint32_t *) nullptr);
-        prims::exclusive_scan<unsigned long long>(lr, lr, na, b.scan_tmp, st);
-        hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) nullptr);
-        hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) nullptr);
+        if (old_levels)
+        {
+          const unsigned nbk = cdiv(na, 256);
+          hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, na, lr, segof, (const uint32_t *) nullptr);
+          prims::exclusive_scan<unsigned long long>(lr, lr, na, b.scan_tmp, st);
+          hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) nullptr);
+          hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) nullptr);
+        }
+        else
+        {
+          const unsigned nbt = cdiv(na, LV_TILE);
+          hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, (const uint32_t *) nullptr);
+          hipLaunchKernelGGL(k_lv_sums, dim3(1), dim3(LV_SUM_THREADS), 0, st, tile_cnt, ns, na, segbase, (const uint32_t *) nullptr);
+          hipLaunchKernelGGL(k_lv_lists, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, posL, posR, segbase, (const uint32_t *) nullptr);
+          hipLaunchKernelGGL(k_lv_swap, dim3(nbt), dim3(256), 0, st, segs, ns, key, idx, na, segbase, posL, posR, (const uint32_t *) nullptr);
+        }
         hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
         prims::exclusive_scan<unsigned long long>(cnt, cnt, ns, b.scan_tmp, st);
         // the children are written while the host waits for their count (at most 2 per segment: 2 * ns <= capacity)
@@ -1823,14 +2059,24 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         const uint32_t cur[2] = {ns, na};
         HIP_CHECK(hipMemcpyAsync(lvl, cur, 8, hipMemcpyHostToDevice, st));
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-        const unsigned nbk = cdiv(na, 256);
+        const unsigned nbk = cdiv(na, 256), nbt = cdiv(na, LV_TILE);
         uint32_t ns_bound = ns;
         for (int l = 0; l < batch; ++l)
         {
-          hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns_bound, key, na, lr, segof, (const uint32_t *) lvl);
-          prims::exclusive_scan_devn<unsigned long long>(lr, lr, na, lvl + 1, b.scan_tmp, st);
-          hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) lvl);
-          hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) lvl);
+          if (old_levels)
+          {
+            hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns_bound, key, na, lr, segof, (const uint32_t *) lvl);
+            prims::exclusive_scan_devn<unsigned long long>(lr, lr, na, lvl + 1, b.scan_tmp, st);
+            hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) lvl);
+            hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) lvl);
+          }
+          else
+          {
+            hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, (const uint32_t *) lvl);
+            hipLaunchKernelGGL(k_lv_sums, dim3(1), dim3(LV_SUM_THREADS), 0, st, tile_cnt, ns_bound, na, segbase, (const uint32_t *) lvl);
+            hipLaunchKernelGGL(k_lv_lists, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, posL, posR, segbase, (const uint32_t *) lvl);
+            hipLaunchKernelGGL(k_lv_swap, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, idx, na, segbase, posL, posR, (const uint32_t *) lvl);
+          }
           hipLaunchKernelGGL(k_se_children_small, dim3(1), dim3(CHILD_THREADS), 0, st, segs, lvl, segs2, fin_list, fin, key, idx, err, heap_list);
           std::swap(segs, segs2);
           ns_bound = ns_bound * 2 < CHILD_FUSED ? ns_bound * 2 : CHILD_FUSED;
