@@ -631,22 +631,34 @@ static bool lanes_apply(const bk_ctx *ctx, int fast)
 }
 
 // K lanes of groups.  A lane's time is (a) per sort the LONGEST heapsort segment of any of its groups - a serial chain of one wave
-// that belongs, in practice, to its largest same-chromosome group - plus (b) partition levels and masks in proportion to its
-// pairs plus (c) a fixed number of launch-bound late levels.  The largest group's chain is the critical path of the whole
-// stage, so BREAKID_LANE_SOLO (default 1) of the largest groups get a lane of their own - nothing else waits in front of
-// their sorts - and the remaining groups are spread over the remaining lanes by longest-processing-time on size^e.
-static void group_lanes(bk_ctx *ctx, double w, int fast)
+// - plus (b) partition levels and masks in proportion to its pairs plus (c) a fixed number of launch-bound late levels.  Which
+// groups own long heap segments cannot be told from their sizes (all same-chromosome groups of a WGS sample are about equally
+// large; two or three of them carry segments of 30-46 K elements, most carry a few thousand), but it can be OBSERVED: a group
+// whose sort by x (by y) ran into the depth limit does so again in the next sort by the same coordinate.  So the stage runs in
+// two parts:
+//   part 1  sorts 1-2 (x, mask, y, mask) in K lanes split blindly (longest-processing-time on size^e); every lane records
+//           the longest heap segment of each of its groups per coordinate;
+//   part 2  sorts 3-5 (x | x-windows, y, y-windows, x) in K lanes split on what was observed: the groups are placed, heaviest
+//           chain first, where the lane's sum over the three sorts of its longest segment (+ a term for its pair count) grows least.
+// Off by default (BREAKID_LANE_ADAPT=1 turns it on): on the 30x WGS shape the sorts by x of the unmasked list (sort 1) say little
+// about the later sorts by x, so only the y-heavy groups are placed well and the barrier between the parts costs what that gains.  Results are identical whatever the split: the groups never
+// interact, a lane's list keeps every group's order, and the lists are merged back into group order.
+struct LanePlan
+{
+  std::vector<int> lane_of;
+};
+static LanePlan plan_blind(const bk_ctx *ctx, int K)
 {
   const uint32_t ng = ctx->jr.n_groups;
-  const int K = lanes_wanted();
   std::vector<uint32_t> order(ng);
   std::iota(order.begin(), order.end(), 0u);
   auto size_of = [&](uint32_t g) { return ctx->gstart_host[g + 1] - ctx->gstart_host[g]; };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size_of(a) > size_of(b); });
   static const double wexp = getenv("BREAKID_LANE_WEIGHT_EXP") ? atof(getenv("BREAKID_LANE_WEIGHT_EXP")) : 2.0;
-  static const int solo_env = getenv("BREAKID_LANE_SOLO") ? atoi(getenv("BREAKID_LANE_SOLO")) : 1;
+  static const int solo_env = getenv("BREAKID_LANE_SOLO") ? atoi(getenv("BREAKID_LANE_SOLO")) : 0;
   const int solo = std::max(0, std::min(solo_env, K - 1));
-  std::vector<int> lane_of(ng, 0);
+  LanePlan p;
+  p.lane_of.assign(ng, 0);
   std::vector<double> load(K, 0.0);
   for (uint32_t i = 0; i < ng; ++i)
   {
@@ -661,73 +673,182 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
         if (load[k] < load[l]) l = k;
       load[l] += std::pow((double) size_of(g), wexp);
     }
-    lane_of[g] = l;
+    p.lane_of[g] = l;
   }
+  return p;
+}
+// sizes = pairs per group now; hx / hy = longest heap segment per group seen in a sort by x / by y (0: none)
+static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vector<uint32_t> &hx, const std::vector<uint32_t> &hy, int K)
+{
+  const uint32_t ng = (uint32_t) sizes.size();
+  // one pop of a lone wave ~ 0.17 us; one pair costs a lane ~ 0.4 ns per sort in the bandwidth-bound levels and masks
+  static const double per_pair = getenv("BREAKID_LANE_PAIR_COST") ? atof(getenv("BREAKID_LANE_PAIR_COST")) : 0.008;
+  std::vector<uint32_t> order(ng);
+  std::iota(order.begin(), order.end(), 0u);
+  auto chain = [&](uint32_t g) { return 2.0 * hx[g] + hy[g]; };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    const double ca = chain(a), cb = chain(b);
+    return ca != cb ? ca > cb : sizes[a] > sizes[b];
+  });
+  LanePlan p;
+  p.lane_of.assign(ng, 0);
+  std::vector<double> mx(K, 0.0), my(K, 0.0), pairs(K, 0.0);
+  auto cost = [&](int l) { return 2.0 * mx[l] + my[l] + per_pair * pairs[l]; };
+  for (uint32_t g : order)
+  {
+    int best = 0;
+    double best_cost = 0;
+    for (int l = 0; l < K; ++l)
+    {
+      const double c = 2.0 * std::max(mx[l], (double) hx[g]) + std::max(my[l], (double) hy[g]) + per_pair * (pairs[l] + (double) sizes[g]);
+      // the lane whose own cost ends lowest takes the group (ties: the emptier lane)
+      if (l == 0 || c < best_cost || (c == best_cost && cost(l) < cost(best)))
+      {
+        best = l;
+        best_cost = c;
+      }
+    }
+    mx[best] = std::max(mx[best], (double) hx[g]);
+    my[best] = std::max(my[best], (double) hy[g]);
+    pairs[best] += (double) sizes[g];
+    p.lane_of[g] = best;
+  }
+  if (getenv("BK_DEBUG_LANES"))
+    for (int l = 0; l < K; ++l)
+    {
+      fprintf(stderr, "[lanes] lane %d: max heap x %.0f y %.0f, %.0f pairs, cost %.0f; heavy groups:", l, mx[l], my[l], pairs[l], cost(l));
+      for (uint32_t g = 0; g < ng; ++g)
+        if (p.lane_of[g] == l && (hx[g] || hy[g])) fprintf(stderr, " %u(%u,%u)", g, hx[g], hy[g]);
+      fprintf(stderr, "\n");
+    }
+  return p;
+}
+
+static void group_lanes(bk_ctx *ctx, double w, int fast)
+{
+  const uint32_t ng = ctx->jr.n_groups;
+  const int K = lanes_wanted();
+  static const bool adapt = getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) != 0;
   while ((int) ctx->lanes.size() < K - 1)
   {
     ctx->lanes.emplace_back(new bk_ctx::Lane());
     HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes.back()->st, hipStreamNonBlocking));
   }
-  std::vector<uint32_t> drop(ng);
-  for (int l = 0; l < K; ++l)
-  {
-    for (uint32_t g = 0; g < ng; ++g) drop[g] = lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
-    uint32_t *d = (l == 0 ? ctx->d_dropA : ctx->lanes[l - 1]->d_drop).as<uint32_t>((uint64_t) ng + 1);
-    HIP_CHECK(hipMemcpyAsync(d, drop.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
-    HIP_CHECK(hipStreamSynchronize(ctx->st));  // (drop is reused)
-  }
-  // the pair table and the masks are ready for all lanes
-  std::vector<std::string> err(K);
-  std::vector<int> code(K, BK_OK);
-  std::vector<std::thread> th;
-  for (int l = 1; l < K; ++l)
-    th.emplace_back([&, l] {
-      bk_ctx::Lane &B = *ctx->lanes[l - 1];
+  auto lane_cb = [&](int l) -> ClusterBufs & { return l == 0 ? ctx->cb : ctx->lanes[l - 1]->cb; };
+  auto lane_st = [&](int l) { return l == 0 ? ctx->st : ctx->lanes[l - 1]->st; };
+  auto lane_list = [&](int l) -> PairList & { return l == 0 ? ctx->listA : ctx->lanes[l - 1]->list; };
+  auto lane_iso = [&](int l) -> PairList & { return l == 0 ? ctx->isoA : ctx->lanes[l - 1]->iso; };
+  auto lane_cl = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_clusterA : ctx->lanes[l - 1]->d_cluster; };
+  auto lane_drop = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_dropA : ctx->lanes[l - 1]->d_drop; };
+  auto upload_plan = [&](const LanePlan &p) {
+    std::vector<uint32_t> drop(ng);
+    for (int l = 0; l < K; ++l)
+    {
+      for (uint32_t g = 0; g < ng; ++g) drop[g] = p.lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
+      uint32_t *d = lane_drop(l).as<uint32_t>((uint64_t) ng + 1);
+      HIP_CHECK(hipMemcpyAsync(d, drop.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
+      HIP_CHECK(hipStreamSynchronize(ctx->st));  // (drop is reused; the pair table and the masks are ready for all lanes)
+    }
+  };
+  // runs body(l) for every lane, lane 0 on this thread; the lanes' streams are synchronised when this returns
+  auto in_lanes = [&](auto body) {
+    std::vector<std::string> err(K);
+    std::vector<int> code(K, BK_OK);
+    auto guarded_body = [&](int l) {
       try
       {
-        HIP_CHECK(hipSetDevice(ctx->device));
-        run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, B.d_drop.get<uint32_t>(), B.list, B.iso, B.d_cluster, B.cb, ctx->ab, B.st);
-        HIP_CHECK(hipStreamSynchronize(B.st));
+        body(l);
+        HIP_CHECK(hipStreamSynchronize(lane_st(l)));
       }
       catch (const bk_error &e)
       {
         code[l] = e.code;
         err[l] = e.msg;
       }
+    };
+    std::vector<std::thread> th;
+    for (int l = 1; l < K; ++l)
+      th.emplace_back([&, l] {
+        (void) hipSetDevice(ctx->device);
+        guarded_body(l);
+      });
+    guarded_body(0);
+    for (std::thread &t : th) t.join();
+    for (int l = 0; l < K; ++l)
+      if (code[l] != BK_OK) throw bk_error(code[l], err[l]);
+  };
+  // folds the lanes' lists (disjoint groups) into one list in group order; cl = the cluster numbers travel along
+  auto merge_all = [&](auto list_of, auto cl_of, PairList &out, DevBuf *cl_out, PairList (&acc)[2], DevBuf (&cacc)[2]) {
+    const PairList *cur = &list_of(0);
+    const uint32_t *ccur = cl_of(0);
+    for (int l = 1; l < K; ++l)
+    {
+      const bool last = l == K - 1;
+      PairList &lo = last ? out : acc[l & 1];
+      DevBuf *co = cl_out ? (last ? cl_out : &cacc[l & 1]) : nullptr;
+      merge_lists(*cur, ccur, list_of(l), cl_of(l), lo, co, ctx->st);
+      cur = &lo;
+      ccur = co ? co->get<uint32_t>() : nullptr;
+    }
+  };
+  const bk_pair *pairs = ctx->jr.pairs;
+  upload_plan(plan_blind(ctx, K));
+  if (!adapt)
+  {
+    in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l).get<uint32_t>(), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l)); });
+  }
+  else
+  {
+    // part 1: sorts 1-2, observed
+    in_lanes([&](int l) {
+      ClusterBufs &cb = lane_cb(l);
+      cb.heavy_x.assign(ng, 0u);
+      cb.heavy_y.assign(ng, 0u);
+      cb.observe = true;
+      remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>());
+      cb.observe = false;
     });
-  try
-  {
-    run_lane(ctx->jr.pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, ctx->d_dropA.get<uint32_t>(), ctx->listA, ctx->isoA, ctx->d_clusterA, ctx->cb, ctx->ab, ctx->st);
+    PairList mid, acc[2];
+    DevBuf cacc[2];
+    merge_all([&](int l) -> const PairList & { return lane_list(l); }, [&](int) -> const uint32_t * { return nullptr; }, mid, nullptr, acc, cacc);
+    std::vector<uint64_t> goff_h((size_t) ng + 1);
+    HIP_CHECK(hipMemcpyAsync(goff_h.data(), mid.goff.get<uint64_t>(), ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
+    HIP_CHECK(hipStreamSynchronize(ctx->st));
+    std::vector<uint64_t> sizes(ng);
+    std::vector<uint32_t> hx(ng, 0u), hy(ng, 0u);
+    for (uint32_t g = 0; g < ng; ++g) sizes[g] = goff_h[g + 1] - goff_h[g];
+    for (int l = 0; l < K; ++l)
+      for (uint32_t g = 0; g < ng; ++g)
+      {
+        hx[g] = std::max(hx[g], lane_cb(l).heavy_x[g]);
+        hy[g] = std::max(hy[g], lane_cb(l).heavy_y[g]);
+      }
+    upload_plan(plan_observed(sizes, hx, hy, K));
+    // part 2: sorts 3-5
+    in_lanes([&](int l) {
+      PairList &L = lane_list(l), &iso = lane_iso(l);
+      hipStream_t st = lane_st(l);
+      list_subset(mid, lane_drop(l).get<uint32_t>(), L, lane_cb(l), st);
+      remove_isolated_end(pairs, L, lane_cb(l), st);
+      iso.n = L.n;
+      iso.ng = L.ng;
+      uint32_t *ii = iso.idx.as<uint32_t>(L.n + 1), *ig = iso.gof.as<uint32_t>(L.n + 1);
+      uint64_t *io = iso.goff.as<uint64_t>((uint64_t) L.ng + 1);
+      if (L.n) HIP_CHECK(hipMemcpyAsync(ii, L.idx.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToDevice, st));
+      if (L.n) HIP_CHECK(hipMemcpyAsync(ig, L.gof.get<uint32_t>(), L.n * 4, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(io, L.goff.get<uint64_t>(), ((uint64_t) L.ng + 1) * 8, hipMemcpyDeviceToDevice, st));
+      if (fast)
+        fast_cluster_all(pairs, L, w, lane_cl(l), lane_cb(l), st);
+      else
+        ahc_cluster_all(pairs, L, w, lane_cl(l), ctx->ab, lane_cb(l), st);
+    });
   }
-  catch (const bk_error &e)
-  {
-    code[0] = e.code;
-    err[0] = e.msg;
-  }
-  for (std::thread &t : th) t.join();
-  for (int l = 0; l < K; ++l)
-    if (code[l] != BK_OK) throw bk_error(code[l], err[l]);
-  // one list in group order again (the other lanes have finished: their streams were synchronised by their threads); the lanes
-  // own disjoint groups, so they fold into the result one after the other
-  PairList iso_acc[2], list_acc[2];
-  DevBuf cl_acc[2];
-  const PairList *iso_cur = &ctx->isoA, *list_cur = &ctx->listA;
-  const uint32_t *cl_cur = ctx->d_clusterA.get<uint32_t>();
-  for (int l = 1; l < K; ++l)
-  {
-    bk_ctx::Lane &B = *ctx->lanes[l - 1];
-    const bool last = l == K - 1;
-    PairList &io = iso_acc[l & 1];
-    merge_lists(*iso_cur, nullptr, B.iso, nullptr, io, nullptr, ctx->st);
-    iso_cur = &io;
-    PairList &lo = last ? ctx->list : list_acc[l & 1];
-    DevBuf &co = last ? ctx->d_cluster : cl_acc[l & 1];
-    merge_lists(*list_cur, cl_cur, B.list, B.d_cluster.get<uint32_t>(), lo, &co, ctx->st);
-    list_cur = &lo;
-    cl_cur = co.get<uint32_t>();
-  }
+  // one list in group order again
+  PairList iso_m, iacc[2], lacc[2];
+  DevBuf icacc[2], lcacc[2];
+  merge_all([&](int l) -> const PairList & { return lane_iso(l); }, [&](int) -> const uint32_t * { return nullptr; }, iso_m, nullptr, iacc, icacc);
+  merge_all([&](int l) -> const PairList & { return lane_list(l); }, [&](int l) -> const uint32_t * { return lane_cl(l).get<uint32_t>(); }, ctx->list, &ctx->d_cluster, lacc, lcacc);
   HIP_CHECK(hipStreamSynchronize(ctx->st));
-  PairList &iso_m = iso_acc[(K - 1) & 1];
   ctx->iso_n = iso_m.n;
   std::swap(ctx->iso_idx, iso_m.idx);
   std::swap(ctx->iso_goff, iso_m.goff);

@@ -17,6 +17,9 @@ struct PairList
 
 struct ClusterBufs
 {
+  // observers for the lanes of api.hip (host, may stay empty): the longest heapsort segment of every group in the sorts by x / by y
+  std::vector<uint32_t> heavy_x, heavy_y;
+  bool observe = false;
   DevBuf key, perm, tmp, cnt, off, off2, idx2, gof2, goff2, jump, mark, apos, kid, kprev2, k1, k2, pk, knum, clfull, small, scan_tmp;
   SortEmuBufs se;
   prims::RadixBufs radix;
@@ -25,6 +28,12 @@ struct ClusterBufs
 // remove_isolated_pairs for every group; L receives the surviving list (x-sorted, duplicates included)
 void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
                          const uint32_t *drop_group = nullptr);  // drop_group[g] != 0: group g is left to another rank
+// the same in two parts, so that a caller may redistribute the groups between them: through the second mask / the third sort
+void remove_isolated_begin(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
+                           const uint32_t *drop_group = nullptr);
+void remove_isolated_end(const bk_pair *pairs, PairList &L, ClusterBufs &b, hipStream_t st);
+// dst = src without the groups flagged in drop[] (device, one u32 per group; offsets for all groups are kept)
+void list_subset(const PairList &src, const uint32_t *drop, PairList &dst, ClusterBufs &b, hipStream_t st);
 // removes the groups that keep fewer than 2 pairs (they are not clustered, BreakID.cc:125)
 void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st);
 // find_cluster_pairs_enspan_fast for every group with >= 2 pairs; L becomes the clustered list, cluster_out[p] its cluster number

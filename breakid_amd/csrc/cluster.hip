@@ -250,7 +250,9 @@ static void sort_list(const bk_pair *pairs, PairList &L, int use_y, uint32_t **e
   uint32_t *key = b.key.as<uint32_t>(L.n), *perm = b.perm.as<uint32_t>(L.n);
   hipLaunchKernelGGL(k_gather_key, dim3(nb(L.n)), dim3(256), 0, st, pairs, L.idx.get<uint32_t>(), L.n, use_y, key);
   hipLaunchKernelGGL(k_iota, dim3(nb(L.n)), dim3(256), 0, st, perm, L.n);
+  b.se.heavy = b.observe ? (use_y ? &b.heavy_y : &b.heavy_x) : nullptr;
   std_sort_groups(key, perm, L.gof.get<uint32_t>(), L.goff.get<uint64_t>(), L.ng, L.n, b.se, st);
+  b.se.heavy = nullptr;
   uint32_t *tmp = b.tmp.as<uint32_t>(L.n);
   auto apply = [&](uint32_t *arr) {
     hipLaunchKernelGGL(k_gather_u32, dim3(nb(L.n)), dim3(256), 0, st, arr, perm, L.n, tmp);
@@ -283,6 +285,34 @@ static void mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs 
 void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
                          const uint32_t *drop_group)
 {
+  remove_isolated_begin(pairs, gof0, gstart, ng, n, w, L, b, st, drop_group);
+  remove_isolated_end(pairs, L, b, st);
+}
+
+void remove_isolated_end(const bk_pair *pairs, PairList &L, ClusterBufs &b, hipStream_t st)
+{
+  if (L.n == 0 || L.ng == 0) return;
+  sort_list(pairs, L, 0, nullptr, 0, b, st);
+}
+
+void list_subset(const PairList &src, const uint32_t *drop, PairList &dst, ClusterBufs &b, hipStream_t st)
+{
+  dst.n = src.n;
+  dst.ng = src.ng;
+  uint32_t *idx = dst.idx.as<uint32_t>(src.n + 1), *gof = dst.gof.as<uint32_t>(src.n + 1);
+  uint64_t *goff = dst.goff.as<uint64_t>((uint64_t) src.ng + 1);
+  if (src.n)
+  {
+    HIP_CHECK(hipMemcpyAsync(idx, src.idx.get<uint32_t>(), src.n * 4, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(gof, src.gof.get<uint32_t>(), src.n * 4, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_CHECK(hipMemcpyAsync(goff, src.goff.get<uint64_t>(), ((uint64_t) src.ng + 1) * 8, hipMemcpyDeviceToDevice, st));
+  filter_groups(dst, drop, b, st);
+}
+
+void remove_isolated_begin(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
+                           const uint32_t *drop_group)
+{
   L.n = n;
   L.ng = ng;
   uint32_t *idx = L.idx.as<uint32_t>(n + 1);
@@ -298,7 +328,6 @@ void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint6
   mask_list(pairs, L, dist, b, st);
   sort_list(pairs, L, 1, nullptr, 0, b, st);
   mask_list(pairs, L, dist, b, st);
-  sort_list(pairs, L, 0, nullptr, 0, b, st);
 }
 
 // one anchored-window pass (on the list's current order, keyed by x or y): keeps members of windows with

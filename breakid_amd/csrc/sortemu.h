@@ -2,11 +2,15 @@
 #pragma once
 #include "bk_common.h"
 #include "prims.h"
+#include <vector>
 
 struct SortEmuBufs
 {
   DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, fin_list, fin_cnt, lvl, lv_tile, lv_segbase;
   prims::RadixBufs radix;
+  // optional observer (host): heavy[g] = largest heapsort segment (elements) any sort through these buffers left to group g's
+  // lone-wave heap kernels - what the lanes of api.hip balance on.  Set by the caller around the sorts it wants recorded.
+  std::vector<uint32_t> *heavy = nullptr;
   // the three size classes of the heapsort branch run side by side (fork/join around the caller's stream)
   static constexpr int N_AUX = 5;
   hipStream_t aux[N_AUX] = {};

@@ -280,6 +280,30 @@ template <class M> __device__ void make_heap_wave(const M &mem, const uint32_t m
   }
 }
 
+// the same with every wave of the workgroup (NT threads, all of them call this): the nodes of one depth are spread over the
+// waves, a barrier separates the depths
+template <class M> __device__ void make_heap_block(const M &mem, const uint32_t m, const uint32_t NT)
+{
+  if (m < 2) return;
+  const uint32_t lastp = (m - 2) / 2;
+  for (int d = 31 - __clz(lastp + 1); d >= 0; --d)
+  {
+    const uint32_t lo = (1u << d) - 1;
+    uint32_t hi = (1u << (d + 1)) - 2;
+    if (hi > lastp) hi = lastp;
+    for (uint32_t p = lo + threadIdx.x; p <= hi; p += NT)
+    {
+      uint32_t hole = p;
+      const typename M::T v = mem.ld(p);
+      while (sift_step(mem, hole, m, v))
+      {
+      }
+    }
+    mem.step_sync();
+    __syncthreads();
+  }
+}
+
 // sort_heap: pops follow each other two steps apart (lag-2 pipeline) until the heap has shrunk to `stop` elements;
 // every pop has finished when this returns.  One loop iteration = one sift step of every pop in flight (one lane
 // each) + at most one launch.  The wave is alone on its critical path, so the loop is written branch-free: the
@@ -944,7 +968,8 @@ __device__ __forceinline__ void sort_heap_lds_q(uint32_t *slot1, const uint32_t 
 
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
-constexpr uint32_t HEAP_LARGE32 = 40000; // the same LDS in 4-byte ranked entries (+ slot 0 and two zero slots)
+constexpr size_t HEAP_BIG_LDS = 163800;  // dynamic LDS of the one-per-CU kernel: all of the CU's 160 KiB but the kernel's few static bytes
+constexpr uint32_t HEAP_LARGE32 = HEAP_BIG_LDS / 4 - 3; // that LDS in 4-byte ranked entries (+ slot 0 and two zero slots): 40 947
 constexpr uint32_t HEAP_RANKED_MIN = 4096;   // level-loop heaps above this size run on ranked entries (sort_heap_lds_zero)
 constexpr uint32_t HEAP_RANKED_MAX = 65534;  // rank + 1 must fit 16 bits and stay below the idle marker's 0xffff
 
@@ -986,10 +1011,9 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
       if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : m + threadIdx.x] = 0;
       __syncthreads();
       tp1 = wall_clock64();
-      if (w0)
       {
         LdsMemT<E32> mem{l32 + 1};
-        make_heap_wave(mem, m);
+        make_heap_block(mem, m, NT);
       }
       tp2 = tp3 = wall_clock64();
       if (w0) sort_heap_lds_q(l32 + 1, m, g32);
@@ -1000,10 +1024,9 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       tp1 = wall_clock64();
-      if (w0)
       {
         GlbMemT<E32> gmem{g32};
-        make_heap_wave(gmem, m);
+        make_heap_block(gmem, m, NT);
       }
       tp2 = wall_clock64();
       if (w0)
@@ -2129,22 +2152,38 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   if (nh1 || nfin)
   {
     hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
-    if (!b.fork)
-    {
-      HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
-      for (int i = 0; i < SortEmuBufs::N_AUX; ++i)
-      {
-        HIP_CHECK(hipStreamCreateWithFlags(&b.aux[i], hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&b.join[i], hipEventDisableTiming));
-      }
-    }
+    if (!b.fork) HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
   }
   auto side = [&](auto k, size_t lds, const HeapSeg *list, uint32_t count, uint32_t lo, uint32_t hi, uint32_t threads = 64) {
+    if (!b.aux[used])
+    {
+      // side streams are made when they are first needed (two per sort unless BK_HEAP_CLASSES): every stream takes one of the
+      // runtime's hardware queues in turn, and two lanes' heap kernels on one queue would run one after the other
+      HIP_CHECK(hipStreamCreateWithFlags(&b.aux[used], hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&b.join[used], hipEventDisableTiming));
+    }
     HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
     hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32);
     HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
     ++used;
   };
+  if (b.heavy && nh1 && max1 > HEAP_RANKED_MIN)
+  {
+    // the caller balances its lanes of groups on the longest heap segment per group
+    std::vector<HeapSeg> hh(nh1);
+    std::vector<uint64_t> go((size_t) ng + 1);
+    HIP_CHECK(hipMemcpyAsync(hh.data(), hl, (size_t) nh1 * sizeof(HeapSeg), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(go.data(), goff, ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (b.heavy->size() < ng) b.heavy->resize(ng, 0u);
+    for (const HeapSeg &h : hh)
+    {
+      const uint32_t m = h.last - h.first;
+      if (m <= HEAP_RANKED_MIN) continue;
+      const uint32_t g = (uint32_t) (std::upper_bound(go.begin(), go.end(), (uint64_t) h.first) - go.begin()) - 1;
+      if (g < ng && (*b.heavy)[g] < m) (*b.heavy)[g] = m;
+    }
+  }
   if (nh1 && max1 > HEAP_SMALL)
   {
     const uint32_t nh = nh1;
@@ -2180,6 +2219,22 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         fprintf(stderr, "[sortemu]   heap segment of %u: %u distinct keys, %u elements in tie groups (largest %u), key range %u..%u, %u descents in arrival order\n", m, distinct, in_ties, maxrun,
                 kk.front(), kk.back(), inv);
       }
+    }
+    if (dbg)
+    {
+      // which groups own the big heap segments?  (size : group, largest first)
+      std::vector<HeapSeg> hh(nh);
+      std::vector<uint64_t> go((size_t) ng + 1);
+      HIP_CHECK(hipMemcpy(hh.data(), hl, (size_t) nh * sizeof(HeapSeg), hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(go.data(), goff, ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost));
+      std::sort(hh.begin(), hh.end(), [](const HeapSeg &a, const HeapSeg &c) { return a.last - a.first > c.last - c.first; });
+      fprintf(stderr, "[sortemu]   big heap segments (size:group/group size):");
+      for (uint32_t i = 0; i < nh && i < 10; ++i)
+      {
+        const uint32_t g = (uint32_t) (std::upper_bound(go.begin(), go.end(), (uint64_t) hh[i].first) - go.begin()) - 1;
+        fprintf(stderr, " %u:%u/%llu", hh[i].last - hh[i].first, g, (unsigned long long) (go[g + 1] - go[g]));
+      }
+      fprintf(stderr, "\n");
     }
     // heaps of HEAP_LARGE+1 .. HEAP_RANKED_MAX elements run on ranked 4-byte entries: rank their keys first
     static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
@@ -2217,15 +2272,20 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       HIP_CHECK(hipEventRecord(b.fork, st));
       if (max1 > big_lo)
       {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        side(k2, dyn, hl, nh1, big_lo, 0xFFFFFFFFu, HEAP_BIG_THREADS);
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_BIG_LDS));
+        side(k2, HEAP_BIG_LDS, hl, nh1, big_lo, 0xFFFFFFFFu, HEAP_BIG_THREADS);
       }
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
       const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
       // one launch per LDS footprint (BK_HEAP_CLASSES=1) packs more mid-size heaps per CU but measured slower
       // end to end (197 vs 187 ms per step): the extra activity slows the lone wave on the critical path
       static const bool split = getenv("BK_HEAP_CLASSES") != nullptr;
-      if (!split || ranked_on)
+      // the mid-size heaps of the level loop (at most big_lo elements, ~1.5 ms) go in front of the finisher on the caller's own
+      // stream: only the big heaps need a side stream, and every stream of every lane of groups costs a hardware queue
+      static const bool mid_side = getenv("BK_HEAP_MID_SIDE") != nullptr;
+      if ((!split || ranked_on) && !mid_side)
+        hipLaunchKernelGGL(k1, dim3(nh1), dim3(64), ((size_t) big_lo + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, big_lo, rank32, scratch32);
+      else if (!split || ranked_on)
         side(k1, ((size_t) big_lo + HEAP_PAD) * 8, hl, nh1, HEAP_SMALL, big_lo);
       else
         for (int c = 0; c < 4; ++c)

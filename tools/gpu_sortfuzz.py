@@ -54,8 +54,8 @@ for case in range(cases):
     for g in range(ng):
         cls = int(rng.integers(0, 6))
         hi = [20, 300, 3000, 30_000, 70_000, 250_000][cls]
-        if rng.random() < 0.25:  # class boundaries of the emulation: 16/17, finisher 256 / 2048, heaps 1024 / 20000 / 40000 / 65536
-            sizes.append(max(0, int(rng.choice([16, 17, 32, 33, 256, 257, 1024, 1025, 2048, 2049, 20000, 20001, 40000, 40001, 65536, 65537])) + int(rng.integers(-2, 3))))
+        if rng.random() < 0.25:  # class boundaries of the emulation: 16/17, finisher 256 / 2048, heaps 1024 / 4096 / 20000 / 40947 / 65534
+            sizes.append(max(0, int(rng.choice([16, 17, 32, 33, 256, 257, 1024, 1025, 2048, 2049, 20000, 20001, 40000, 40001, 40947, 40948, 65534, 65535, 65536, 65537])) + int(rng.integers(-2, 3))))
         else:
             sizes.append(int(rng.integers(0, hi)))
     parts = [np.asarray(gen(rng, s), dtype=np.int64).astype(np.uint32) for s in sizes]
