@@ -733,6 +733,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   {
     ctx->lanes.emplace_back(new bk_ctx::Lane());
     HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes.back()->st, hipStreamNonBlocking));
+    ctx->lanes.back()->cb.max_group_bound = ctx->cb.max_group_bound;
   }
   auto lane_cb = [&](int l) -> ClusterBufs & { return l == 0 ? ctx->cb : ctx->lanes[l - 1]->cb; };
   auto lane_st = [&](int l) { return l == 0 ? ctx->st : ctx->lanes[l - 1]->st; };
@@ -857,6 +858,12 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
 int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
 {
   return guarded(ctx, [&] {
+    {
+      uint64_t mg = 0;
+      for (uint32_t g = 0; g < ctx->jr.n_groups && g + 1 < ctx->gstart_host.size(); ++g) mg = std::max<uint64_t>(mg, ctx->gstart_host[g + 1] - ctx->gstart_host[g]);
+      ctx->cb.max_group_bound = mg;
+      for (auto &l : ctx->lanes) l->cb.max_group_bound = mg;
+    }
     if (lanes_apply(ctx, fast))
     {
       {

@@ -20,6 +20,8 @@ struct ClusterBufs
   // observers for the lanes of api.hip (host, may stay empty): the longest heapsort segment of every group in the sorts by x / by y
   std::vector<uint32_t> heavy_x, heavy_y;
   bool observe = false;
+  // upper bound on the pairs of any one group (host; 0 = unknown): the anchored-window passes need log2 of it pointer-jumping levels
+  uint64_t max_group_bound = 0;
   DevBuf key, perm, tmp, cnt, off, off2, idx2, gof2, goff2, jump, mark, apos, kid, kprev2, k1, k2, pk, knum, clfull, small, scan_tmp;
   SortEmuBufs se;
   prims::RadixBufs radix;

@@ -338,8 +338,10 @@ static void fast_pass(const bk_pair *pairs, PairList &L, int use_y, double w, De
   const uint64_t n = L.n;
   uint32_t *key = b.key.as<uint32_t>(n);
   hipLaunchKernelGGL(k_gather_key, dim3(nb(n)), dim3(256), 0, st, pairs, L.idx.get<uint32_t>(), n, use_y, key);
+  // a chain of anchors never leaves its group: 2^levels hops must cover the largest group, not the whole list
+  const uint64_t chain_bound = b.max_group_bound && b.max_group_bound < n ? b.max_group_bound : n;
   int levels = 1;
-  while ((1ull << levels) < n) ++levels;
+  while ((1ull << levels) < chain_bound) ++levels;
   uint32_t *jump = b.jump.as<uint32_t>(n * (uint64_t) (levels + 1));
   hipLaunchKernelGGL(k_fast_next, dim3(nb(n)), dim3(256), 0, st, key, L.gof.get<uint32_t>(), L.goff.get<uint64_t>(), n, w, jump);
   for (int k = 1; k <= levels; ++k)
