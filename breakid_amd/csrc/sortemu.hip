@@ -850,8 +850,11 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
 //     program order, so they see it); the launch decision, the launch and the bookkeeping of a launch (which moves into the
 //     following iteration) run while that read is in flight;
 //   * the ancestor test is prepared from the holes BEFORE the step while the children are still on their way: a lane that
-//     descends ends one level deeper, so the only ancestor of L it can reach is L >> (clz(hole) - 1 - clz(L)); after the
-//     step one compare against the new hole is left;
+//     descends ends one level deeper, so the only ancestor of L it can reach is L >> (clz(hole) - 1 - clz(L)) (a hole that
+//     ends below L's level is compared with L itself, which it cannot equal; a lane that sits ON L stops there, so it is
+//     compared with 0, the hole of a lane that stopped); after the step ONE vector compare against the new holes and a
+//     branch are left - a scalar instruction that combines masks a vector compare has just written waits ~20 clocks for
+//     them (tools/ubench/issue.hip);
 //   * the launching lane is a rotating one-hot mask in SGPRs; launches are counted by L itself.
 // 20 instructions in the iteration after a launch, 36 in a launching one (was 21 and 42, with two exposed LDS round trips).
 // Per-lane: hole v40 (0 = idle), value v42 (-1 = idle).  Uniform: L s43, clz(L) + 1 s47, budget s45, clamp address s42,
@@ -864,7 +867,8 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
   "v_cndmask_b32 v51, v42, v50, vcc\n"                                                                                     \
   "ds_write_b32 v52, v51\n"                                                                                                \
   "v_cndmask_b32 v40, v55, v53, vcc\n"                                                                                     \
-  "v_cndmask_b32 v42, v59, v42, vcc\n"                                                                                     \
+  "v_cndmask_b32 v42, v59, v42, vcc\n"
+#define BK_HEAP32Q_NEXT                                                                                                   \
   "v_lshl_add_u32 v45, v40, 3, s40\n"                                                                                      \
   "v_min_u32 v45, s42, v45\n"                                                                                              \
   "ds_read2_b32 v[46:47], v45 offset1:1\n"
@@ -896,22 +900,23 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
   "s_cselect_b64 s[58:59], s[58:59], 1\n"                                                                                  \
   "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
   BK_HEAP32Q_STEP                                                                                                         \
+  BK_HEAP32Q_NEXT                                                                                                         \
   "BK_QB_%=:\n"                                                                                                           \
   "ds_read_b32 v56, v60\n"                                                                                                 \
   "ds_read_b32 v58, v61\n"                                                                                                 \
   "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
   "v_ffbh_u32 v63, v40\n"                                                                                                  \
   "v_subrev_u32 v63, s47, v63\n"                                                                                           \
+  "v_max_i32 v63, 0, v63\n"                                                                                                \
   "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
-  "v_cmp_le_i32_e64 s[52:53], 0, v63\n"                                                                                    \
-  "v_cmp_eq_u32_e64 s[60:61], s43, v40\n"                                                                                  \
+  "v_cmp_eq_u32 vcc, s43, v40\n"                                                                                           \
+  "v_cndmask_b32 v64, v64, v55, vcc\n"                                                                                     \
   "s_waitcnt lgkmcnt(2)\n"                                                                                                 \
   BK_HEAP32Q_STEP                                                                                                         \
+  "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
+  BK_HEAP32Q_NEXT                                                                                                         \
   "s_cmp_lt_u32 s43, 2\n"                                                                                                  \
   "s_cbranch_scc1 BK_QNOMORE_%=\n"                                                                                         \
-  "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
-  "s_and_b64 vcc, vcc, s[52:53]\n"                                                                                         \
-  "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
   "s_cbranch_vccnz BK_QBNEXT_%=\n"                                                                                         \
   "s_waitcnt lgkmcnt(2)\n"                                                                                                 \
   "s_mov_b64 exec, s[58:59]\n"                                                                                             \
