@@ -50,6 +50,15 @@ struct Seg
 // Segments of up to FIN_MAX elements leave the device-wide level loop: one workgroup finishes each of them in LDS
 // (k_se_finish).  fin[0] = number of entries of the finisher list.
 constexpr uint32_t FIN_MAX = 2048;
+// The partition passes work on tiles of LV_TILE compact indices (k_lv_*).  Whoever writes a level's segment list also leaves,
+// for every tile, the segment that owns the tile's first index: a tile then starts with one load instead of a binary search
+// over the list (seven dependent round trips that were most of a late level's kernel time).
+constexpr uint32_t LV_TILE = 2048;
+__device__ __forceinline__ void lv_mark_tiles(uint32_t *__restrict__ tile_seg, uint32_t s, uint32_t cbase, uint32_t size)
+{
+  if (!tile_seg) return;
+  for (uint32_t t = (cbase + LV_TILE - 1) / LV_TILE; (unsigned long long) t * LV_TILE < (unsigned long long) cbase + size; ++t) tile_seg[t] = s;
+}
 struct FinSeg
 {
   uint32_t first, last;
@@ -78,7 +87,7 @@ __global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsign
   cnt[g] = sz > FIN_MAX ? (1ull | (sz << 32)) : 0ull;
   if (sz > 16 && sz <= FIN_MAX) fin_append(fl, fin, (uint32_t) goff[g], (uint32_t) goff[g + 1], 2 * (63 - __clzll((long long) sz)));
 }
-__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs)
+__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs, uint32_t *__restrict__ tile_seg)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
@@ -93,6 +102,7 @@ __global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, 
     s.cut = 0;
     s.cbase = (uint32_t) (off[g] >> 32);
     segs[(uint32_t) off[g]] = s;
+    lv_mark_tiles(tile_seg, (uint32_t) off[g], s.cbase, (uint32_t) sz);
   }
 }
 
@@ -1274,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const u
 //   k_lv_swap    pair j of segment s = (posL[bL + j], posR[bR + nR - 1 - j]): swap while l_j < r_j, then the cut
 // ~27 B per element and level, five launches with the children kernel.  A live segment holds more than FIN_MAX = LV_TILE
 // elements, so a tile touches at most two segments: one binary search per tile, no owner array.
-constexpr uint32_t LV_TILE = 2048, LV_EPT = LV_TILE / 256;
+constexpr uint32_t LV_EPT = LV_TILE / 256;
 static_assert(LV_TILE <= FIN_MAX, "a tile must not span more than one segment boundary");
 struct LvTile
 {
@@ -1282,11 +1292,11 @@ struct LvTile
   Seg a, b;
 };
 // executed by every thread of the block after a barrier; c0 = first compact index of the tile
-__device__ __forceinline__ void lv_tile_setup(const Seg *__restrict__ segs, uint32_t ns, uint32_t c0, LvTile *sh)
+__device__ __forceinline__ void lv_tile_setup(const Seg *__restrict__ segs, uint32_t ns, uint32_t c0, LvTile *sh, const uint32_t *__restrict__ tile_seg)
 {
   if (threadIdx.x == 0)
   {
-    const uint32_t s = find_seg(segs, ns, c0);
+    const uint32_t s = tile_seg[c0 / LV_TILE];
     sh->s0 = s;
     sh->a = segs[s];
     Seg z = {};
@@ -1307,7 +1317,7 @@ __device__ __forceinline__ uint32_t lv_flags(const Seg &sg, uint32_t c, uint32_t
   return v;
 }
 __global__ __launch_bounds__(256) void k_lv_count(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na, unsigned long long *__restrict__ tile_cnt,
-                                                  const uint32_t *__restrict__ lvl)
+                                                  const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
 {
   __shared__ LvTile sh;
   __shared__ uint32_t s_scan[prims::WAVES];
@@ -1318,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_lv_count(const Seg *__restrict__ segs, 
   }
   const uint32_t c0 = blockIdx.x * LV_TILE;
   if (c0 >= na) return;
-  lv_tile_setup(segs, ns, c0, &sh);
+  lv_tile_setup(segs, ns, c0, &sh, tile_seg);
   const Seg A = sh.a, B = sh.b;
   uint32_t acc = 0;
 #pragma unroll
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(LV_SUM_THREADS) void k_lv_sums(unsigned long long *
 }
 __global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
                                                   const unsigned long long *__restrict__ tile_base, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR,
-                                                  unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ lvl)
+                                                  unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
 {
   __shared__ LvTile sh;
   __shared__ uint32_t s_scan[prims::WAVES];
@@ -1381,7 +1391,7 @@ __global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, 
   }
   const uint32_t c0 = blockIdx.x * LV_TILE;
   if (c0 >= na) return;
-  lv_tile_setup(segs, ns, c0, &sh);
+  lv_tile_setup(segs, ns, c0, &sh, tile_seg);
   const Seg A = sh.a, B = sh.b;
   const uint32_t s0 = sh.s0;
 #pragma unroll
@@ -1424,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, 
 }
 __global__ __launch_bounds__(256) void k_lv_swap(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
                                                  const unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR,
-                                                 const uint32_t *__restrict__ lvl)
+                                                 const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
 {
   __shared__ LvTile sh;
   __shared__ unsigned long long s_base[3];
@@ -1435,7 +1445,7 @@ __global__ __launch_bounds__(256) void k_lv_swap(Seg *__restrict__ segs, uint32_
   }
   const uint32_t c0 = blockIdx.x * LV_TILE;
   if (c0 >= na) return;
-  lv_tile_setup(segs, ns, c0, &sh);
+  lv_tile_setup(segs, ns, c0, &sh, tile_seg);
   const Seg A = sh.a, B = sh.b;
   const uint32_t s0 = sh.s0;
   if (threadIdx.x < 3) s_base[threadIdx.x] = s0 + threadIdx.x <= ns ? segbase[s0 + threadIdx.x] : 0ull;
@@ -1498,7 +1508,7 @@ __global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, unsi
   cnt[s] = v;
 }
 __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, const unsigned long long *__restrict__ off, Seg *__restrict__ out, FinSeg *__restrict__ fl,
-                                 uint32_t *__restrict__ fin)
+                                 uint32_t *__restrict__ fin, uint32_t *__restrict__ tile_seg)
 {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
@@ -1511,6 +1521,7 @@ __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, cons
     Seg c = sg;
     c.last = sg.cut;
     c.cbase = cb;
+    lv_mark_tiles(tile_seg, o, cb, a);
     cb += a;
     out[o++] = c;
   }
@@ -1521,6 +1532,7 @@ __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, cons
     Seg c = sg;
     c.first = sg.cut;
     c.cbase = cb;
+    lv_mark_tiles(tile_seg, o, cb, b);
     out[o++] = c;
   }
   else if (b > 16)
@@ -1535,7 +1547,7 @@ __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, cons
 constexpr uint32_t CHILD_THREADS = 1024, CHILD_PER = 8, CHILD_FUSED = CHILD_THREADS * CHILD_PER;
 __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *__restrict__ segs, uint32_t *__restrict__ lvl, Seg *__restrict__ out, FinSeg *__restrict__ fl,
                                                                      uint32_t *__restrict__ fin, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
-                                                                     uint2 *__restrict__ heap_list)
+                                                                     uint2 *__restrict__ heap_list, uint32_t *__restrict__ tile_seg)
 {
   __shared__ unsigned long long wsum[CHILD_THREADS / 64];
   __shared__ uint32_t s_max;
@@ -1594,6 +1606,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
       Seg c = sg;
       c.last = sg.cut;
       c.cbase = cb;
+      lv_mark_tiles(tile_seg, o, cb, a);
       cb += a;
       pivot_one(c, key, idx, err, heap_list);
       out[o++] = c;
@@ -1605,6 +1618,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
       Seg c = sg;
       c.first = sg.cut;
       c.cbase = cb;
+      lv_mark_tiles(tile_seg, o, cb, b);
       cb += b;
       pivot_one(c, key, idx, err, heap_list);
       out[o++] = c;
@@ -2014,13 +2028,14 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
   if (ns)
   {
-    hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs);
+    hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs, b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2));
     // BK_SORT_OLD_LEVELS=1: the seven-launch partition level over materialised flags (debugging / comparison)
     static const bool old_levels = getenv("BK_SORT_OLD_LEVELS") != nullptr;
     unsigned long long *lr = old_levels ? b.lr.as<unsigned long long>((uint64_t) n + 1) : nullptr;
     uint32_t *segof = old_levels ? b.segof.as<uint32_t>(n) : nullptr;
     unsigned long long *tile_cnt = b.lv_tile.as<unsigned long long>((uint64_t) n / LV_TILE + 2);
     unsigned long long *segbase = b.lv_segbase.as<unsigned long long>(max_segs + 1);
+    uint32_t *tile_seg = b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2);
     uint32_t *posL = b.posL.as<uint32_t>((uint64_t) n + 2), *posR = b.posR.as<uint32_t>((uint64_t) n + 2);
     int level = 0;
     static const bool dbg_levels = getenv("BK_DEBUG_SORT") != nullptr;
@@ -2065,16 +2080,16 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         else
         {
           const unsigned nbt = cdiv(na, LV_TILE);
-          hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, (const uint32_t *) nullptr);
+          hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, (const uint32_t *) nullptr, (const uint32_t *) tile_seg);
           hipLaunchKernelGGL(k_lv_sums, dim3(1), dim3(LV_SUM_THREADS), 0, st, tile_cnt, ns, na, segbase, (const uint32_t *) nullptr);
-          hipLaunchKernelGGL(k_lv_lists, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, posL, posR, segbase, (const uint32_t *) nullptr);
-          hipLaunchKernelGGL(k_lv_swap, dim3(nbt), dim3(256), 0, st, segs, ns, key, idx, na, segbase, posL, posR, (const uint32_t *) nullptr);
+          hipLaunchKernelGGL(k_lv_lists, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, posL, posR, segbase, (const uint32_t *) nullptr, (const uint32_t *) tile_seg);
+          hipLaunchKernelGGL(k_lv_swap, dim3(nbt), dim3(256), 0, st, segs, ns, key, idx, na, segbase, posL, posR, (const uint32_t *) nullptr, (const uint32_t *) tile_seg);
         }
         hipLaunchKernelGGL(k_se_child_count, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt);
         prims::exclusive_scan<unsigned long long>(cnt, cnt, ns, b.scan_tmp, st);
         // the children are written while the host waits for their count (at most 2 per segment: 2 * ns <= capacity)
         if (2ull * ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-        hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin);
+        hipLaunchKernelGGL(k_se_child_write, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, cnt, segs2, fin_list, fin, tile_seg);
         HIP_CHECK(hipMemcpyAsync(&tot, cnt + ns, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         std::swap(segs, segs2);
@@ -2100,12 +2115,12 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
           }
           else
           {
-            hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, (const uint32_t *) lvl);
+            hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, (const uint32_t *) lvl, (const uint32_t *) tile_seg);
             hipLaunchKernelGGL(k_lv_sums, dim3(1), dim3(LV_SUM_THREADS), 0, st, tile_cnt, ns_bound, na, segbase, (const uint32_t *) lvl);
-            hipLaunchKernelGGL(k_lv_lists, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, posL, posR, segbase, (const uint32_t *) lvl);
-            hipLaunchKernelGGL(k_lv_swap, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, idx, na, segbase, posL, posR, (const uint32_t *) lvl);
+            hipLaunchKernelGGL(k_lv_lists, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, posL, posR, segbase, (const uint32_t *) lvl, (const uint32_t *) tile_seg);
+            hipLaunchKernelGGL(k_lv_swap, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, idx, na, segbase, posL, posR, (const uint32_t *) lvl, (const uint32_t *) tile_seg);
           }
-          hipLaunchKernelGGL(k_se_children_small, dim3(1), dim3(CHILD_THREADS), 0, st, segs, lvl, segs2, fin_list, fin, key, idx, err, heap_list);
+          hipLaunchKernelGGL(k_se_children_small, dim3(1), dim3(CHILD_THREADS), 0, st, segs, lvl, segs2, fin_list, fin, key, idx, err, heap_list, tile_seg);
           std::swap(segs, segs2);
           ns_bound = ns_bound * 2 < CHILD_FUSED ? ns_bound * 2 : CHILD_FUSED;
           ++level;
