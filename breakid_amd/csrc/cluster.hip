@@ -131,6 +131,75 @@ __global__ __launch_bounds__(256) void k_mark_jump(const uint32_t *__restrict__ 
     if (t != END) mark[t] = 1;
   }
 }
+// ---- anchors of all windows: the positions a group's chain start -> nxt -> nxt ... visits ------------------------------
+// Pointer jumping over the whole list (k_jump_double / k_mark_jump: log2(largest group) launches each, every one a pass over n
+// elements) is kept as the reference statement (BK_FAST_JUMP_GLOBAL=1).  The chain is strictly increasing and never leaves its
+// group, so it is followed tile by tile instead:
+//   k_fw_exit   per tile of FW_TILE positions, in LDS: exit[p] = the first position of p's chain behind the tile (END if it ends
+//               inside)
+//   k_fw_chain  one thread per group: from the group's start, exit -> exit -> ...: the first anchor of every tile the chain
+//               visits is marked (at most one hop per tile)
+//   k_fw_mark   per tile, in LDS: exact 2^k-hop tables of the tile's part of nxt, then the marks spread from the seeds (group
+//               starts and chain entries) highest level first, as k_mark_jump does over the whole list
+constexpr uint32_t FW_TILE = 1024, FW_LEVELS = 10;
+__global__ __launch_bounds__(FW_TILE) void k_fw_exit(const uint32_t *__restrict__ nxt, uint64_t n, uint32_t *__restrict__ exitp)
+{
+  __shared__ uint32_t e[FW_TILE];
+  const uint64_t t0 = (uint64_t) blockIdx.x * FW_TILE, p = t0 + threadIdx.x;
+  const uint64_t tend = t0 + FW_TILE;
+  e[threadIdx.x] = p < n ? nxt[p] : END;
+  for (uint32_t r = 0; r < FW_LEVELS; ++r)
+  {
+    __syncthreads();
+    const uint32_t v = e[threadIdx.x];
+    // a value read while its owner moves it on is still a position of the chain, only further along
+    if (v != END && v < tend) e[threadIdx.x] = e[v - t0];
+  }
+  __syncthreads();
+  if (p < n) exitp[p] = e[threadIdx.x];
+}
+__global__ __launch_bounds__(64) void k_fw_chain(const uint64_t *__restrict__ goff, uint32_t ng, const uint32_t *__restrict__ exitp, uint32_t *__restrict__ mark)
+{
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng || goff[g + 1] <= goff[g]) return;
+  uint32_t p = (uint32_t) goff[g];  // marked by k_mark_starts
+  for (;;)
+  {
+    const uint32_t q = exitp[p];
+    if (q == END) break;
+    mark[q] = 1;
+    p = q;
+  }
+}
+__global__ __launch_bounds__(FW_TILE) void k_fw_mark(const uint32_t *__restrict__ nxt, uint64_t n, uint32_t *__restrict__ mark)
+{
+  __shared__ uint16_t j[FW_LEVELS][FW_TILE];
+  __shared__ uint32_t m[FW_TILE];
+  constexpr uint16_t OUT = 0xFFFFu;
+  const uint64_t t0 = (uint64_t) blockIdx.x * FW_TILE, p = t0 + threadIdx.x;
+  const uint32_t i = threadIdx.x;
+  uint32_t v = p < n ? nxt[p] : END;
+  j[0][i] = (v != END && v < t0 + FW_TILE) ? (uint16_t) (v - t0) : OUT;
+  m[i] = p < n ? mark[p] : 0u;
+  for (uint32_t k = 1; k < FW_LEVELS; ++k)
+  {
+    __syncthreads();
+    const uint16_t a = j[k - 1][i];
+    j[k][i] = a == OUT ? OUT : j[k - 1][a];
+  }
+  for (int k = FW_LEVELS - 1; k >= 0; --k)
+  {
+    __syncthreads();
+    if (m[i])
+    {
+      const uint16_t t = j[k][i];
+      if (t != OUT) m[t] = 1u;
+    }
+  }
+  __syncthreads();
+  if (p < n) mark[p] = m[i];
+}
+
 // ascan = exclusive scan of mark.  Anchor ordinal of p = ascan[p] + mark[p] - 1.
 __global__ __launch_bounds__(256) void k_anchor_pos(const uint32_t *__restrict__ mark, const uint32_t *__restrict__ ascan, uint64_t n, uint32_t *__restrict__ apos)
 {
@@ -342,14 +411,26 @@ static void fast_pass(const bk_pair *pairs, PairList &L, int use_y, double w, De
   const uint64_t chain_bound = b.max_group_bound && b.max_group_bound < n ? b.max_group_bound : n;
   int levels = 1;
   while ((1ull << levels) < chain_bound) ++levels;
-  uint32_t *jump = b.jump.as<uint32_t>(n * (uint64_t) (levels + 1));
+  static const bool jump_global = getenv("BK_FAST_JUMP_GLOBAL") != nullptr;
+  uint32_t *jump = b.jump.as<uint32_t>(n * (uint64_t) (jump_global ? levels + 1 : 2));
   hipLaunchKernelGGL(k_fast_next, dim3(nb(n)), dim3(256), 0, st, key, L.gof.get<uint32_t>(), L.goff.get<uint64_t>(), n, w, jump);
-  for (int k = 1; k <= levels; ++k)
-    hipLaunchKernelGGL(k_jump_double, dim3(nb(n)), dim3(256), 0, st, jump + (uint64_t) (k - 1) * n, n, jump + (uint64_t) k * n);
   uint32_t *mark = b.mark.as<uint32_t>(n + 1);
   HIP_CHECK(hipMemsetAsync(mark, 0, (n + 1) * 4, st));
   hipLaunchKernelGGL(k_mark_starts, dim3(cdiv(L.ng, 256)), dim3(256), 0, st, L.goff.get<uint64_t>(), L.ng, mark);
-  for (int k = levels; k >= 0; --k) hipLaunchKernelGGL(k_mark_jump, dim3(nb(n)), dim3(256), 0, st, jump + (uint64_t) k * n, n, mark);
+  if (jump_global)
+  {
+    for (int k = 1; k <= levels; ++k)
+      hipLaunchKernelGGL(k_jump_double, dim3(nb(n)), dim3(256), 0, st, jump + (uint64_t) (k - 1) * n, n, jump + (uint64_t) k * n);
+    for (int k = levels; k >= 0; --k) hipLaunchKernelGGL(k_mark_jump, dim3(nb(n)), dim3(256), 0, st, jump + (uint64_t) k * n, n, mark);
+  }
+  else
+  {
+    uint32_t *exitp = jump + n;
+    const unsigned tiles = (unsigned) cdiv(n, FW_TILE);
+    hipLaunchKernelGGL(k_fw_exit, dim3(tiles), dim3(FW_TILE), 0, st, jump, n, exitp);
+    hipLaunchKernelGGL(k_fw_chain, dim3(cdiv(L.ng, 64)), dim3(64), 0, st, L.goff.get<uint64_t>(), L.ng, exitp, mark);
+    hipLaunchKernelGGL(k_fw_mark, dim3(tiles), dim3(FW_TILE), 0, st, jump, n, mark);
+  }
   uint32_t *ascan = b.off.as<uint32_t>(n + 1);
   prims::exclusive_scan<uint32_t>(mark, ascan, n, b.scan_tmp, st);
   uint32_t *apos = b.apos.as<uint32_t>(n + 1);
