@@ -247,6 +247,50 @@ __global__ __launch_bounds__(256) void k_gather_cand(const Cand *__restrict__ in
 }  // namespace
 
 // mate join proper: candidates -> pairs in no particular order (b.unsorted, keys in b.okey / b.oval)
+// The mate join only needs candidates of one read name NEXT to each other (join_run visits a run in record order whatever its
+// order in memory), so the candidates are sorted by the upper half of the name hash only (four radix passes instead of eight)
+// and the few runs of equal upper halves that hold more than one name (~n^2 / 2^33 of them) are put in order by the full hash
+// here, one thread per run.  A mixed run of more than JOIN_FIX_MAX candidates sets bit 2 of err: the host sorts by all 64 bits.
+constexpr uint32_t JOIN_FIX_MAX = 64;
+__global__ __launch_bounds__(256) void k_join_fix_runs(uint64_t *__restrict__ key, uint32_t *__restrict__ val, uint64_t n, uint32_t *__restrict__ err)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k0 = key[i];
+  const uint32_t hi = (uint32_t) (k0 >> 32);
+  if (i > 0 && (uint32_t) (key[i - 1] >> 32) == hi) return;  // not the start of a run of equal upper halves
+  uint64_t e = i + 1;
+  bool mixed = false;
+  while (e < n)
+  {
+    const uint64_t k = key[e];
+    if ((uint32_t) (k >> 32) != hi) break;
+    mixed |= k != k0;
+    ++e;
+  }
+  if (!mixed) return;
+  const uint64_t len = e - i;
+  if (len > JOIN_FIX_MAX)
+  {
+    atomicOr(err, 4u);
+    return;
+  }
+  for (uint64_t a = 1; a < len; ++a)
+  {
+    const uint64_t kk = key[i + a];
+    const uint32_t vv = val[i + a];
+    uint64_t b = a;
+    while (b > 0 && key[i + b - 1] > kk)
+    {
+      key[i + b] = key[i + b - 1];
+      val[i + b] = val[i + b - 1];
+      --b;
+    }
+    key[i + b] = kk;
+    val[i + b] = vv;
+  }
+}
+
 static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, const uint32_t *tprefix, int32_t nt, JoinBufs &b, hipStream_t st)
 {
   if (n_cand > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 discordant candidates");
@@ -257,20 +301,31 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
   bk_pair *unsorted = b.unsorted.as<bk_pair>(cap);
   uint64_t *okey = b.okey.as<uint64_t>(cap);
   uint32_t *oval = b.oval.as<uint32_t>(cap);
-  if (n_cand)
-  {
-    uint64_t *key = b.key.as<uint64_t>(n_cand);
-    uint32_t *val = b.val.as<uint32_t>(n_cand);
-    hipLaunchKernelGGL(k_join_keys, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, n_cand, key, val);
-    uint64_t *ks;
-    uint32_t *vs;
-    prims::radix_sort_pairs(key, val, n_cand, 0, 64, b.radix, st, &ks, &vs);
-    hipLaunchKernelGGL(k_join_pairs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, ks, vs, n_cand, w, tprefix, nt, unsorted, okey, oval,
-                       (unsigned long long) cap, counter, err);
-  }
   unsigned long long host[2] = {0, 0};
-  HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
+  static const bool full_sort = getenv("BK_JOIN_FULL_SORT") != nullptr;  // all 64 bits from the start (debugging / comparison)
+  for (int attempt = full_sort ? 1 : 0; attempt < 2; ++attempt)
+  {
+    if (n_cand)
+    {
+      uint64_t *key = b.key.as<uint64_t>(n_cand);
+      uint32_t *val = b.val.as<uint32_t>(n_cand);
+      hipLaunchKernelGGL(k_join_keys, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, n_cand, key, val);
+      uint64_t *ks;
+      uint32_t *vs;
+      prims::radix_sort_pairs(key, val, n_cand, attempt == 0 ? 32 : 0, 64, b.radix, st, &ks, &vs);
+      if (attempt == 0) hipLaunchKernelGGL(k_join_fix_runs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, ks, vs, n_cand, err);
+      hipLaunchKernelGGL(k_join_pairs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, ks, vs, n_cand, w, tprefix, nt, unsorted, okey, oval,
+                         (unsigned long long) cap, counter, err);
+    }
+    HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (attempt == 0 && ((uint32_t) host[1] & 4u))
+    {
+      HIP_CHECK(hipMemsetAsync(counter, 0, 16, st));  // a long run of equal upper halves with several names in it: once more, on all 64 bits
+      continue;
+    }
+    break;
+  }
   if ((uint32_t) host[1] & 2u)
     throw bk_error(BK_ERR_COLLISION, "two different read names share one 64-bit name hash (their second hashes differ): the mate join would not be the reference's");
   if ((uint32_t) host[1] & 1u) throw bk_error(BK_ERR_LIMIT, "more than 4096 candidate records share one read-name hash");

@@ -152,3 +152,33 @@ def test_record_longer_than_8_MiB_across_a_feed_chunk_takes_the_host_decoder(mon
         assert e.value.code == abi.BK_ERR_LIMIT and "8 MiB" in str(e.value)
         contigs2, cols = capi.decode_bam(p)
     assert contigs2 == contigs and len(cols["tid"]) == 401 and int(cols["pos"][200]) == 5000
+
+
+@pytest.mark.parametrize("names_per_half", [3, 10**9])
+def test_read_names_sharing_the_upper_half_of_their_hash_are_still_joined_by_name(golden_dir, names_per_half):
+    """the candidates are sorted by the upper 32 bits of the name hash only; runs of equal upper halves that hold several names
+    are put in order by the full hash (k_join_fix_runs: up to 64 candidates per run), longer ones send the join back to a
+    sort on all 64 bits - either way the pairs must be the oracle's"""
+    from oracle import pyoracle
+    contigs, cols = refdump.load_soa(golden_dir, "g2")
+    cols = {k: v.copy() for k, v in cols.items()}
+    q = cols["qhash"]
+    names = np.unique(q)
+    # groups of `names_per_half` names share their upper 32 bits (3 names = 6 candidates: fixed in place; all names in one run: fallback)
+    remap = {}
+    for j, h in enumerate(names):
+        remap[int(h)] = ((0x9E3779B9 + j // names_per_half) << 32) | (j * 2654435761 & 0xFFFFFFFF)
+    assert len(set(remap.values())) == len(names)
+    cols["qhash"] = np.array([remap[int(h)] for h in q], dtype=np.uint64)
+    ctx = capi.Context(contigs)
+    ctx.upload(cols)
+    w, nv = ctx.run(qual=20, fast=True)
+    o = pyoracle.Oracle(contigs, cols)
+    ow, rc = o.run(20, fast=True)
+    assert rc == 0 and w == ow
+    for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_CLUSTERS):
+        a, ao = ctx.fetch(st)
+        b, bo = o.fetch(st)
+        assert np.array_equal(a, b), st
+    ctx.close()
+    o.close()

@@ -335,11 +335,11 @@ def test_other_mapq_thresholds(golden_dir, qual):
     o.close()
 
 
-@pytest.mark.parametrize("lanes,solo", [(2, 0), (2, 1), (3, 1), (4, 2)])
-def test_lanes_of_groups_match_the_single_pass_and_the_oracle(lanes, solo):
+@pytest.mark.parametrize("lanes,solo,adapt", [(2, 0, 0), (2, 1, 0), (3, 1, 0), (4, 2, 0), (2, 0, 1), (3, 0, 1)])
+def test_lanes_of_groups_match_the_single_pass_and_the_oracle(lanes, solo, adapt):
     """BREAKID_GROUP_LANES=K (bench.py and the command line run with it): the chromosome-pair groups are masked and clustered
-    in K disjoint sets on K streams / host threads (BREAKID_LANE_SOLO of the largest groups alone in a lane) and merged back
-    into group order - every stage array must be the same as the oracle's.  Own process: the runtime reads GPU_MAX_HW_QUEUES
+    in K disjoint sets on K streams / host threads (BREAKID_LANE_SOLO of the largest groups alone in a lane; BREAKID_LANE_ADAPT=1:
+    re-split after the second sort on the heap segments observed so far) and merged back into group order - every stage array must be the same as the oracle's.  Own process: the runtime reads GPU_MAX_HW_QUEUES
     when it starts."""
     import subprocess
     import sys
@@ -367,6 +367,6 @@ for st in (abi.STAGE_GROUP_KEYS, abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTE
     if ao is not None: assert np.array_equal(ao, bo), st
 print("LANES_OK", nv)
 """ % ROOT_DIR
-    env = dict(os.environ, BREAKID_GROUP_LANES=str(lanes), BREAKID_LANE_SOLO=str(solo), GPU_MAX_HW_QUEUES="16", BREAKID_LANES_MIN_PAIRS="1000")
+    env = dict(os.environ, BREAKID_GROUP_LANES=str(lanes), BREAKID_LANE_SOLO=str(solo), BREAKID_LANE_ADAPT=str(adapt), GPU_MAX_HW_QUEUES="16", BREAKID_LANES_MIN_PAIRS="1000")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LANES_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
