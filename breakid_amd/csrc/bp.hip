@@ -179,6 +179,26 @@ __device__ __forceinline__ int32_t rec_endpos(const RecView &r, uint64_t i)
 // cache resident) the first ~20 steps stay in the cache and only the last 10 touch the record columns.
 constexpr uint32_t REC_SAMPLE_SHIFT = 10;
 __device__ __forceinline__ unsigned long long rec_key(int32_t tid, long long pos) { return ((unsigned long long) (uint32_t) tid << 32) | (uint32_t) (pos + 0x80000000ll); }
+// Lower bound by a whole wavefront: every lookup of this file is made by all 64 lanes of a wave with the same arguments (one
+// wave per cluster), and a binary search is a chain of dependent memory round trips - 30 of them for a record lookup, ~22 for
+// a tuple lookup, the better part of k_bp_cov / k_bp_regions / k_bp_depth.  64 probes per round trip cut the range 65-fold:
+// `less(i)` = "element i orders before the target" (monotone over [lo, hi)); returns the first index for which it is false.
+template <class Less> __device__ __forceinline__ uint64_t wave_lower(uint64_t lo, uint64_t hi, Less less)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  while (hi - lo > 64)
+  {
+    const uint64_t width = hi - lo;
+    const uint64_t p = lo + width * (lane + 1) / 65;  // lo < p < hi
+    const uint32_t c = (uint32_t) __popcll(__ballot(less(p)));  // the probes that order before the target are a prefix of the lanes
+    const uint64_t nlo = c ? lo + width * c / 65 + 1 : lo;
+    const uint64_t nhi = c < 64 ? lo + width * (c + 1) / 65 : hi;
+    lo = nlo;
+    hi = nhi;
+  }
+  const uint64_t i = lo + lane;
+  return lo + (uint64_t) __popcll(__ballot(i < hi && less(i)));
+}
 __device__ uint64_t rec_lower(const RecView &r, int32_t T, long long P)
 {
   uint64_t lo = 0, hi = r.n;
@@ -186,24 +206,16 @@ __device__ uint64_t rec_lower(const RecView &r, int32_t T, long long P)
   {
     // samp[j] = key of record j << REC_SAMPLE_SHIFT; first sample >= target bounds the answer to one stride
     const unsigned long long want = rec_key(T, P < -0x80000000ll ? -0x80000000ll : P);
-    uint64_t a = 0, b = r.n_samp;
-    while (a < b)
-    {
-      const uint64_t m = (a + b) >> 1;
-      if (r.samp[m] < want) a = m + 1; else b = m;
-    }
+    const unsigned long long *__restrict__ samp = r.samp;
+    const uint64_t a = wave_lower(0, r.n_samp, [&](uint64_t m) { return samp[m] < want; });
     lo = a ? ((a - 1) << REC_SAMPLE_SHIFT) + 1 : 0;  // record (a-1)<<shift is < target, record a<<shift is >= target
     hi = a < r.n_samp ? (a << REC_SAMPLE_SHIFT) : r.n;
   }
   const uint32_t Tu = (uint32_t) T;
-  while (lo < hi)
-  {
-    uint64_t m = (lo + hi) >> 1;
-    uint32_t t = (uint32_t) r.tid[m];
-    bool lt = t != Tu ? (t < Tu) : ((long long) r.pos[m] < P);
-    if (lt) lo = m + 1; else hi = m;
-  }
-  return lo;
+  return wave_lower(lo, hi, [&](uint64_t m) {
+    const uint32_t t = (uint32_t) r.tid[m];
+    return t != Tu ? (t < Tu) : ((long long) r.pos[m] < P);
+  });
 }
 __global__ __launch_bounds__(256) void k_rec_sample(const int32_t *__restrict__ tid, const int32_t *__restrict__ pos, uint64_t n_samp, unsigned long long *__restrict__ samp)
 {
@@ -249,16 +261,11 @@ __device__ __forceinline__ bool in_region(const Region &rg, int32_t tid, int32_t
 __device__ uint64_t split_lower_pos(const bk_split *__restrict__ sp, uint64_t ns, int32_t T, long long P)
 {
   // tuples are ordered by record index = coordinate order: first tuple with (tid,pos) >= (T,P)
-  uint64_t lo = 0, hi = ns;
   const uint32_t Tu = (uint32_t) T;
-  while (lo < hi)
-  {
-    uint64_t m = (lo + hi) >> 1;
-    uint32_t t = (uint32_t) sp[m].tid;
-    bool lt = t != Tu ? (t < Tu) : ((long long) sp[m].pos < P);
-    if (lt) lo = m + 1; else hi = m;
-  }
-  return lo;
+  return wave_lower(0, ns, [&](uint64_t m) {
+    const uint32_t t = (uint32_t) sp[m].tid;
+    return t != Tu ? (t < Tu) : ((long long) sp[m].pos < P);
+  });
 }
 
 // number of records of THIS record table (one shard or the whole file) that overlap the region, counted up to
