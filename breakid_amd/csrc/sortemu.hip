@@ -865,7 +865,9 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
 //     compared with 0, the hole of a lane that stopped); after the step ONE vector compare against the new holes and a
 //     branch are left - a scalar instruction that combines masks a vector compare has just written waits ~20 clocks for
 //     them (tools/ubench/issue.hip);
-//   * the launching lane is a rotating one-hot mask in SGPRs; launches are counted by L itself.
+//   * the launching lane is a rotating one-hot mask in SGPRs; the launches left are counted in the launch path (s46: its
+//     borrow ends the launches), so an iteration that may launch does not test for the end; after the last launch a plain
+//     loop of steps drains the pops in flight.
 // 20 instructions in the iteration after a launch, 36 in a launching one (was 21 and 42, with two exposed LDS round trips).
 // Per-lane: hole v40 (0 = idle), value v42 (-1 = idle).  Uniform: L s43, clz(L) + 1 s47, budget s45, clamp address s42,
 // launch mask s[58:59].
@@ -889,6 +891,7 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
   "s_sub_u32 s40, %[base], 4\n"                                                                                            \
   "v_mov_b32 v60, %[base]\n"                                                                                               \
   "s_mov_b32 s43, %[m]\n"                                                                                                  \
+  "s_sub_u32 s46, s43, 2\n"                                                                                               \
   "s_flbit_i32_b32 s47, s43\n s_add_u32 s47, s47, 1\n"                                                                     \
   "s_lshl_b32 s48, s43, 2\n s_add_u32 s42, s48, %[base]\n"                                                                 \
   "s_add_u32 s48, s48, s40\n v_mov_b32 v61, s48\n"                                                                         \
@@ -925,8 +928,6 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
   BK_HEAP32Q_STEP                                                                                                         \
   "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
   BK_HEAP32Q_NEXT                                                                                                         \
-  "s_cmp_lt_u32 s43, 2\n"                                                                                                  \
-  "s_cbranch_scc1 BK_QNOMORE_%=\n"                                                                                         \
   "s_cbranch_vccnz BK_QBNEXT_%=\n"                                                                                         \
   "s_waitcnt lgkmcnt(2)\n"                                                                                                 \
   "s_mov_b64 exec, s[58:59]\n"                                                                                             \
@@ -936,15 +937,22 @@ __device__ __forceinline__ void sort_heap_lds_zero(uint32_t *slot1, const uint32
   "v_mov_b32 v40, 1\n"                                                                                                     \
   "ds_read2_b32 v[46:47], v60 offset0:1 offset1:2\n"                                                                       \
   "s_mov_b64 exec, s[56:57]\n"                                                                                                   \
-  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_sub_u32 s46, s46, 1\n"                                                                                               \
   "s_cbranch_scc0 BK_QA_%=\n"                                                                                              \
-  "s_branch BK_QDONE_%=\n"                                                                                                 \
-  "BK_QNOMORE_%=:\n"                                                                                                      \
-  "v_cmp_ne_u32 vcc, 0, v40\n"                                                                                             \
-  "s_cbranch_vccz BK_QDONE_%=\n"                                                                                           \
+  "s_branch BK_QDRAIN_%=\n"                                                                                                 \
   "BK_QBNEXT_%=:\n"                                                                                                       \
-  "s_sub_u32 s45, s45, 1\n"                                                                                                \
-  "s_cbranch_scc0 BK_QB_%=\n"                                                                                              \
+  "s_sub_u32 s45, s45, 1\n"                                                                                               \
+  "s_cbranch_scc0 BK_QB_%=\n"                                                                                             \
+  "s_branch BK_QDONE_%=\n"                                                                                                \
+  "BK_QDRAIN_%=:\n"                                                                                                       \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                     \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                \
+  BK_HEAP32Q_STEP                                                                                                         \
+  BK_HEAP32Q_NEXT                                                                                                         \
+  "v_cmp_ne_u32 vcc, 0, v40\n"                                                                                            \
+  "s_cbranch_vccz BK_QDONE_%=\n"                                                                                          \
+  "s_sub_u32 s45, s45, 1\n"                                                                                               \
+  "s_cbranch_scc0 BK_QDRAIN_%=\n"                                                                                         \
   "BK_QDONE_%=:\n"                                                                                                        \
   "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
   "s_setprio 0\n"                                                                                                          \

@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for cfg in "2 1 16" "2 0 16" "3 0 16" "4 0 16" "5 0 16" "6 0 16" "8 0 24" "4 1 16"; do
+for cfg in "2 0 16" "3 0 16" "4 0 16" "3 1 16"; do
   set -- $cfg
   GPU_MAX_HW_QUEUES=$3 BREAKID_GROUP_LANES=$1 BREAKID_LANE_ADAPT=$2 timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/lanesA_$1_$2.json 2> gpurun_out/lanesA_$1_$2.err
   python - <<PY
