@@ -627,7 +627,7 @@ static int lanes_wanted()
 static bool lanes_apply(const bk_ctx *ctx, int fast)
 {
   static const uint64_t min_pairs = getenv("BREAKID_LANES_MIN_PAIRS") ? strtoull(getenv("BREAKID_LANES_MIN_PAIRS"), nullptr, 10) : (1ull << 20);  // below: launch-bound anyway
-  return lanes_wanted() >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->own_groups.empty() && ctx->jr.n_pairs >= min_pairs;
+  return lanes_wanted() >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->jr.n_pairs >= min_pairs;
 }
 
 // K lanes of groups.  A lane's time is (a) per sort the LONGEST heapsort segment of any of its groups - a serial chain of one wave
@@ -660,9 +660,17 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
   LanePlan p;
   p.lane_of.assign(ng, 0);
   std::vector<double> load(K, 0.0);
+  // sharded sample: this rank only masks and clusters the groups it owns (bk_shard_own_groups); the others belong to no lane
+  const bool owned_only = !ctx->own_groups.empty();
+  if (owned_only && ctx->own_groups.size() != ng) throw bk_error(BK_ERR_ARG, "bk_shard_own_groups: group count changed");
   for (uint32_t i = 0; i < ng; ++i)
   {
     const uint32_t g = order[i];
+    if (owned_only && !ctx->own_groups[g])
+    {
+      p.lane_of[g] = -1;
+      continue;
+    }
     int l;
     if ((int) i < solo)
       l = (int) i;

@@ -45,6 +45,15 @@ def test_two_rank_sharded_sample_matches_oracle(mode, exchange):
     assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
 
+def test_two_rank_sharded_sample_with_lanes_of_groups_inside_every_rank():
+    """BREAKID_GROUP_LANES=2 on a sharded sample: every rank deals the groups it OWNS to two lanes (the others belong to no lane)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", BREAKID_GROUP_LANES="2", BREAKID_LANES_MIN_PAIRS="1000", GPU_MAX_HW_QUEUES="16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "shard_worker.py"), "600000", "79", "fast", "routed"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("exchange", ["routed", "replicated"])
 def test_rccl_backend_world_size_1(exchange):
     """backend "nccl" (= RCCL) at world size 1: the device-tensor branch of the exchange layer - collectives on device buffers
