@@ -603,9 +603,10 @@ int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, 
 // command line set it together with GPU_MAX_HW_QUEUES before the runtime starts).  Results are identical by construction:
 // the groups never interact, the lanes' lists are merged back into group order.
 static void run_lane(const bk_pair *pairs, const uint32_t *gof, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, int fast, const uint32_t *drop, PairList &L, PairList &iso,
-                     DevBuf &d_cluster, ClusterBufs &cb, AhcBufs &ab, hipStream_t st)
+                     DevBuf &d_cluster, ClusterBufs &cb, AhcBufs &ab, hipStream_t st, const uint64_t *gstart_host, const uint8_t *keep_host)
 {
-  remove_isolated_all(pairs, gof, gstart, ng, n, w, L, cb, st, drop);
+  remove_isolated_begin(pairs, gof, gstart, ng, n, w, L, cb, st, drop, gstart_host, keep_host);
+  remove_isolated_end(pairs, L, cb, st);
   iso.n = L.n;
   iso.ng = L.ng;
   uint32_t *ii = iso.idx.as<uint32_t>(L.n + 1), *ig = iso.gof.as<uint32_t>(L.n + 1);
@@ -749,7 +750,10 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   auto lane_iso = [&](int l) -> PairList & { return l == 0 ? ctx->isoA : ctx->lanes[l - 1]->iso; };
   auto lane_cl = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_clusterA : ctx->lanes[l - 1]->d_cluster; };
   auto lane_drop = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_dropA : ctx->lanes[l - 1]->d_drop; };
+  std::vector<std::vector<uint8_t>> keep(K, std::vector<uint8_t>(ng, 0));  // keep[l][g]: lane l owns group g (host copy of the plan)
   auto upload_plan = [&](const LanePlan &p) {
+    for (int l = 0; l < K; ++l)
+      for (uint32_t g = 0; g < ng; ++g) keep[l][g] = p.lane_of[g] == l ? 1 : 0;
     std::vector<uint32_t> drop(ng);
     for (int l = 0; l < K; ++l)
     {
@@ -804,7 +808,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   upload_plan(plan_blind(ctx, K));
   if (!adapt)
   {
-    in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l).get<uint32_t>(), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l)); });
+    in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l).get<uint32_t>(), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l), ctx->gstart_host.data(), keep[l].data()); });
   }
   else
   {
@@ -814,7 +818,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       cb.heavy_x.assign(ng, 0u);
       cb.heavy_y.assign(ng, 0u);
       cb.observe = true;
-      remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>());
+      remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>(), ctx->gstart_host.data(), keep[l].data());
       cb.observe = false;
     });
     PairList mid, acc[2];

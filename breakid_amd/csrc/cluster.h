@@ -31,8 +31,9 @@ struct ClusterBufs
 void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
                          const uint32_t *drop_group = nullptr);  // drop_group[g] != 0: group g is left to another rank
 // the same in two parts, so that a caller may redistribute the groups between them: through the second mask / the third sort
+// (gstart_host + keep_host given: the list is built straight from the ranges of the kept groups instead of filtering all n pairs)
 void remove_isolated_begin(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
-                           const uint32_t *drop_group = nullptr);
+                           const uint32_t *drop_group = nullptr, const uint64_t *gstart_host = nullptr, const uint8_t *keep_host = nullptr);
 void remove_isolated_end(const bk_pair *pairs, PairList &L, ClusterBufs &b, hipStream_t st);
 // dst = src without the groups flagged in drop[] (device, one u32 per group; offsets for all groups are kept)
 void list_subset(const PairList &src, const uint32_t *drop, PairList &dst, ClusterBufs &b, hipStream_t st);

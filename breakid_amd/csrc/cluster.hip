@@ -354,7 +354,7 @@ static void mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs 
 void remove_isolated_all(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
                          const uint32_t *drop_group)
 {
-  remove_isolated_begin(pairs, gof0, gstart, ng, n, w, L, b, st, drop_group);
+  remove_isolated_begin(pairs, gof0, gstart, ng, n, w, L, b, st, drop_group, nullptr, nullptr);
   remove_isolated_end(pairs, L, b, st);
 }
 
@@ -379,19 +379,68 @@ void list_subset(const PairList &src, const uint32_t *drop, PairList &dst, Clust
   filter_groups(dst, drop, b, st);
 }
 
-void remove_isolated_begin(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
-                           const uint32_t *drop_group)
+// list of the pairs of the groups with keep[g] != 0, straight from the group ranges of the pair table (the pairs of a group are
+// contiguous there): what iota + copy + filter_groups over all n pairs would leave, in one launch over the list itself
+namespace
 {
-  L.n = n;
+__global__ __launch_bounds__(256) void k_subset_list(const uint64_t *__restrict__ gstart, const uint64_t *__restrict__ goff, uint32_t ng, uint64_t n_list,
+                                                     uint32_t *__restrict__ idx, uint32_t *__restrict__ gof)
+{
+  const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_list) return;
+  uint32_t lo = 0, hi = ng;  // largest g with goff[g] <= p (a group that is empty in the list never wins: the next one starts at the same offset)
+  while (hi - lo > 1)
+  {
+    const uint32_t m = (lo + hi) >> 1;
+    if (goff[m] <= p) lo = m; else hi = m;
+  }
+  idx[p] = (uint32_t) (gstart[lo] + (p - goff[lo]));
+  gof[p] = lo;
+}
+}  // namespace
+void list_of_groups(const uint64_t *gstart_dev, const uint64_t *gstart_host, const uint8_t *keep_host, uint32_t ng, PairList &L, hipStream_t st)
+{
+  std::vector<uint64_t> goff((size_t) ng + 1, 0);
+  for (uint32_t g = 0; g < ng; ++g) goff[g + 1] = goff[g] + (keep_host[g] ? gstart_host[g + 1] - gstart_host[g] : 0);
+  L.n = goff[ng];
   L.ng = ng;
-  uint32_t *idx = L.idx.as<uint32_t>(n + 1);
-  uint32_t *gof = L.gof.as<uint32_t>(n + 1);
-  uint64_t *goff = L.goff.as<uint64_t>((uint64_t) ng + 1);
-  if (n == 0 || ng == 0) return;
-  hipLaunchKernelGGL(k_iota, dim3(nb(n)), dim3(256), 0, st, idx, n);
-  HIP_CHECK(hipMemcpyAsync(gof, gof0, n * 4, hipMemcpyDeviceToDevice, st));
-  HIP_CHECK(hipMemcpyAsync(goff, gstart, ((uint64_t) ng + 1) * 8, hipMemcpyDeviceToDevice, st));
-  if (drop_group) filter_groups(L, drop_group, b, st);
+  uint32_t *idx = L.idx.as<uint32_t>(L.n + 1), *gof = L.gof.as<uint32_t>(L.n + 1);
+  uint64_t *dgoff = L.goff.as<uint64_t>((uint64_t) ng + 1);
+  HIP_CHECK(hipMemcpyAsync(dgoff, goff.data(), ((size_t) ng + 1) * 8, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));  // (goff is a local)
+  if (L.n) hipLaunchKernelGGL(k_subset_list, dim3(nb(L.n)), dim3(256), 0, st, gstart_dev, dgoff, ng, L.n, idx, gof);
+}
+
+void remove_isolated_begin(const bk_pair *pairs, const uint32_t *gof0, const uint64_t *gstart, uint32_t ng, uint64_t n, double w, PairList &L, ClusterBufs &b, hipStream_t st,
+                           const uint32_t *drop_group, const uint64_t *gstart_host, const uint8_t *keep_host)
+{
+  if (gstart_host && keep_host)
+  {
+    if (n == 0 || ng == 0)
+    {
+      L.n = 0;
+      L.ng = ng;
+      (void) L.idx.as<uint32_t>(1);
+      (void) L.gof.as<uint32_t>(1);
+      (void) L.goff.as<uint64_t>((uint64_t) ng + 1);
+      return;
+    }
+    list_of_groups(gstart, gstart_host, keep_host, ng, L, st);
+  }
+  else
+  {
+    L.n = n;
+    L.ng = ng;
+    uint32_t *idx = L.idx.as<uint32_t>(n + 1);
+    uint32_t *gof = L.gof.as<uint32_t>(n + 1);
+    uint64_t *goff = L.goff.as<uint64_t>((uint64_t) ng + 1);
+    if (n == 0 || ng == 0) return;
+    hipLaunchKernelGGL(k_iota, dim3(nb(n)), dim3(256), 0, st, idx, n);
+    HIP_CHECK(hipMemcpyAsync(gof, gof0, n * 4, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(goff, gstart, ((uint64_t) ng + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (drop_group) filter_groups(L, drop_group, b, st);
+  }
+  if (L.n == 0) return;
   const long dist = (long) w;  // remove_isolated_pairs passes double w to a `long distance` parameter
   sort_list(pairs, L, 0, nullptr, 0, b, st);
   mask_list(pairs, L, dist, b, st);
