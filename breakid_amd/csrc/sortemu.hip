@@ -258,7 +258,6 @@ template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint3
 }
 
 constexpr uint32_t HEAP_PAD = 32;
-__device__ int g_heap_no_pipe = 0;  // BK_HEAP_NO_PIPE=1: the unpipelined LDS pop loop (debugging / comparison)
 __device__ unsigned long long g_heap_iters[2];
 __device__ unsigned long long g_heap_phase[8];  // debug: 10 ns ticks of the phases of the largest ranked heap (BK_DEBUG_SORT)  // debug: loop iterations / pops of sort_heap (BK_DEBUG_SORT)
 
@@ -612,99 +611,7 @@ template <bool GLB> __device__ __forceinline__ void sort_heap_asm(hent *buf, con
   WAIT_ALL                                                                                                                \
   "s_mov_b32 %[left], s45\n"
 
-// ---- the LDS / 4-byte variant again, software pipelined: the children of the NEXT step's hole are requested right after
-// this step's hole is known (behind this step's store in program order, so they see it), and their LDS latency passes
-// under the launch logic instead of in front of the next compare.  A launching lane computes its own child masks and
-// requests the root's children inside the launch block.  (sort_heap_asm32<false, true>, used for heaps that fit LDS from
-// the start; BK_HEAP_NO_PIPE=1 takes the loop above.)
-#define BK_HEAP32P_HEAD                                                                                                   \
-  "v_lshlrev_b32 v44, 1, v40\n"                                                                                            \
-  "v_cmp_le_u32_e64 s[48:49], v44, v41\n"                                                                                  \
-  "v_cmp_lt_u32_e64 s[50:51], v44, v41\n"                                                                                  \
-  "v_lshl_add_u32 v45, v44, 2, s40\n"                                                                                      \
-  "v_cndmask_b32_e64 v45, v60, v45, s[48:49]\n"                                                                            \
-  "ds_read2_b32 v[46:47], v45 offset1:1\n"
-#define BK_HEAP32P_BODY                                                                                                   \
-  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
-  "v_mov_b32 v54, v40\n"                                                                                                   \
-  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
-  "v_lshrrev_b32 v48, 16, v46\n"                                                                                           \
-  "v_lshrrev_b32 v49, 16, v47\n"                                                                                           \
-  "v_cmp_ge_u32_e32 vcc, v49, v48\n"                                                                                       \
-  "s_and_b64 s[52:53], vcc, s[50:51]\n"                                                                                    \
-  "v_cndmask_b32_e64 v50, v46, v47, s[52:53]\n"                                                                            \
-  "v_cndmask_b32_e64 v51, v48, v49, s[52:53]\n"                                                                            \
-  "v_cmp_ge_u32_e32 vcc, v51, v43\n"                                                                                       \
-  "s_and_b64 s[54:55], vcc, s[48:49]\n"                                                                                    \
-  "v_cndmask_b32_e64 v50, v42, v50, s[54:55]\n"                                                                            \
-  "ds_write_b32 v52, v50\n"                                                                                                \
-  "v_addc_co_u32_e64 v53, vcc, v44, 0, s[52:53]\n"                                                                         \
-  "v_cndmask_b32_e64 v40, v55, v53, s[54:55]\n"
-#define BK_HEAP32P_ASM                                                                                                    \
-  "v_mov_b32 v62, %[lane]\n"                                                                                               \
-  "s_sub_u32 s40, %[base], 4\n"                                                                                            \
-  "v_mov_b32 v60, %[base]\n"                                                                                               \
-  "s_mov_b32 s46, %[tend]\n s_mov_b32 s41, 1\n s_mov_b32 s43, %[m]\n"                                                       \
-  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
-  "s_lshl_b32 s47, s43, 2\n s_add_u32 s47, s47, s40\n v_mov_b32 v61, s47\n"                                                  \
-  "s_mov_b32 s45, %[budget]\n"                                                                                             \
-  "s_add_u32 s47, %[m], 2\n v_mov_b32 v55, s47\n v_mov_b32 v40, v55\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"                                               \
-  BK_HEAP32P_HEAD                                                                                                         \
-  "s_branch BK_PB_%=\n"                                                                                                    \
-  "BK_PA_%=:\n"                                                                                                           \
-  BK_HEAP32P_BODY                                                                                                         \
-  BK_HEAP32P_HEAD                                                                                                         \
-  "s_sub_u32 s45, s45, 1\n"                                                                                                \
-  "s_cbranch_scc1 BK_PDONE_%=\n"                                                                                           \
-  "BK_PB_%=:\n"                                                                                                           \
-  "ds_read_b32 v56, v60\n"                                                                                                 \
-  "ds_read_b32 v58, v61\n"                                                                                                 \
-  BK_HEAP32P_BODY                                                                                                         \
-  BK_HEAP32P_HEAD                                                                                                         \
-  "s_cmp_ge_u32 s41, s46\n"                                                                                                \
-  "s_cbranch_scc1 BK_PNOMORE_%=\n"                                                                                         \
-  "v_ffbh_u32_e32 v63, v40\n"                                                                                              \
-  "v_subrev_u32_e32 v63, s44, v63\n"                                                                                       \
-  "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
-  "v_cmp_eq_u32_e32 vcc, v64, v40\n"                                                                                       \
-  "v_cmp_gt_u32_e64 s[60:61], 32, v63\n"                                                                                   \
-  "s_and_b64 vcc, vcc, s[60:61]\n"                                                                                         \
-  "v_cmp_eq_u32_e64 s[60:61], s43, v54\n"                                                                                  \
-  "s_or_b64 vcc, vcc, s[60:61]\n"                                                                                          \
-  "s_cbranch_vccnz BK_PBNEXT_%=\n"                                                                                         \
-  "s_and_b32 s47, s41, 63\n"                                                                                               \
-  "v_cmp_eq_u32_e32 vcc, s47, v62\n"                                                                                       \
-  "s_sub_u32 s47, s43, 1\n"                                                                                                \
-  "s_and_saveexec_b64 s[56:57], vcc\n"                                                                                     \
-  "ds_write_b32 v61, v56\n"                                                                                                \
-  "v_mov_b32 v42, v58\n v_lshrrev_b32 v43, 16, v58\n v_mov_b32 v40, 1\n v_mov_b32 v41, s47\n"                                 \
-  "v_mov_b32 v44, 2\n"                                                                                                     \
-  "v_cmp_le_u32_e64 s[58:59], v44, v41\n"                                                                                  \
-  "v_cmp_lt_u32_e64 s[60:61], v44, v41\n"                                                                                  \
-  "v_add_u32_e32 v45, 4, v60\n"                                                                                            \
-  "v_cndmask_b32_e64 v45, v60, v45, s[58:59]\n"                                                                            \
-  "ds_read2_b32 v[46:47], v45 offset1:1\n"                                                                                 \
-  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
-  "s_andn2_b64 s[48:49], s[48:49], vcc\n s_or_b64 s[48:49], s[48:49], s[58:59]\n"                                            \
-  "s_andn2_b64 s[50:51], s[50:51], vcc\n s_or_b64 s[50:51], s[50:51], s[60:61]\n"                                            \
-  "s_add_u32 s41, s41, 1\n"                                                                                                \
-  "s_mov_b32 s43, s47\n"                                                                                                   \
-  "s_flbit_i32_b32 s44, s43\n"                                                                                             \
-  "v_add_u32_e32 v61, -4, v61\n"                                                                                           \
-  "s_sub_u32 s45, s45, 1\n"                                                                                                \
-  "s_cbranch_scc0 BK_PA_%=\n"                                                                                              \
-  "s_branch BK_PDONE_%=\n"                                                                                                 \
-  "BK_PNOMORE_%=:\n"                                                                                                      \
-  "v_cmp_ne_u32_e32 vcc, v40, v55\n"                                                                                       \
-  "s_cbranch_vccz BK_PDONE_%=\n"                                                                                           \
-  "BK_PBNEXT_%=:\n"                                                                                                       \
-  "s_sub_u32 s45, s45, 1\n"                                                                                                \
-  "s_cbranch_scc0 BK_PB_%=\n"                                                                                              \
-  "BK_PDONE_%=:\n"                                                                                                        \
-  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
-  "s_mov_b32 %[left], s45\n"
-
-template <bool GLB, bool PIPE = false> __device__ __forceinline__ void sort_heap_asm32(uint32_t *buf, const uint32_t m, const uint32_t stop)
+template <bool GLB> __device__ __forceinline__ void sort_heap_asm32(uint32_t *buf, const uint32_t m, const uint32_t stop)
 {
   if (m < 2 || m <= stop) return;
   const uint32_t lane = threadIdx.x & 63;
@@ -721,11 +628,6 @@ template <bool GLB, bool PIPE = false> __device__ __forceinline__ void sort_heap
                                "global_store_dword v61, v56, s[62:63]\n", "s_waitcnt vmcnt(0)\n", "", BK_IDLE_BY_LEN, BK_CHECK_ACTIVE_LEN, BK_ANY_ACTIVE_LEN)
                  : [left] "=s"(left)
                  : [lane] "v"(lane), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
-                 : BK_HEAP_CLOBBERS);
-  else if (PIPE && g_heap_no_pipe == 0)
-    asm volatile(BK_HEAP32P_ASM
-                 : [left] "=s"(left)
-                 : [lane] "v"(lane), [base] "s"(base), [tend] "s"(t_end), [m] "s"(mm), [budget] "s"(budget)
                  : BK_HEAP_CLOBBERS);
   else
     asm volatile(BK_HEAP32_ASM("ds_read_b32 v56, v60\n", "ds_read_b32 v58, v61\n", "ds_read2_b32 v[46:47], v45 offset1:1\n",
@@ -1982,8 +1884,6 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   static bool pipe_flag_set = false;
   if (!pipe_flag_set)
   {
-    const int v = getenv("BK_HEAP_NO_PIPE") != nullptr;
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_pipe), &v, sizeof v));
     const int nq = getenv("BK_HEAP_NO_Q") != nullptr;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_q), &nq, sizeof nq));
     pipe_flag_set = true;
