@@ -370,3 +370,47 @@ print("LANES_OK", nv)
     env = dict(os.environ, BREAKID_GROUP_LANES=str(lanes), BREAKID_LANE_SOLO=str(solo), BREAKID_LANE_ADAPT=str(adapt), GPU_MAX_HW_QUEUES="16", BREAKID_LANES_MIN_PAIRS="1000")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LANES_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("switch", ["BK_SORT_OLD_LEVELS", "BK_SORT_NO_BATCH", "BK_HEAP_NO_Q", "BK_HEAP_CXX", "BK_HEAP_NO_RANKED", "BK_FAST_JUMP_GLOBAL", "BK_JOIN_FULL_SORT"])
+def test_earlier_statements_of_the_same_computation_still_agree(switch):
+    """the library keeps the earlier forms of the partition level, the pop loop, the anchored windows and the candidate sort
+    behind environment switches (comparison / debugging): each must give the reference's order and the oracle's stages.
+    Own process: the switches are read once."""
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from breakid_amd import abi, capi, synth_gpu
+from oracle import pyoracle
+n = 60_000
+k = n // 2
+i = np.arange(k)
+a = np.zeros(n, np.int64)
+a[:k] = np.where(i %% 2 == 0, i + 1, k + i + (1 if k %% 2 == 0 else 0))
+a[k:2 * k] = 2 * (i + 1)
+key = (np.concatenate([[0], a]) // 3).astype(np.uint32)          # median-of-3 killer with ties: one segment through the heapsort branch
+off = np.array([0, len(key)], np.uint64)
+ctx = capi.Context([("chr1", 1000)])
+assert np.array_equal(ctx.debug_std_sort(key, off), pyoracle.unit_std_sort(key, off))
+ctx.close()
+dev = torch.device("cuda", 0)
+contigs, cols = synth_gpu.make_wgs(1_500_000, 99, dev, disc_frac=0.3)
+ctx = capi.Context(contigs)
+ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+w, nv = ctx.run(qual=20, fast=True)
+o = pyoracle.Oracle(contigs, synth_gpu.to_numpy_cols(cols))
+ow, rc = o.run(20, fast=True)
+assert rc == 0 and w == ow
+for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_CLUSTERS):
+    x, _ = ctx.fetch(st)
+    y, _ = o.fetch(st)
+    assert np.array_equal(x, y), st
+print("SWITCH_OK", nv)
+""" % ROOT_DIR
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SWITCH_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
