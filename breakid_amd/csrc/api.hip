@@ -5,6 +5,7 @@
 #include <memory>
 #include <numeric>
 #include <thread>
+#include <chrono>
 
 #include "bk_common.h"
 #include "prims.h"
@@ -113,6 +114,8 @@ struct bk_ctx
   };
   std::vector<std::unique_ptr<Lane>> lanes;  // lanes 1 .. K-1 (lane 0 uses the context's own stream and buffers)
   PairList listA, isoA;  // first lane's lists before the merge
+  PairList lane_mid, lane_iso_m, lane_acc[4];  // kept between calls: a list that is a local is allocated and freed (a device-wide wait) in every call
+  DevBuf lane_cacc[4];
   DevBuf d_clusterA, d_dropA;
   uint64_t iso_n = 0;
   bool clustered = false;
@@ -637,12 +640,14 @@ static bool lanes_apply(const bk_ctx *ctx, int fast)
 // large; two or three of them carry segments of 30-46 K elements, most carry a few thousand), but it can be OBSERVED: a group
 // whose sort by x (by y) ran into the depth limit does so again in the next sort by the same coordinate.  So the stage runs in
 // two parts:
-//   part 1  sorts 1-2 (x, mask, y, mask) in K lanes split blindly (longest-processing-time on size^e); every lane records
-//           the longest heap segment of each of its groups per coordinate;
-//   part 2  sorts 3-5 (x | x-windows, y, y-windows, x) in K lanes split on what was observed: the groups are placed, heaviest
-//           chain first, where the lane's sum over the three sorts of its longest segment (+ a term for its pair count) grows least.
-// Off by default (BREAKID_LANE_ADAPT=1 turns it on): on the 30x WGS shape the sorts by x of the unmasked list (sort 1) say little
-// about the later sorts by x, so only the y-heavy groups are placed well and the barrier between the parts costs what that gains.  Results are identical whatever the split: the groups never
+//   part 1  sorts 1-3 (x, mask, y, mask, x: remove_isolated_pairs) in K lanes split blindly (longest-processing-time on size^e);
+//           every lane records the longest heap segment of each of its groups in the sort by y and in the LAST sort by x;
+//   part 2  sorts 4-5 (x-windows, y, y-windows, x) in K lanes split on what was observed: the groups are placed, heaviest
+//           chain first, where the lane's longest segment by y + longest segment by x (+ a term for its pair count) grows least.
+// BREAKID_LANE_ADAPT=0 keeps the blind split for the whole stage.  On the 30x WGS shape part 2 comes out balanced (18.9 / 21.4 ms
+// with two lanes) where the blind split leaves one lane 9 ms behind the other (46.6 / 37 ms); part 1 stays as the blind split
+// leaves it (24.1 / 21.3 ms); the barrier and the re-split cost ~1 ms.
+// Results are identical whatever the split: the groups never
 // interact, a lane's list keeps every group's order, and the lists are merged back into group order.
 struct LanePlan
 {
@@ -690,11 +695,14 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
 static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vector<uint32_t> &hx, const std::vector<uint32_t> &hy, int K)
 {
   const uint32_t ng = (uint32_t) sizes.size();
-  // one pop of a lone wave ~ 0.17 us; one pair costs a lane ~ 0.4 ns per sort in the bandwidth-bound levels and masks
-  static const double per_pair = getenv("BREAKID_LANE_PAIR_COST") ? atof(getenv("BREAKID_LANE_PAIR_COST")) : 0.008;
+  // in units of one pop of a lone wave in LDS (~0.15 us): a pair costs a lane ~0.15 ns in the two sorts that are left (most of a
+  // lane's time outside the heaps is a fixed number of launches), an element of a heap segment beyond what fits the LDS of a
+  // CU is popped in global memory at four times the price
+  static const double per_pair = getenv("BREAKID_LANE_PAIR_COST") ? atof(getenv("BREAKID_LANE_PAIR_COST")) : 0.001;
+  auto heap_cost = [](uint32_t m) { return (double) m + (m > 40947u ? 3.0 * (double) (m - 40947u) : 0.0); };
   std::vector<uint32_t> order(ng);
   std::iota(order.begin(), order.end(), 0u);
-  auto chain = [&](uint32_t g) { return 2.0 * hx[g] + hy[g]; };
+  auto chain = [&](uint32_t g) { return heap_cost(hx[g]) + heap_cost(hy[g]); };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
     const double ca = chain(a), cb = chain(b);
     return ca != cb ? ca > cb : sizes[a] > sizes[b];
@@ -702,14 +710,14 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
   LanePlan p;
   p.lane_of.assign(ng, 0);
   std::vector<double> mx(K, 0.0), my(K, 0.0), pairs(K, 0.0);
-  auto cost = [&](int l) { return 2.0 * mx[l] + my[l] + per_pair * pairs[l]; };
+  auto cost = [&](int l) { return mx[l] + my[l] + per_pair * pairs[l]; };
   for (uint32_t g : order)
   {
     int best = 0;
     double best_cost = 0;
     for (int l = 0; l < K; ++l)
     {
-      const double c = 2.0 * std::max(mx[l], (double) hx[g]) + std::max(my[l], (double) hy[g]) + per_pair * (pairs[l] + (double) sizes[g]);
+      const double c = std::max(mx[l], heap_cost(hx[g])) + std::max(my[l], heap_cost(hy[g])) + per_pair * (pairs[l] + (double) sizes[g]);
       // the lane whose own cost ends lowest takes the group (ties: the emptier lane)
       if (l == 0 || c < best_cost || (c == best_cost && cost(l) < cost(best)))
       {
@@ -717,8 +725,8 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
         best_cost = c;
       }
     }
-    mx[best] = std::max(mx[best], (double) hx[g]);
-    my[best] = std::max(my[best], (double) hy[g]);
+    mx[best] = std::max(mx[best], heap_cost(hx[g]));
+    my[best] = std::max(my[best], heap_cost(hy[g]));
     pairs[best] += (double) sizes[g];
     p.lane_of[g] = best;
   }
@@ -737,7 +745,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
 {
   const uint32_t ng = ctx->jr.n_groups;
   const int K = lanes_wanted();
-  static const bool adapt = getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) != 0;
+  static const bool adapt = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
   while ((int) ctx->lanes.size() < K - 1)
   {
     ctx->lanes.emplace_back(new bk_ctx::Lane());
@@ -767,11 +775,15 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   auto in_lanes = [&](auto body) {
     std::vector<std::string> err(K);
     std::vector<int> code(K, BK_OK);
+    static const bool dbg_lanes = getenv("BK_DEBUG_LANES") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
     auto guarded_body = [&](int l) {
       try
       {
         body(l);
         HIP_CHECK(hipStreamSynchronize(lane_st(l)));
+        if (dbg_lanes)
+          fprintf(stderr, "[lanes] lane %d done after %.2f ms\n", l, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
       }
       catch (const bk_error &e)
       {
@@ -791,7 +803,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       if (code[l] != BK_OK) throw bk_error(code[l], err[l]);
   };
   // folds the lanes' lists (disjoint groups) into one list in group order; cl = the cluster numbers travel along
-  auto merge_all = [&](auto list_of, auto cl_of, PairList &out, DevBuf *cl_out, PairList (&acc)[2], DevBuf (&cacc)[2]) {
+  auto merge_all = [&](auto list_of, auto cl_of, PairList &out, DevBuf *cl_out, PairList *acc, DevBuf *cacc) {
     const PairList *cur = &list_of(0);
     const uint32_t *ccur = cl_of(0);
     for (int l = 1; l < K; ++l)
@@ -819,10 +831,13 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       cb.heavy_y.assign(ng, 0u);
       cb.observe = true;
       remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>(), ctx->gstart_host.data(), keep[l].data());
+      cb.heavy_x.assign(ng, 0u);  // the third sort (by x, on the masked list) is the one that tells about the fifth
+      remove_isolated_end(pairs, lane_list(l), cb, lane_st(l));
       cb.observe = false;
     });
-    PairList mid, acc[2];
-    DevBuf cacc[2];
+    PairList &mid = ctx->lane_mid;
+    PairList *acc = ctx->lane_acc;
+    DevBuf *cacc = ctx->lane_cacc;
     merge_all([&](int l) -> const PairList & { return lane_list(l); }, [&](int) -> const uint32_t * { return nullptr; }, mid, nullptr, acc, cacc);
     std::vector<uint64_t> goff_h((size_t) ng + 1);
     HIP_CHECK(hipMemcpyAsync(goff_h.data(), mid.goff.get<uint64_t>(), ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost, ctx->st));
@@ -841,8 +856,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
     in_lanes([&](int l) {
       PairList &L = lane_list(l), &iso = lane_iso(l);
       hipStream_t st = lane_st(l);
-      list_subset(mid, lane_drop(l).get<uint32_t>(), L, lane_cb(l), st);
-      remove_isolated_end(pairs, L, lane_cb(l), st);
+      list_subset_ranges(mid, goff_h.data(), keep[l].data(), L, st);
       iso.n = L.n;
       iso.ng = L.ng;
       uint32_t *ii = iso.idx.as<uint32_t>(L.n + 1), *ig = iso.gof.as<uint32_t>(L.n + 1);
@@ -857,8 +871,9 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
     });
   }
   // one list in group order again
-  PairList iso_m, iacc[2], lacc[2];
-  DevBuf icacc[2], lcacc[2];
+  PairList &iso_m = ctx->lane_iso_m;
+  PairList *iacc = ctx->lane_acc, *lacc = ctx->lane_acc + 2;
+  DevBuf *icacc = ctx->lane_cacc, *lcacc = ctx->lane_cacc + 2;
   merge_all([&](int l) -> const PairList & { return lane_iso(l); }, [&](int) -> const uint32_t * { return nullptr; }, iso_m, nullptr, iacc, icacc);
   merge_all([&](int l) -> const PairList & { return lane_list(l); }, [&](int l) -> const uint32_t * { return lane_cl(l).get<uint32_t>(); }, ctx->list, &ctx->d_cluster, lacc, lcacc);
   HIP_CHECK(hipStreamSynchronize(ctx->st));

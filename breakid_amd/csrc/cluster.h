@@ -37,6 +37,8 @@ void remove_isolated_begin(const bk_pair *pairs, const uint32_t *gof0, const uin
 void remove_isolated_end(const bk_pair *pairs, PairList &L, ClusterBufs &b, hipStream_t st);
 // dst = src without the groups flagged in drop[] (device, one u32 per group; offsets for all groups are kept)
 void list_subset(const PairList &src, const uint32_t *drop, PairList &dst, ClusterBufs &b, hipStream_t st);
+// the same from host knowledge: keep_host[g] != 0 selects group g, src_goff_host = src's offsets; one launch over the subset
+void list_subset_ranges(const PairList &src, const uint64_t *src_goff_host, const uint8_t *keep_host, PairList &dst, hipStream_t st);
 // removes the groups that keep fewer than 2 pairs (they are not clustered, BreakID.cc:125)
 void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st);
 // find_cluster_pairs_enspan_fast for every group with >= 2 pairs; L becomes the clustered list, cluster_out[p] its cluster number

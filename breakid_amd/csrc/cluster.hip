@@ -398,6 +398,37 @@ __global__ __launch_bounds__(256) void k_subset_list(const uint64_t *__restrict_
   gof[p] = lo;
 }
 }  // namespace
+namespace
+{
+__global__ __launch_bounds__(256) void k_subset_of_list(const uint32_t *__restrict__ src_idx, const uint64_t *__restrict__ src_goff, const uint64_t *__restrict__ goff, uint32_t ng,
+                                                        uint64_t n_list, uint32_t *__restrict__ idx, uint32_t *__restrict__ gof)
+{
+  const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_list) return;
+  uint32_t lo = 0, hi = ng;
+  while (hi - lo > 1)
+  {
+    const uint32_t m = (lo + hi) >> 1;
+    if (goff[m] <= p) lo = m; else hi = m;
+  }
+  idx[p] = src_idx[src_goff[lo] + (p - goff[lo])];
+  gof[p] = lo;
+}
+}  // namespace
+void list_subset_ranges(const PairList &src, const uint64_t *src_goff_host, const uint8_t *keep_host, PairList &dst, hipStream_t st)
+{
+  const uint32_t ng = src.ng;
+  std::vector<uint64_t> goff((size_t) ng + 1, 0);
+  for (uint32_t g = 0; g < ng; ++g) goff[g + 1] = goff[g] + (keep_host[g] ? src_goff_host[g + 1] - src_goff_host[g] : 0);
+  dst.n = goff[ng];
+  dst.ng = ng;
+  uint32_t *idx = dst.idx.as<uint32_t>(dst.n + 1), *gof = dst.gof.as<uint32_t>(dst.n + 1);
+  uint64_t *dgoff = dst.goff.as<uint64_t>((uint64_t) ng + 1);
+  HIP_CHECK(hipMemcpyAsync(dgoff, goff.data(), ((size_t) ng + 1) * 8, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));  // (goff is a local)
+  if (dst.n) hipLaunchKernelGGL(k_subset_of_list, dim3(nb(dst.n)), dim3(256), 0, st, src.idx.get<uint32_t>(), src.goff.get<uint64_t>(), dgoff, ng, dst.n, idx, gof);
+}
+
 void list_of_groups(const uint64_t *gstart_dev, const uint64_t *gstart_host, const uint8_t *keep_host, uint32_t ng, PairList &L, hipStream_t st)
 {
   std::vector<uint64_t> goff((size_t) ng + 1, 0);
