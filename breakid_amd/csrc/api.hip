@@ -697,9 +697,9 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
   const uint32_t ng = (uint32_t) sizes.size();
   // in units of one pop of a lone wave in LDS (~0.15 us): a pair costs a lane ~0.15 ns in the two sorts that are left (most of a
   // lane's time outside the heaps is a fixed number of launches), an element of a heap segment beyond what fits the LDS of a
-  // CU is popped in global memory at four times the price
+  // CU costs twice as much (the hybrid loop: 0.30 us per pop while the heap's tail is in global memory)
   static const double per_pair = getenv("BREAKID_LANE_PAIR_COST") ? atof(getenv("BREAKID_LANE_PAIR_COST")) : 0.001;
-  auto heap_cost = [](uint32_t m) { return (double) m + (m > 40947u ? 3.0 * (double) (m - 40947u) : 0.0); };
+  auto heap_cost = [](uint32_t m) { return (double) m + (m > 40947u ? 1.0 * (double) (m - 40947u) : 0.0); };
   std::vector<uint32_t> order(ng);
   std::iota(order.begin(), order.end(), 0u);
   auto chain = [&](uint32_t g) { return heap_cost(hx[g]) + heap_cost(hy[g]); };

@@ -891,6 +891,164 @@ __device__ __forceinline__ void sort_heap_lds_q(uint32_t *slot1, const uint32_t 
   }
 }
 
+// ---- a heap that is larger than the LDS: the same loop with its tail in global memory ------------------------------------
+// Slots 1 .. CAP (the CU's LDS) hold the upper levels, slots CAP+1 .. m live in a global array O (O[slot]); m < 2 (CAP + 1), so
+// every slot in O is a leaf.  The loop is sort_heap_lds_q with three additions (model: the same schedule was checked against
+// libstdc++ on the host before it was written):
+//   * after every step one more vector compare asks whether a new hole lies beyond CAP / 2, i.e. has its children in O (or
+//     lies in O itself); if none does - most iterations - nothing else changes;
+//   * otherwise: a lane whose new hole lies IN O is done - a leaf: it stores its value there one step early and goes idle
+//     (if that leaf is L, the value is also the leaf of the next launch); a lane whose children are in O loads them from
+//     there (slots beyond m read the zeros behind the heap) over the zeros its clamped LDS read returned;
+//   * the leaf to detach is in O: it is requested right after the launch before (two to three iterations ahead of its use)
+//     and zeroed there by the launch.
+// Runs the m - CAP pops that bring the heap down to CAP slots, waits for the pops in flight and returns; the caller carries
+// on with sort_heap_lds_q on the LDS part.  0.6 us per pop (everything in global memory) -> ~0.25.
+#define BK_HEAP32H_SLOW(TAG)                                                                                                  \
+  "v_cmp_lt_u32_e64 s[52:53], s67, v40\n"                                                                                  \
+  "s_mov_b64 exec, s[52:53]\n"                                                                                             \
+  "v_mov_b32 v71, v42\n"                                                                                                   \
+  "v_lshlrev_b32 v70, 2, v40\n"                                                                                            \
+  "global_store_dword v70, v42, s[64:65]\n"                                                                                \
+  "v_cmp_eq_u32_e64 s[54:55], s43, v40\n"                                                                                  \
+  "v_mov_b32 v40, 0\n"                                                                                                     \
+  "v_mov_b32 v42, -1\n"                                                                                                    \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "s_cmp_lg_u64 s[54:55], 0\n"                                                                                             \
+  "s_cbranch_scc0 BK_HS1_" TAG "_%=\n"                                                                                             \
+  "s_ff1_i32_b64 s70, s[54:55]\n"                                                                                          \
+  "s_nop 3\n"                                                                                                              \
+  "v_readlane_b32 s69, v71, s70\n"                                                                                         \
+  "v_mov_b32 v58, s69\n"                                                                                                   \
+  "BK_HS1_" TAG "_%=:\n"                                                                                                          \
+  "v_cmp_lt_u32_e64 s[50:51], s66, v40\n"                                                                                  \
+  "s_mov_b64 exec, s[50:51]\n"                                                                                             \
+  "v_lshlrev_b32 v70, 1, v40\n"                                                                                            \
+  "v_min_u32 v70, s68, v70\n"                                                                                              \
+  "v_lshlrev_b32 v70, 2, v70\n"                                                                                            \
+  "global_load_dwordx2 v[68:69], v70, s[64:65]\n"                                                                          \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                                                        \
+  "v_cndmask_b32_e64 v46, v46, v68, s[50:51]\n"                                                                            \
+  "v_cndmask_b32_e64 v47, v47, v69, s[50:51]\n"
+#define BK_HEAP32H_ASM                                                                                                    \
+  "s_setprio 3\n"                                                                                                          \
+  "s_mov_b64 s[56:57], exec\n"                                                                                             \
+  "s_mov_b32 s62, %[olo]\n s_mov_b32 s63, %[ohi]\n"                                                                        \
+  "s_mov_b32 s64, %[plo]\n s_mov_b32 s65, %[phi]\n"                                                                        \
+  "s_sub_u32 s40, %[base], 4\n"                                                                                            \
+  "v_mov_b32 v60, %[base]\n"                                                                                               \
+  "s_mov_b32 s43, %[m]\n"                                                                                                  \
+  "s_mov_b32 s67, %[cap]\n"                                                                                                \
+  "s_lshr_b32 s66, s67, 1\n"                                                                                               \
+  "s_add_u32 s68, s43, 1\n"                                                                                                \
+  "s_sub_u32 s46, s43, s67\n s_sub_u32 s46, s46, 1\n"                                                                      \
+  "s_flbit_i32_b32 s47, s43\n s_add_u32 s47, s47, 1\n"                                                                     \
+  "s_add_u32 s48, s67, 1\n s_lshl_b32 s48, s48, 2\n s_add_u32 s42, s48, s40\n"                                             \
+  "s_lshl_b32 s48, s43, 2\n v_mov_b32 v61, s48\n"                                                                          \
+  "s_sub_u32 s48, s48, 4\n v_mov_b32 v57, s48\n"                                                                           \
+  "s_mov_b32 s45, %[budget]\n"                                                                                             \
+  "v_mov_b32 v55, 0\n v_mov_b32 v59, -1\n v_mov_b32 v40, 0\n v_mov_b32 v42, -1\n"                                          \
+  "s_mov_b64 s[58:59], 1\n"                                                                                                \
+  "global_load_dword v58, v61, s[64:65]\n"                                                                                 \
+  "v_mov_b32 v45, s40\n"                                                                                                   \
+  "ds_read2_b32 v[46:47], v45 offset1:1\n"                                                                                 \
+  "s_branch BK_HB_%=\n"                                                                                                    \
+  "BK_HA_%=:\n"                                                                                                           \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "s_sub_u32 s43, s43, 1\n"                                                                                                \
+  "s_flbit_i32_b32 s47, s43\n"                                                                                             \
+  "s_add_u32 s47, s47, 1\n"                                                                                                \
+  "v_add_u32 v61, -4, v61\n"                                                                                               \
+  "v_add_u32 v57, -4, v57\n"                                                                                               \
+  "s_lshl_b64 s[58:59], s[58:59], 1\n"                                                                                     \
+  "s_cselect_b64 s[58:59], s[58:59], 1\n"                                                                                  \
+  "global_load_dword v58, v61, s[64:65]\n"                                                                                 \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+  BK_HEAP32Q_STEP                                                                                                         \
+  "v_cmp_lt_u32_e64 s[50:51], s66, v40\n"                                                                                  \
+  BK_HEAP32Q_NEXT                                                                                                         \
+  "s_cmp_lg_u64 s[50:51], 0\n"                                                                                             \
+  "s_cbranch_scc0 BK_HB_%=\n"                                                                                              \
+  BK_HEAP32H_SLOW("a")                                                                                                    \
+  "BK_HB_%=:\n"                                                                                                           \
+  "ds_read_b32 v56, v60\n"                                                                                                 \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "v_ffbh_u32 v63, v40\n"                                                                                                  \
+  "v_subrev_u32 v63, s47, v63\n"                                                                                           \
+  "v_max_i32 v63, 0, v63\n"                                                                                                \
+  "v_lshrrev_b32_e64 v64, v63, s43\n"                                                                                      \
+  "s_waitcnt lgkmcnt(1)\n"                                                                                                 \
+  BK_HEAP32Q_STEP                                                                                                         \
+  "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
+  "v_cmp_lt_u32_e64 s[50:51], s66, v40\n"                                                                                  \
+  BK_HEAP32Q_NEXT                                                                                                         \
+  "s_cmp_lg_u64 s[50:51], 0\n"                                                                                             \
+  "s_cbranch_scc0 BK_HB2_%=\n"                                                                                             \
+  BK_HEAP32H_SLOW("b")                                                                                                    \
+  "v_cmp_eq_u32 vcc, v64, v40\n"                                                                                           \
+  "BK_HB2_%=:\n"                                                                                                          \
+  "s_cbranch_vccnz BK_HBNEXT_%=\n"                                                                                         \
+  "s_waitcnt vmcnt(0) lgkmcnt(2)\n"                                                                                        \
+  "s_mov_b64 exec, s[58:59]\n"                                                                                             \
+  "global_store_dword v61, v55, s[64:65]\n"                                                                                \
+  "global_store_dword v57, v56, s[62:63]\n"                                                                                \
+  "v_mov_b32 v42, v58\n"                                                                                                   \
+  "v_mov_b32 v40, 1\n"                                                                                                     \
+  "ds_read2_b32 v[46:47], v60 offset0:1 offset1:2\n"                                                                       \
+  "s_mov_b64 exec, s[56:57]\n"                                                                                             \
+  "s_sub_u32 s46, s46, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_HA_%=\n"                                                                                              \
+  "s_branch BK_HDRAIN_%=\n"                                                                                                \
+  "BK_HBNEXT_%=:\n"                                                                                                       \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_HB_%=\n"                                                                                              \
+  "s_branch BK_HDONE_%=\n"                                                                                                 \
+  "BK_HDRAIN_%=:\n"                                                                                                       \
+  "v_lshl_add_u32 v52, v40, 2, s40\n"                                                                                      \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                 \
+  BK_HEAP32Q_STEP                                                                                                         \
+  "v_cmp_lt_u32_e64 s[50:51], s66, v40\n"                                                                                  \
+  BK_HEAP32Q_NEXT                                                                                                         \
+  "s_cmp_lg_u64 s[50:51], 0\n"                                                                                             \
+  "s_cbranch_scc0 BK_HD2_%=\n"                                                                                             \
+  BK_HEAP32H_SLOW("d")                                                                                                    \
+  "BK_HD2_%=:\n"                                                                                                          \
+  "v_cmp_ne_u32 vcc, 0, v40\n"                                                                                             \
+  "s_cbranch_vccz BK_HDONE_%=\n"                                                                                           \
+  "s_sub_u32 s45, s45, 1\n"                                                                                                \
+  "s_cbranch_scc0 BK_HDRAIN_%=\n"                                                                                          \
+  "BK_HDONE_%=:\n"                                                                                                        \
+  "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                                                        \
+  "s_setprio 0\n"                                                                                                          \
+  "s_mov_b32 %[left], s45\n"
+
+__device__ int g_heap_no_hybrid = 0;  // BK_HEAP_NO_HYBRID=1: heaps beyond the LDS pop in global memory until they fit (the earlier loop)
+
+// slot1 = LDS address of slot 1 (slots 0, cap+1, cap+2 zero), ovf = O (ovf[slot] for cap < slot <= m + 2, the last two zero),
+// m > cap odd, m < 2 (cap + 1); pops leaves m .. cap+1 to out[m-1 .. cap]; the heap is left in LDS slots 1 .. cap
+__device__ __forceinline__ void sort_heap_hybrid(uint32_t *slot1, const uint32_t m, const uint32_t cap, uint32_t *ovf, uint32_t *out)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t budget = __builtin_amdgcn_readfirstlane(64u * (m - cap) + 4096u);
+  const uint32_t mm = __builtin_amdgcn_readfirstlane(m), cc = __builtin_amdgcn_readfirstlane(cap);
+  const unsigned long long o = (unsigned long long) out, pp = (unsigned long long) ovf;
+  const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t) o), ohi = __builtin_amdgcn_readfirstlane((uint32_t) (o >> 32));
+  const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t) pp), phi = __builtin_amdgcn_readfirstlane((uint32_t) (pp >> 32));
+  const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t) (unsigned long long) slot1);
+  uint32_t left;
+  asm volatile(BK_HEAP32H_ASM
+               : [left] "=s"(left)
+               : [olo] "s"(olo), [ohi] "s"(ohi), [plo] "s"(plo), [phi] "s"(phi), [base] "s"(base), [m] "s"(mm), [cap] "s"(cc), [budget] "s"(budget)
+               : BK_HEAP_CLOBBERS, "v68", "v69", "v70", "v71", "s64", "s65", "s66", "s67", "s68", "s69", "s70");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0)
+  {
+    atomicAdd(&g_heap_iters[0], (unsigned long long) (budget - left) + (m - cap));
+    atomicAdd(&g_heap_iters[1], (unsigned long long) (m - cap));
+  }
+}
+
 constexpr uint32_t HEAP_SMALL = 1024;    // 8 KiB of LDS per wave
 constexpr uint32_t HEAP_LARGE = 20000;   // 156 KiB of LDS (one wave per CU)
 constexpr size_t HEAP_BIG_LDS = 163800;  // dynamic LDS of the one-per-CU kernel: all of the CU's 160 KiB but the kernel's few static bytes
@@ -906,7 +1064,8 @@ constexpr uint32_t HEAP_RANKED_MAX = 65534;  // rank + 1 must fit 16 bits and st
 constexpr uint32_t HEAP_BIG_THREADS = 256;
 template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                                        hent *__restrict__ scratch, uint32_t lo, uint32_t hi,
-                                                                       const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32)
+                                                                       const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32,
+                                                                       uint32_t *__restrict__ scratch32b)
 {
   extern __shared__ __attribute__((aligned(16))) hent dyn[];
   __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
@@ -954,15 +1113,35 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
         make_heap_block(gmem, m, NT);
       }
       tp2 = wall_clock64();
-      if (w0)
+      if (scratch32b != nullptr && g_heap_no_hybrid == 0 && m < 2 * (HEAP_LARGE32 + 1))
       {
-        sort_heap_asm32<true>(g32, m, HEAP_LARGE32);  // pops in global memory until the heap fits LDS
+        // the upper levels to LDS, the rest (all leaves) to the overflow array; the pops that bring the heap down to the LDS part
+        uint32_t *ovf = scratch32b + sg.first;  // ovf[slot], slots HEAP_LARGE32 + 1 .. m + 2
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += NT)
+        {
+          const uint32_t e = g32[i];
+          if (i < HEAP_LARGE32) l32[1 + i] = e; else ovf[1 + i] = e;
+        }
+        if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
+        if (threadIdx.x < 2) ovf[m + 1 + threadIdx.x] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (w0) sort_heap_hybrid(l32 + 1, m, HEAP_LARGE32, ovf, g32);
+        tp3 = wall_clock64();
       }
-      tp3 = wall_clock64();
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += NT) l32[1 + i] = g32[i];
-      if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
+      else
+      {
+        if (w0)
+        {
+          sort_heap_asm32<true>(g32, m, HEAP_LARGE32);  // pops in global memory until the heap fits LDS
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        tp3 = wall_clock64();
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += NT) l32[1 + i] = g32[i];
+        if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
+      }
       __syncthreads();
       if (w0) sort_heap_lds_q(l32 + 1, HEAP_LARGE32, g32);
     }
@@ -1886,6 +2065,8 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   {
     const int nq = getenv("BK_HEAP_NO_Q") != nullptr;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_q), &nq, sizeof nq));
+    const int nhy = getenv("BK_HEAP_NO_HYBRID") != nullptr || nq;
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_hybrid), &nhy, sizeof nhy));
     pipe_flag_set = true;
   }
   const uint32_t n = (uint32_t) n64;
@@ -2068,7 +2249,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   const size_t dyn = (HEAP_LARGE + HEAP_PAD) * 8;
   hent *hscratch = nullptr;
   const uint32_t *rank32 = nullptr;
-  uint32_t *scratch32 = nullptr;
+  uint32_t *scratch32 = nullptr, *scratch32b = nullptr;
   int used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg)
@@ -2091,7 +2272,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       HIP_CHECK(hipEventCreateWithFlags(&b.join[used], hipEventDisableTiming));
     }
     HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-    hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32);
+    hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32, scratch32b);
     HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
     ++used;
   };
@@ -2183,6 +2364,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         uint32_t *hval = b.hr_val.as<uint32_t>(e2), *hf = b.hr_f.as<uint32_t>((uint64_t) e2 + 1), *hord = b.hr_ord.as<uint32_t>(n_ord);
         uint32_t *r32 = b.rank32.as<uint32_t>(n);
         scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
+        if (max1 > HEAP_LARGE32) scratch32b = b.scratch32b.as<uint32_t>((uint64_t) n + HEAP_PAD);  // overflow slots of the heaps beyond the LDS
         hipLaunchKernelGGL(k_hr_gather, dim3(nh), dim3(256), 0, st, hl, nh, hc, key, hck, hval, hord);
         int obits = 1;
         while ((1u << obits) < n_ord && obits < 31) ++obits;
@@ -2212,7 +2394,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       // stream: only the big heaps need a side stream, and every stream of every lane of groups costs a hardware queue
       static const bool mid_side = getenv("BK_HEAP_MID_SIDE") != nullptr;
       if ((!split || ranked_on) && !mid_side)
-        hipLaunchKernelGGL(k1, dim3(nh1), dim3(64), ((size_t) big_lo + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, big_lo, rank32, scratch32);
+        hipLaunchKernelGGL(k1, dim3(nh1), dim3(64), ((size_t) big_lo + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, big_lo, rank32, scratch32, scratch32b);
       else if (!split || ranked_on)
         side(k1, ((size_t) big_lo + HEAP_PAD) * 8, hl, nh1, HEAP_SMALL, big_lo);
       else
@@ -2241,9 +2423,9 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         if (nh2 > nh1 && e[1] > HEAP_SMALL)
         {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, HEAP_SMALL, HEAP_LARGE, rank32, scratch32);
+          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, HEAP_SMALL, HEAP_LARGE, rank32, scratch32, scratch32b);
         }
-        hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32);
+        hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b);
       };
       if (use_asm)
         small(k_se_heapsort<0, true>, k_se_heapsort<1, true>);
