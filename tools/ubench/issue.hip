@@ -16,6 +16,17 @@
     unsigned long long t1 = __builtin_readcyclecounter();                                                           \
     if (threadIdx.x == 0) out[0] = (t1 - t0) * 100 / ((unsigned long long) iters * 64 * NINSTR);                    \
   }
+// the same with EXEC narrowed to the given lanes for the timed loop (does the SIMD skip passes over idle lanes?)
+#define CASEX(ID, NINSTR, LO, HI, BODY)                                                                             \
+  if (which == ID)                                                                                                  \
+  {                                                                                                                 \
+    asm volatile("s_mov_b64 s[26:27], exec\n s_mov_b32 exec_lo, " #LO "\n s_mov_b32 exec_hi, " #HI "\n" ::: "s26", "s27", "memory"); \
+    unsigned long long t0 = __builtin_readcyclecounter();                                                           \
+    for (int it = 0; it < iters; ++it) asm volatile(R64(BODY) ::: "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "s20", "s21", "s22", "s23", "s24", "s25", "vcc", "scc", "memory"); \
+    unsigned long long t1 = __builtin_readcyclecounter();                                                           \
+    asm volatile("s_mov_b64 exec, s[26:27]\n" ::: "memory");                                                        \
+    if (threadIdx.x == 0) out[0] = (t1 - t0) * 100 / ((unsigned long long) iters * 64 * NINSTR);                    \
+  }
 __global__ __launch_bounds__(64) void k(unsigned long long *out, int which, int iters)
 {
   __shared__ uint32_t lds[1024];
@@ -43,6 +54,14 @@ __global__ __launch_bounds__(64) void k(unsigned long long *out, int which, int 
   CASE(19, 1, "v_addc_co_u32_e32 v1, vcc, v1, v1, vcc\n")
   CASE(20, 4, "ds_read2_b32 v[8:9], v5 offset1:1\n v_add_u32 v1, v2, v3\n v_add_u32 v4, v2, v3\n s_waitcnt lgkmcnt(0)\n")
   CASE(21, 2, "s_setprio 3\n s_setprio 0\n")
+  CASEX(22, 1, 0xffffffff, 0, "v_add_u32 v1, v1, v2\n")
+  CASEX(23, 1, 0xffff, 0, "v_add_u32 v1, v1, v2\n")
+  CASEX(24, 1, 0xff, 0, "v_add_u32 v1, v1, v2\n")
+  CASEX(25, 1, 0xff, 0, "v_cmp_ge_u32_sdwa vcc, v1, v2 src0_sel:WORD_1 src1_sel:WORD_1\n")
+  CASEX(26, 2, 0xff, 0, "ds_read2_b32 v[8:9], v5 offset1:1\n s_waitcnt lgkmcnt(0)\n")
+  CASEX(27, 1, 0xff, 0, "ds_write_b32 v5, v1\n")
+  CASEX(28, 1, 0xff, 0, "v_lshl_add_u32 v1, v2, 3, s22\n")
+  CASEX(29, 2, 0xffff, 0, "ds_read2_b32 v[8:9], v5 offset1:1\n s_waitcnt lgkmcnt(0)\n")
   if (threadIdx.x == 99) out[1] = lds[threadIdx.x];
 }
 int main()
@@ -52,8 +71,10 @@ int main()
   const char *names[] = {"v_add independent", "v_add dependent chain", "two interleaved v_add chains", "v_cndmask (vcc) independent", "v_cmp -> v_cndmask via vcc", "v_cmp_e64 -> v_cndmask_e64 via SGPR pair",
                          "v_cmp_sdwa", "v_lshl_add with SGPR", "s_add dependent", "v_add / s_add alternating", "v_cmp_e64 -> s_and_b64", "s_waitcnt (nothing outstanding)", "s_cbranch not taken",
                          "ds_write_b32 issue", "ds_read2_b32 + wait", "ds_read_b32 + wait", "ds_read_b64 + wait", "ds_read_b128 + wait", "exec save / set / restore", "v_addc dependent",
-                         "ds_read2 + 2 v_add + wait", "s_setprio pair"};
-  for (int which = 0; which < 22; ++which)
+                         "ds_read2 + 2 v_add + wait", "s_setprio pair",
+                         "v_add dependent, 32 lanes in EXEC", "v_add dependent, 16 lanes in EXEC", "v_add dependent, 8 lanes in EXEC", "v_cmp_sdwa, 8 lanes in EXEC", "ds_read2_b32 + wait, 8 lanes in EXEC",
+                         "ds_write_b32 issue, 8 lanes in EXEC", "v_lshl_add with SGPR, 8 lanes in EXEC", "ds_read2_b32 + wait, 16 lanes in EXEC"};
+  for (int which = 0; which < 30; ++which)
   {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, which, 200);
     CK(hipDeviceSynchronize());
