@@ -4,10 +4,10 @@
 A step = one pass of the whole hot path (insert-size statistics, discordant-pair scan + mate join,
 isolated-pair masking, -fast clustering, per-read split evidence, cluster summary, split-read
 breakpoints) over one synthetic WGS-shape record table that is already resident in HBM when the timed
-region starts.  Workload at N=1 = BASELINE.json configs[1] (30x WGS shape, hg19, 2x150 bp); for N>1 ONE
-sample of N x that size (capped below 2^32 records) is sharded over the ranks - every rank holds a contiguous range of
-its coordinate-sorted records, candidates and pairs travel to their owners by RCCL all-to-all (breakid_amd/sharded.py) -
-so the per-GPU work stays fixed (weak scaling).
+region starts.  Workload at N=1 = BASELINE.json configs[1] (30x WGS shape, hg19, 2x150 bp); for N>1 it is configs[2]:
+the SAME sample sharded over the ranks - every rank holds a contiguous range of its coordinate-sorted records, candidates
+and pairs travel to their owners by RCCL all-to-all (breakid_amd/sharded.py) - so the total work stays fixed (strong
+scaling; `--scaling weak` shards one sample of N x that size instead, capped below 2^32 records).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--records R]
 
@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--from-bam", type=int, default=0, metavar="PAIRS",
                     help="side measurement (N=1): write a synthetic BAM of PAIRS read pairs and time file -> calls end to end: GPU feed alone, feed with the "
                          "stream pass overlapped (bk_bam_decode_device_ctx), rest of the hot path")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = configs[2], the --records sample sharded over the ranks (default); weak = one sample of N x --records")
     ap.add_argument("--sharded", type=int, default=-1, help="1: one sample sharded over the ranks (default when --gpus > 1), 0: plain single-table run")
     args = ap.parse_args()
 
@@ -106,7 +108,9 @@ def main():
     # size the table to the card (configs[1] needs ~60 GB including generator temporaries)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     n_rec = args.records
-    if use_shards:
+    if use_shards and args.scaling == "strong":
+        n_rec = max(1_000_000, n_rec // world)
+    elif use_shards:
         n_rec = min(n_rec, (0xFFFF0000 // max(world, 1)) // 1_000_000 * 1_000_000)  # the whole sample stays below 2^32 records (536 M per rank at 8 ranks)
     while n_rec * 110 > free_b and n_rec > 1_000_000:
         n_rec //= 2
@@ -120,6 +124,7 @@ def main():
         contigs, cols = synth_gpu.make_wgs(n_rec, args.seed + rank, dev)
     torch.cuda.synchronize(dev)
     gen_s = time.time() - t0
+    torch.cuda.empty_cache()  # the generator's temporaries go back to the driver: the library allocates with hipMalloc
     n = cols["n"]
 
     ctx = capi.Context(contigs, device=local_rank)
@@ -137,10 +142,7 @@ def main():
         # bk_upload_records(BK_MEM_DEVICE) is zero copy; re-attaching invalidates every cached stage result
         ctx.attach_device(ptrs, n, cols["n_cigar_words"], cols["n_aux_bytes"])
         if use_shards:
-            w = runner.run(rec_base, qual=20, fast=fast)
-            cl, _ = ctx.fetch(abi.STAGE_CLUSTERS) if rank == 0 else (None, None)
-            nv = int(((cl["flags"] & 2) != 0).sum()) if cl is not None else 0
-            return w, nv
+            return runner.run(rec_base, qual=20, fast=fast), 0
         w, nv = ctx.run(qual=20, fast=fast)
         return w, nv
 
@@ -167,6 +169,11 @@ def main():
     timing = ctx.timing()
     touched = ctx.timing_touched()
     ctx.timing_enable(False)
+    if use_shards and rank == 0:
+        # every rank ends a sharded step with the whole cluster table; the count for the report is taken from the last step's
+        # (bk_fetch assembles on the host: inspection path, outside the timed region)
+        cl, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+        n_valid = int(((cl["flags"] & 2) != 0).sum())
 
     if rank == 0:
         PEAK = 8000.0  # GB/s, HBM3E (MI355X_MICROARCH.md)
@@ -211,9 +218,9 @@ def main():
         out = {
             "metric": "M reads/s clustered+split-scanned", "value": round(value, 3), "unit": "M records/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u8 (+f64 sd replay)",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "int32/u8 (+f64 sd replay)",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]: 30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" if args.workload == "wgs" else
+            "config": {"workload": (("configs[2]: the " if use_shards and args.scaling == "strong" and world > 1 else "configs[1]: ") + "30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" if args.workload == "wgs" else
                                     "configs[3]: targeted-panel shape, 500 fusion loci x 2000x, 20%% split reads, 10%% discordant, -%s clustering") % args.mode,
                        "records_per_gpu": int(n), "bytes_per_record_algorithmic": round(path_bytes / max(1, n), 2),
                        "valid_clusters": int(n_valid), "w": w, "generator_s": round(gen_s, 2),

@@ -14,6 +14,9 @@ each group is clustered by exactly one rank (LPT on pair counts)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
+import time
 
 import numpy as np
 import torch
@@ -137,6 +140,8 @@ class ShardedRun:
         self.ctx, self.comm = ctx, comm
         self.routed = routed  # False: the simpler replicated join (all-gather of every candidate to every rank)
         self._keep = []
+        self._trace = os.environ.get("BREAKID_SHARD_TRACE") is not None
+        self._t_mark = 0.0
         if comm.on and not comm.host_staged:
             # RCCL: the library runs on torch's current stream, so a collective is ordered behind the kernel that produced its
             # input and the next kernel behind the collective - on the device, without host synchronisation
@@ -144,6 +149,18 @@ class ShardedRun:
             comm.same_stream = True
         else:
             comm.before = ctx.sync
+
+    def _mark(self, label):
+        """BREAKID_SHARD_TRACE=1: host time of every phase (device drained at each mark) on stderr, rank 0."""
+        if not self._trace:
+            return
+        self.ctx.sync()
+        if self.comm.device.type == "cuda":
+            torch.cuda.synchronize(self.comm.device)
+        now = time.perf_counter()
+        if label is not None and self.comm.rank == 0:
+            print("[sharded] %-24s %8.3f ms" % (label, (now - self._t_mark) * 1e3), file=sys.stderr, flush=True)
+        self._t_mark = now
 
     def _buffer(self, which):
         L, h = self.ctx.L, self.ctx.h
@@ -200,7 +217,9 @@ class ShardedRun:
         ctx, comm = self.ctx, self.comm
         L, h, dev = ctx.L, ctx.h, comm.device
         self._keep = []
+        self._mark(None)
         ctx._check(L.bk_shard_begin(h, rec_base, qual))
+        self._mark("begin (stream pass)")
         st = abi.ShardStats()
         ctx._check(L.bk_shard_get_stats(h, C.byref(st)))
         sums = comm.all_reduce(torch.tensor([st.isize_sum, st.isize_n], dtype=torch.int64, device=dev))
@@ -225,6 +244,7 @@ class ShardedRun:
         ctx._check(L.bk_shard_sd_finish(h, C.c_void_p(all_ex.data_ptr() if all_ex.numel() else 0), all_ex.numel() // 16, int(per[:, 0].sum()),
                                         C.byref(mean), C.byref(sd)))
         w = capi.w_from(mean.value, sd.value)
+        self._mark("statistics + exact sd")
         if self.routed:
             self._routed_join(qual, w)
         else:
@@ -237,11 +257,14 @@ class ShardedRun:
             owner = lpt_owner(sizes, comm.world)
             own = np.asarray([1 if o == comm.rank else 0 for o in owner], dtype=np.uint8)
             ctx._check(L.bk_shard_own_groups(h, own.ctypes.data if len(own) else None, ng.value))
+        self._mark("join + routing")
         ctx.mask_and_cluster(w, fast)
+        self._mark("mask + cluster")
         ctx.cluster_summary(w)
         # tuples and cluster summaries to everybody
         self._gather_into(abi.BUF_TUPLES)
         ncl = self._gather_into(abi.BUF_CLUSTERS)
+        self._mark("summary + gathers")
         # breakpoints: range counts add over the record shards
         p, n = C.c_void_p(), C.c_uint64()
         ctx._check(L.bk_shard_bp_cov(h, w, C.byref(p), C.byref(n)))
@@ -263,5 +286,6 @@ class ShardedRun:
         dep = comm.all_reduce(tensor_from_ptr(p.value, n.value * 4, dev).view(torch.int32).clone())
         self._keep.append(dep)
         ctx._check(L.bk_shard_bp_finish(h, C.c_void_p(dep.data_ptr() if dep.numel() else 0)))
+        self._mark("breakpoints")
         self.mean, self.sd, self.w, self.n_clusters = mean.value, sd.value, w, ncl
         return w
