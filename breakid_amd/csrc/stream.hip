@@ -428,13 +428,25 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
       const uchar4 m4 = reinterpret_cast<const uchar4 *>(a.mapq)[q];
       const uint4 co = reinterpret_cast<const uint4 *>(a.cigar_off)[q];
       const uint4 ao = reinterpret_cast<const uint4 *>(a.aux_off)[q];
-      const uint32_t co_n = a.cigar_off[i0 + ST_V], ao_n = a.aux_off[i0 + ST_V];
-      uint32_t ptid = 0;
-      int32_t ppos = 0;
-      if (i0 > 0)
+      // the neighbours' values (offset that ends the quad, record in front of it) sit in the neighbouring lanes' registers:
+      // only the lanes at the edge of the wave (or of the table) load them
+      uint32_t co_n = (uint32_t) __shfl_down((int) co.x, 1, 64), ao_n = (uint32_t) __shfl_down((int) ao.x, 1, 64);
+      uint32_t ptid = (uint32_t) __shfl_up(t4.w, 1, 64);
+      int32_t ppos = __shfl_up(p4.w, 1, 64);
+      if (lane == 63 || q + 1 >= nq)
       {
-        ptid = (uint32_t) a.tid[i0 - 1];
-        ppos = a.pos[i0 - 1];
+        co_n = a.cigar_off[i0 + ST_V];
+        ao_n = a.aux_off[i0 + ST_V];
+      }
+      if (lane == 0)
+      {
+        ptid = 0;
+        ppos = 0;
+        if (i0 > 0)
+        {
+          ptid = (uint32_t) a.tid[i0 - 1];
+          ppos = a.pos[i0 - 1];
+        }
       }
       tidv[0] = t4.x; tidv[1] = t4.y; tidv[2] = t4.z; tidv[3] = t4.w;
       posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
