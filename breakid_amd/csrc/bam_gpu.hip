@@ -239,16 +239,60 @@ __device__ __forceinline__ uint64_t qname_hash_dev(const uint8_t *name, uint32_t
   return h;
 }
 
-// EMIT = false: validate + count; EMIT = true: write the columns (bases from the scans).
+// where a record lies in a chunk's inflated data and what the chunk holds in front of it (k_bam_blocks<2> writes one per record,
+// k_bam_emit reads them: the chain of record lengths is serial inside a block, writing the columns is not)
+struct RecIndex
+{
+  uint64_t at;        // offset of the record's length word in the chunk's inflated data
+  uint32_t cig, aux;  // CIGAR words / aux bytes of the chunk's records before this one
+};
+
+// columns of one record: r = the record behind its length word bs, ri / ci / ai = its row and the running CIGAR / aux offsets
+__device__ __forceinline__ void emit_record(const BamCols &c, uint64_t ri, uint64_t ci, uint64_t ai, const uint8_t *r, int32_t tid, uint32_t l_name, uint32_t n_cig, uint32_t sa_at,
+                                            uint32_t sa_len, uint32_t oc_at, uint32_t oc_len)
+{
+  c.tid[ri] = tid;
+  c.pos[ri] = (int32_t) ld32(r + 4);
+  c.mapq[ri] = r[9];
+  c.flag[ri] = (uint16_t) ld16(r + 14);
+  c.mtid[ri] = (int32_t) ld32(r + 20);
+  c.mpos[ri] = (int32_t) ld32(r + 24);
+  c.isize[ri] = (int32_t) ld32(r + 28);
+  c.qhash[ri] = qname_hash_dev(r + 32, l_name);
+  {
+    uint32_t ql = 0;  // bam_get_qname is a C string
+    while (ql < l_name && r[32 + ql]) ++ql;
+    c.qcheck[ri] = qname_check32(r + 32, ql);
+  }
+  c.cigar_off[ri] = (uint32_t) ci;
+  c.aux_off[ri] = (uint32_t) ai;
+  const uint8_t *cg = r + 32 + l_name;
+  for (uint32_t k = 0; k < n_cig; ++k) c.cigar[ci + k] = ld32(cg + 4 * k);
+  if (sa_len)
+  {
+    uint64_t w = ai;
+    if (oc_len)
+    {
+      for (uint32_t k = 0; k < oc_len; ++k) c.aux[w++] = r[oc_at + k];
+      c.aux[w++] = '\t';
+    }
+    for (uint32_t k = 0; k < sa_len; ++k) c.aux[w++] = r[sa_at + k];
+  }
+}
+
+// MODE 0: validate + count; MODE 1: write the columns (bases from the scans); MODE 2: write one RecIndex per record (chunk-relative
+// bases from the scans) for k_bam_emit.
 // Aligned files (entry == nullptr): every block starts with a record and no record leaves its block.  Packed mode
 // (entry != nullptr, the inflated stream is contiguous, `total` bytes): the lane of block b takes the records that START
 // in b, from entry[b] (the block's size = none), wherever they end; next_abs[b] = stream offset where its walk stopped.
 // allow_tail: a record that does not fit the stream is not an error but the end of the walk (the next chunk starts with it).
-template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk,
+template <int MODE> __global__ __launch_bounds__(64) void k_bam_blocks(const uint8_t *__restrict__ data, const BgzfBlock *__restrict__ blk, uint32_t nblk, uint32_t first_blk,
                                                                          uint32_t first_off, int32_t n_ref, BlockCount *__restrict__ cnt, const uint64_t *__restrict__ rec_base,
                                                                          const uint64_t *__restrict__ cig_base, const uint64_t *__restrict__ aux_base, uint64_t rec0, uint64_t cig0, uint64_t aux0, BamCols c,
-                                                                         const uint32_t *__restrict__ entry = nullptr, uint64_t total = 0, uint64_t *__restrict__ next_abs = nullptr, int allow_tail = 0)
+                                                                         const uint32_t *__restrict__ entry = nullptr, uint64_t total = 0, uint64_t *__restrict__ next_abs = nullptr, int allow_tail = 0,
+                                                                         RecIndex *__restrict__ rindex = nullptr)
 {
+  constexpr bool EMIT = MODE == 1, INDEX = MODE == 2;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
   BlockCount bc = {0, 0, 0, 0};
@@ -260,7 +304,7 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
     // bytes a record that starts in this block may use
     const uint64_t room = entry ? total - bb.out_off : (uint64_t) bb.isize;
     uint64_t p = entry ? entry[b] : (b == first_blk ? first_off : 0u);
-    uint64_t ri = EMIT ? rec0 + rec_base[b] : 0, ci = EMIT ? cig0 + cig_base[b] : 0, ai = EMIT ? aux0 + aux_base[b] : 0;  // rec0.. = totals of the chunks before this one
+    uint64_t ri = MODE ? rec0 + rec_base[b] : 0, ci = MODE ? cig0 + cig_base[b] : 0, ai = MODE ? aux0 + aux_base[b] : 0;  // rec0.. = totals of the chunks before this one
     while (p < bb.isize)
     {
       if (p + 36 > room)
@@ -287,35 +331,14 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
       uint32_t sa_at, sa_len, oc_at, oc_len;
       aux_scan(r, q, bs, sa_at, sa_len, oc_at, oc_len);
       const uint32_t blob = sa_len ? sa_len + (oc_len ? oc_len + 1 : 0) : 0;
-      if (EMIT)
+      if (EMIT) emit_record(c, ri, ci, ai, r, tid, l_name, n_cig, sa_at, sa_len, oc_at, oc_len);
+      if (INDEX)
       {
-        c.tid[ri] = tid;
-        c.pos[ri] = (int32_t) ld32(r + 4);
-        c.mapq[ri] = r[9];
-        c.flag[ri] = (uint16_t) ld16(r + 14);
-        c.mtid[ri] = (int32_t) ld32(r + 20);
-        c.mpos[ri] = (int32_t) ld32(r + 24);
-        c.isize[ri] = (int32_t) ld32(r + 28);
-        c.qhash[ri] = qname_hash_dev(r + 32, l_name);
-        {
-          uint32_t ql = 0;  // bam_get_qname is a C string
-          while (ql < l_name && r[32 + ql]) ++ql;
-          c.qcheck[ri] = qname_check32(r + 32, ql);
-        }
-        c.cigar_off[ri] = (uint32_t) ci;
-        c.aux_off[ri] = (uint32_t) ai;
-        const uint8_t *cg = r + 32 + l_name;
-        for (uint32_t k = 0; k < n_cig; ++k) c.cigar[ci + k] = ld32(cg + 4 * k);
-        if (blob)
-        {
-          uint64_t w = ai;
-          if (oc_len)
-          {
-            for (uint32_t k = 0; k < oc_len; ++k) c.aux[w++] = r[oc_at + k];
-            c.aux[w++] = '\t';
-          }
-          for (uint32_t k = 0; k < sa_len; ++k) c.aux[w++] = r[sa_at + k];
-        }
+        RecIndex x;
+        x.at = bb.out_off + p;
+        x.cig = (uint32_t) ci;
+        x.aux = (uint32_t) ai;
+        rindex[ri] = x;
       }
       ++ri;
       ci += n_cig;
@@ -327,11 +350,26 @@ template <bool EMIT> __global__ __launch_bounds__(64) void k_bam_blocks(const ui
     }
     stop = bb.out_off + p;
   }
-  if (!EMIT)
+  if (MODE == 0)
   {
     cnt[b] = bc;
     if (next_abs) next_abs[b] = stop;
   }
+}
+
+// one lane per record of a chunk (the records were validated by the count pass and located by the index pass)
+__global__ __launch_bounds__(256) void k_bam_emit(const uint8_t *__restrict__ data, const RecIndex *__restrict__ rindex, uint64_t n, uint64_t rec0, uint64_t cig0, uint64_t aux0, BamCols c)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const RecIndex x = rindex[i];
+  const uint32_t bs = ld32(data + x.at);
+  const uint8_t *r = data + x.at + 4;
+  const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
+  const uint32_t q = 32u + l_name + 4u * n_cig + (l_seq + 1) / 2 + l_seq;
+  uint32_t sa_at, sa_len, oc_at, oc_len;
+  aux_scan(r, q, bs, sa_at, sa_len, oc_at, oc_len);
+  emit_record(c, rec0 + i, cig0 + x.cig, aux0 + x.aux, r, (int32_t) ld32(r), l_name, n_cig, sa_at, sa_len, oc_at, oc_len);
 }
 
 __global__ void k_bam_count_split(const BlockCount *__restrict__ cnt, uint32_t nblk, uint64_t *__restrict__ nr, uint64_t *__restrict__ nc, uint64_t *__restrict__ na, uint32_t *__restrict__ err)
@@ -735,7 +773,7 @@ struct not_block_aligned
 // one chunk of the file in flight: its compressed bytes, inflated bytes, match tokens and per-block counts
 struct FeedSlot
 {
-  DevBuf dfile, dblk, ddata, dslab, dcnt, dnr, dnc, dna, dscan, derr;
+  DevBuf dfile, dblk, ddata, dslab, dcnt, dnr, dnc, dna, dscan, derr, dindex;
   hipStream_t st = nullptr;
   hipEvent_t ev_count = nullptr, ev_emit = nullptr;
   uint64_t *tot = nullptr;  // pinned: records, CIGAR words, aux bytes, error flags of the chunk
@@ -782,10 +820,19 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     int copy_threads = 4;
     if (const char *e = getenv("BREAKID_THREADS"))
       if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
-    constexpr int NS = 4, LAG = 2;  // chunks in flight; how far the driver thread runs ahead of the totals it waits for
-    FeedSlot slot[NS];
-    for (auto &s : slot)
+    // chunks in flight; how far the driver thread runs ahead of the totals it waits for (a slot is reused LAG + 1 .. NS chunks later)
+    constexpr int NS_MAX = 12;
+    int NS = 4, LAG = 2;
+    if (const char *e = getenv("BREAKID_FEED_SLOTS"))
+      if (atoi(e) >= 2 && atoi(e) <= NS_MAX) NS = atoi(e);
+    if (const char *e = getenv("BREAKID_FEED_LAG"))
+      if (atoi(e) >= 1) LAG = atoi(e);
+    LAG = std::min(LAG, NS - 1);
+    FeedSlot slot_store[NS_MAX];
+    FeedSlot *slot = slot_store;
+    for (int k = 0; k < NS; ++k)
     {
+      FeedSlot &s = slot[k];
       HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
       HIP_CHECK(hipEventCreateWithFlags(&s.ev_count, hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
@@ -798,11 +845,12 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     uint64_t est_total = 0;
     StagePool pool(file.data(), file.size(), chunk_bytes, copy_threads, device);
     uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
-    double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0;
+    double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0, t_launch = 0, t_emit = 0, t_slot_wait = 0;
+    const double t_setup_done = now_s2();
     std::string why;
     BamCols c = {};
     auto sync_all = [&]() {
-      for (auto &s : slot) HIP_CHECK(hipStreamSynchronize(s.st));
+      for (int k = 0; k < NS; ++k) HIP_CHECK(hipStreamSynchronize(slot[k].st));
     };
     // columns for at least (r, g, a) records / CIGAR words / aux bytes; the emits in flight finish before a buffer moves
     auto reserve = [&](uint64_t r, uint64_t g, uint64_t a) {
@@ -853,12 +901,14 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     };
     // chunk k -> slot: hop over the block headers in the staged bytes, copy, inflate, count
     auto stage = [&](FeedSlot &s, uint64_t k) {
+      const double tsw = now_s2();
       if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
       s.used = true;
       s.blocks.clear();
       s.first_blk = 0;
       s.first_off = 0;
       const double ts00 = now_s2();
+      t_slot_wait += ts00 - tsw;
       StagePool::Buf *sb = k >= StagePool::FIRST ? &pool.get(k) : nullptr;
       const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
       const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
@@ -892,7 +942,8 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       HIP_CHECK(hipMemcpyAsync(df, fdata, rel, hipMemcpyHostToDevice, s.st));
       if (sb) pool.release(*sb, s.st);
       HIP_CHECK(hipMemcpyAsync(db, s.blocks.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
-      t_h2d += now_s2() - ta;
+      const double tl0 = now_s2();
+      t_h2d += tl0 - ta;
       HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
       launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st);
       BamCols none = {};
@@ -907,6 +958,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       HIP_CHECK(hipMemcpyAsync(&s.tot[2], na + nb, 8, hipMemcpyDeviceToHost, s.st));
       HIP_CHECK(hipMemcpyAsync(&s.tot[3], de, 4, hipMemcpyDeviceToHost, s.st));
       HIP_CHECK(hipEventRecord(s.ev_count, s.st));
+      t_launch += now_s2() - tl0;
     };
     // totals of the chunk are known: room in the columns, emit at the running offsets
     auto finish = [&](FeedSlot &s, bool first, bool more) {
@@ -926,9 +978,21 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
         est_total = (uint64_t) (r * scale);
       }
       reserve(r, g, a);
-      t_reserve += now_s2() - tw0;
-      hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref,
-                         s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(), s.dna.get<uint64_t>(), n_rec, n_cig, n_aux, c);
+      const double te0 = now_s2();
+      t_reserve += te0 - tw0;
+      static const bool emit_by_block = getenv("BREAKID_FEED_EMIT_BY_BLOCK") != nullptr;  // the one-lane-per-block emit (comparison)
+      if (emit_by_block || s.tot[0] == 0)
+        hipLaunchKernelGGL(k_bam_blocks<1>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref,
+                           s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(), s.dna.get<uint64_t>(), n_rec, n_cig, n_aux, c);
+      else
+      {
+        // the chain of record lengths once more, leaving where every record lies; then one lane per record writes the columns
+        RecIndex *rx = s.dindex.as<RecIndex>(s.tot[0]);
+        BamCols none = {};
+        hipLaunchKernelGGL(k_bam_blocks<2>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref,
+                           s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(), s.dna.get<uint64_t>(), 0ull, 0ull, 0ull, none, nullptr, 0ull, nullptr, 0, rx);
+        hipLaunchKernelGGL(k_bam_emit, dim3((unsigned) cdiv(s.tot[0], 256)), dim3(256), 0, s.st, s.ddata.get<uint8_t>(), rx, s.tot[0], n_rec, n_cig, n_aux, c);
+      }
       HIP_CHECK(hipEventRecord(s.ev_emit, s.st));
       n_rec = r;
       n_cig = g;
@@ -944,6 +1008,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
         v.n_aux_bytes = n_aux;
         fc->on_chunk(fc->user, &v, n_rec, std::max(est_total, n_rec), s.ev_emit);
       }
+      t_emit += now_s2() - te0;
     };
     // the driver thread stages chunk ci, then takes the totals of chunk ci - LAG
     const uint64_t nchunk = pool.nchunks;
@@ -970,12 +1035,12 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     cols->n_aux_bytes = (uint32_t) n_aux;
     const double td0 = now_s2();
     pool.shutdown();
-    for (auto &sl : slot)
-      for (DevBuf *b : {&sl.dfile, &sl.dblk, &sl.ddata, &sl.dslab, &sl.dcnt, &sl.dnr, &sl.dnc, &sl.dna, &sl.dscan, &sl.derr}) b->release();
+    for (int k = 0; k < NS; ++k)
+      for (DevBuf *b : {&slot[k].dfile, &slot[k].dblk, &slot[k].ddata, &slot[k].dslab, &slot[k].dcnt, &slot[k].dnr, &slot[k].dnc, &slot[k].dna, &slot[k].dscan, &slot[k].derr, &slot[k].dindex}) b->release();
     const double td2 = now_s2();
     if (getenv("BREAKID_FEED_STATS"))
-      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, waiting for chunk totals + column growth %.3f s, final sync %.3f s, teardown %.3f s)\n",
-              (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_stage_wait, t_scan, t_alloc, t_h2d, t_reserve, t3 - t_end_loop, td2 - td0);
+      fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: setup %.3f s, waiting for a free slot %.3f s, waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, kernel launches %.3f s, waiting for chunk totals + column growth %.3f s, emit launches %.3f s, final sync %.3f s, teardown %.3f s)\n",
+              (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_setup_done - t0, t_slot_wait, t_stage_wait, t_scan, t_alloc, t_h2d, t_launch, t_reserve, t_emit, t3 - t_end_loop, td2 - td0);
   }
 }
 

@@ -45,7 +45,8 @@ __device__ unsigned long long g_bgzf_stats[8];
 #endif
 constexpr uint32_t CHUNK_DW = 64;            // one dword per lane
 constexpr uint32_t WIN_DW = 3 * CHUNK_DW;    // input window: three chunks in LDS, the fourth on its way in a register
-constexpr uint32_t RESOLVE_THREADS = 1024;
+constexpr uint32_t RESOLVE_THREADS = 256;
+constexpr uint32_t RES_WIN = 16384;            // output positions whose parents are in LDS at a time (k_bgzf_resolve)
 
 // direct-table entries (u16)
 //   literal/length: bits 0-3 code length (0 = longer than the table); bit 4 clear: literal in bits 8-15; bit 4 set: bits 5-7 extra
@@ -523,7 +524,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
 }
 
 // blk[first + blockIdx.x]: literals into out, match tokens into slab block blockIdx.x, their number into ntok[blockIdx.x]
-__global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
                                                     unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
   __shared__ HuffLds s_h;
@@ -542,74 +543,108 @@ __global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ 
   }
 }
 
-// LZ77 resolution of one block by pointer jumping in LDS (file comment).  Thread t owns positions t + 1024 i.
+// LZ77 resolution of one block by pointer jumping in LDS (file comment), a window of RES_WIN output positions at a time.
+// A match reaches back at most 32 KiB, but nothing here depends on that: a parent in front of the window's first position is
+// final already (the earlier windows wrote it), so it ends a chain like a literal does.  32 KiB of LDS and 4 waves per block
+// instead of 128 KiB and 16: a resolve block finds room on a CU that also holds decode waves of the neighbouring chunks
+// (with the whole block's parents in LDS it had to wait until a CU was nearly empty, i.e. for the other chunks' decoders).
+// Thread t owns window positions t + RESOLVE_THREADS i.  Tokens are in output order (the decoder writes them so).
 __global__ __launch_bounds__(RESOLVE_THREADS) void k_bgzf_resolve(const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
                                                                   const unsigned long long *__restrict__ slab, const uint32_t *__restrict__ ntok)
 {
-  extern __shared__ __attribute__((aligned(16))) uint16_t s_par[];
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_par[];  // RES_WIN parents (absolute positions)
+  __shared__ uint32_t s_hi;
   if (blockIdx.x >= nblk) return;
   const BgzfBlock b = blk[first + blockIdx.x];
   const uint32_t n = b.isize <= 65536u ? b.isize : 0u, t = threadIdx.x, nt = ntok[blockIdx.x];
   if (n == 0 || nt == 0) return;  // literals only: the decoder wrote every byte
   const unsigned long long *tok = slab + (size_t) blockIdx.x * BGZF_TOKENS_PER_BLOCK;
   uint8_t *o = out + b.out_off;
-  for (uint32_t p = 8 * t; p < n; p += 8 * RESOLVE_THREADS)
+  const bool packed = (b.out_off & 3u) != 0;
+  constexpr uint32_t PER = RES_WIN / RESOLVE_THREADS;
+  static_assert(PER <= 64 && RES_WIN % (8 * RESOLVE_THREADS) == 0, "one todo bit per owned position");
+  uint32_t tok_lo = 0;  // first token that may reach into the window
+  for (uint32_t base = 0; base < n; base += RES_WIN)
   {
-    const uint32_t a = p | ((p + 1) << 16);
-    *reinterpret_cast<uint4 *>(s_par + p) = make_uint4(a, a + 0x00020002u, a + 0x00040004u, a + 0x00060006u);
-  }
-  __syncthreads();
-  for (uint32_t i = t; i < nt; i += RESOLVE_THREADS)
-  {
-    const unsigned long long k = tok[i];
-    const uint32_t pos = (uint32_t) k & 0xFFFFu, len = (uint32_t) (k >> 16) & 0xFFFFu, dist = (uint32_t) (k >> 32);
-    for (uint32_t j = 0; j < len; ++j) s_par[pos + j] = (uint16_t) (pos + j - dist);
-  }
-  __syncthreads();
-  unsigned long long todo = 0;
-  for (uint32_t i = 0; i < 64; ++i)
-  {
-    const uint32_t p = t + RESOLVE_THREADS * i;
-    if (p < n && s_par[p] != p) todo |= 1ull << i;
-  }
-  while (todo)
-  {
-    unsigned long long m = todo;
-    while (m)
+    const uint32_t end = base + RES_WIN < n ? base + RES_WIN : n;
+    for (uint32_t q = 8 * t; q < RES_WIN; q += 8 * RESOLVE_THREADS)
     {
-      const uint32_t i = (uint32_t) __ffsll((long long) m) - 1u;
-      m &= m - 1ull;
-      const uint32_t p = t + RESOLVE_THREADS * i;
-      const uint32_t s = s_par[p], r = s_par[s];
-      if (r == s)
-        todo &= ~(1ull << i);  // s is a literal
-      else
-        s_par[p] = (uint16_t) r;
+      const uint32_t a = ((base + q) & 0xFFFFu) | (((base + q + 1) & 0xFFFFu) << 16);
+      *reinterpret_cast<uint4 *>(s_par + q) = make_uint4(a, a + 0x00020002u, a + 0x00040004u, a + 0x00060006u);
     }
-  }
-  __syncthreads();
-  if ((b.out_off & 3u) != 0)
-  {
-    // packed output (blocks at arbitrary offsets): only the copied bytes are written, one at a time
-    for (uint32_t p = t; p < n; p += RESOLVE_THREADS)
+    if (t == 0) s_hi = nt;
+    __syncthreads();
     {
-      const uint32_t s = s_par[p];
-      if (s != p) o[p] = o[s];
+      uint32_t i = tok_lo + t;
+      for (; i < nt; i += RESOLVE_THREADS)
+      {
+        const unsigned long long k = tok[i];
+        const uint32_t pos = (uint32_t) k & 0xFFFFu, len = (uint32_t) (k >> 16) & 0xFFFFu, dist = (uint32_t) (k >> 32);
+        if (pos >= end) break;
+        const uint32_t j0 = pos < base ? base - pos : 0u, j1 = pos + len > end ? end - pos : len;
+        for (uint32_t j = j0; j < j1; ++j) s_par[pos + j - base] = (uint16_t) (pos + j - dist);
+      }
+      if (i < nt) atomicMin(&s_hi, i);  // the first token of a later window, as far as this thread saw
     }
-    return;
-  }
-  // four output bytes per thread and store
-  const uint32_t n4 = n & ~3u;
-  for (uint32_t p = 4 * t; p < n4; p += 4 * RESOLVE_THREADS)
-  {
-    const uint2 s = *reinterpret_cast<const uint2 *>(s_par + p);
-    const uint32_t v = (uint32_t) o[s.x & 0xFFFFu] | ((uint32_t) o[s.x >> 16] << 8) | ((uint32_t) o[s.y & 0xFFFFu] << 16) | ((uint32_t) o[s.y >> 16] << 24);
-    *reinterpret_cast<uint32_t *>(o + p) = v;
-  }
-  if (t < n - n4)
-  {
-    const uint32_t p = n4 + t, s = s_par[p];
-    if (s != p) o[p] = o[s];
+    __syncthreads();
+    unsigned long long todo = 0;
+    for (uint32_t i = 0; i < PER; ++i)
+    {
+      const uint32_t q = t + RESOLVE_THREADS * i;
+      if (base + q < end && s_par[q] != ((base + q) & 0xFFFFu)) todo |= 1ull << i;
+    }
+    while (todo)
+    {
+      unsigned long long m = todo;
+      while (m)
+      {
+        const uint32_t i = (uint32_t) __ffsll((long long) m) - 1u;
+        m &= m - 1ull;
+        const uint32_t q = t + RESOLVE_THREADS * i;
+        const uint32_t sp = s_par[q];
+        if (sp < base)
+          todo &= ~(1ull << i);  // final since an earlier window
+        else
+        {
+          const uint32_t r = s_par[sp - base];
+          if (r == sp)
+            todo &= ~(1ull << i);  // a literal
+          else
+            s_par[q] = (uint16_t) r;
+        }
+      }
+    }
+    __syncthreads();
+    if (packed)
+    {
+      // packed output (blocks at arbitrary offsets): only the copied bytes are written, one at a time
+      for (uint32_t q = t; base + q < end; q += RESOLVE_THREADS)
+      {
+        const uint32_t sp = s_par[q];
+        if (sp != base + q) o[base + q] = o[sp];
+      }
+    }
+    else
+    {
+      // four output bytes per thread and store
+      const uint32_t w4 = (end - base) & ~3u;
+      for (uint32_t q = 4 * t; q < w4; q += 4 * RESOLVE_THREADS)
+      {
+        const uint2 sp = *reinterpret_cast<const uint2 *>(s_par + q);
+        const uint32_t v = (uint32_t) o[sp.x & 0xFFFFu] | ((uint32_t) o[sp.x >> 16] << 8) | ((uint32_t) o[sp.y & 0xFFFFu] << 16) | ((uint32_t) o[sp.y >> 16] << 24);
+        *reinterpret_cast<uint32_t *>(o + base + q) = v;
+      }
+      if (t < end - base - w4)
+      {
+        const uint32_t q = w4 + t, sp = s_par[q];
+        if (sp != base + q) o[base + q] = o[sp];
+      }
+    }
+    const uint32_t hi = s_hi;
+    tok_lo = hi ? hi - 1 : 0;  // the token in front of the next window's first may reach into it
+    // the next window reads what this one wrote (same CU, same L1) and reuses the LDS
+    __threadfence_block();
+    __syncthreads();
   }
 }
 }  // namespace
@@ -622,7 +657,7 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
   static bool attr_set = false;
   if (!attr_set)
   {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, RES_WIN * 2));
     attr_set = true;
   }
   const uint32_t cap = bgzf_scratch_blocks(nblk);
@@ -632,7 +667,7 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
   {
     const uint32_t nb = nblk - first < BGZF_BATCH_BLOCKS ? nblk - first : BGZF_BATCH_BLOCKS;
     hipLaunchKernelGGL(k_bgzf_decode, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
-    hipLaunchKernelGGL(k_bgzf_resolve, dim3(nb), dim3(RESOLVE_THREADS), 65536 * 2, st, blk_dev, first, nb, out_dev, slab, ntok);
+    hipLaunchKernelGGL(k_bgzf_resolve, dim3(nb), dim3(RESOLVE_THREADS), RES_WIN * 2, st, blk_dev, first, nb, out_dev, slab, ntok);
   }
 #ifdef BGZF_STATS
   if (getenv("BK_BGZF_STATS"))
