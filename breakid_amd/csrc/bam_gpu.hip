@@ -372,6 +372,23 @@ __global__ __launch_bounds__(256) void k_bam_emit(const uint8_t *__restrict__ da
   emit_record(c, rec0 + i, cig0 + x.cig, aux0 + x.aux, r, (int32_t) ld32(r), l_name, n_cig, sa_at, sa_len, oc_at, oc_len);
 }
 
+// the columns of the n records a walk counted: once more over the length chains for where the records lie, then one lane per
+// record (BREAKID_FEED_EMIT_BY_BLOCK=1: the walk itself writes the columns, one lane per block - comparison)
+static void launch_emit(const uint8_t *dd, const BgzfBlock *db, uint32_t nb, uint32_t first_blk, uint32_t first_off, int32_t n_ref, BlockCount *dc, const uint64_t *nr, const uint64_t *nc,
+                        const uint64_t *na, uint64_t rec0, uint64_t cig0, uint64_t aux0, const BamCols &c, const uint32_t *entry, uint64_t total, int allow_tail, uint64_t n, DevBuf &index,
+                        hipStream_t st)
+{
+  if (n == 0 || getenv("BREAKID_FEED_EMIT_BY_BLOCK") != nullptr)
+  {
+    hipLaunchKernelGGL(k_bam_blocks<1>, dim3(cdiv(nb, 64)), dim3(64), 0, st, dd, db, nb, first_blk, first_off, n_ref, dc, nr, nc, na, rec0, cig0, aux0, c, entry, total, nullptr, allow_tail, nullptr);
+    return;
+  }
+  RecIndex *rx = index.as<RecIndex>(n);
+  BamCols none = {};
+  hipLaunchKernelGGL(k_bam_blocks<2>, dim3(cdiv(nb, 64)), dim3(64), 0, st, dd, db, nb, first_blk, first_off, n_ref, dc, nr, nc, na, 0ull, 0ull, 0ull, none, entry, total, nullptr, allow_tail, rx);
+  hipLaunchKernelGGL(k_bam_emit, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, st, dd, (const RecIndex *) rx, n, rec0, cig0, aux0, c);
+}
+
 __global__ void k_bam_count_split(const BlockCount *__restrict__ cnt, uint32_t nblk, uint64_t *__restrict__ nr, uint64_t *__restrict__ nc, uint64_t *__restrict__ na, uint32_t *__restrict__ err)
 {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,6 +480,8 @@ __global__ void k_bam_verify(const BgzfBlock *__restrict__ blk, uint32_t nblk, u
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
+#include <cerrno>
 #include <zlib.h>
 #include <cstdio>
 #include <ctime>
@@ -515,6 +534,7 @@ struct MappedFile
   MappedFile &operator=(const MappedFile &) = delete;
   const uint8_t *data() const { return p; }
   size_t size() const { return n; }
+  int descriptor() const { return fd; }
 };
 double now_s2()
 {
@@ -601,6 +621,7 @@ struct StagePool
   };
   Buf buf[NB];
   const uint8_t *file;
+  int fd;  // >= 0: the staging threads read() the file (page cache -> buffer, no page tables to fill and to tear down again)
   uint64_t size, chunk_bytes, nchunks, buf_bytes;
   int threads, device;
   std::mutex mu;
@@ -609,8 +630,8 @@ struct StagePool
   bool stop = false;
   std::string error;
 
-  StagePool(const uint8_t *f, uint64_t n, uint64_t cb, int th, int dev)
-      : file(f), size(n), chunk_bytes(cb), nchunks((n + cb - 1) / cb), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
+  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev)
+      : file(f), fd(fd_), size(n), chunk_bytes(cb), nchunks((n + cb - 1) / cb), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
   {
     for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
     if (nchunks > FIRST) producer = std::thread([this] { run(); });
@@ -663,10 +684,37 @@ struct StagePool
       }
       std::vector<std::thread> ts;
       const uint64_t per = ((n + threads - 1) / threads + 4095) / 4096 * 4096;
+      std::atomic<bool> short_read{false};
+      auto fetch = [&](uint64_t at, uint64_t len) {
+        if (fd < 0)
+        {
+          memcpy(b.p + at, file + lo + at, len);
+          return;
+        }
+        uint64_t got = 0;
+        while (got < len)
+        {
+          const ssize_t r = pread(fd, b.p + at + got, len - got, (off_t) (lo + at + got));
+          if (r <= 0)
+          {
+            if (r < 0 && errno == EINTR) continue;
+            short_read = true;
+            return;
+          }
+          got += (uint64_t) r;
+        }
+      };
       for (int t = 1; t < threads; ++t)
-        if ((uint64_t) t * per < n) ts.emplace_back([&, t] { memcpy(b.p + t * per, file + lo + t * per, std::min(per, n - t * per)); });
-      memcpy(b.p, file + lo, std::min(per, n));
+        if ((uint64_t) t * per < n) ts.emplace_back([&, t] { fetch(t * per, std::min(per, n - t * per)); });
+      fetch(0, std::min(per, n));
       for (auto &t : ts) t.join();
+      if (short_read)
+      {
+        std::lock_guard<std::mutex> g(mu);
+        error = "cannot read the BAM file";
+        cv.notify_all();
+        return;
+      }
       {
         std::lock_guard<std::mutex> g(mu);
         b.chunk = k;
@@ -683,7 +731,7 @@ struct StagePool
     Buf &b = buf[k % NB];
     std::unique_lock<std::mutex> g(mu);
     cv.wait(g, [&] { return !error.empty() || (b.state == 1 && b.chunk == k); });
-    if (!error.empty()) throw bk_error(BK_ERR_LIMIT, error);
+    if (!error.empty()) throw bk_error(error[0] == 'c' ? BK_ERR_IO : BK_ERR_LIMIT, error);
     return b;
   }
   // the consumer has queued its copy out of b on st
@@ -799,30 +847,35 @@ void grow_keep(DevBuf &b, size_t used, size_t need)
 }
 }  // namespace
 
-// The file is taken in chunks of BREAKID_FEED_CHUNK_MB (64) MiB of BGZF blocks.  Per chunk: H2D copy of the mapped
-// bytes, inflate, per-block record counts + scans, D2H of the three totals - all on the chunk's own stream - and, once the
-// totals are on the host, the emit kernel at the running offsets of the columns.  Up to four chunks are in flight, so the
-// copy of one overlaps the inflate of the one before and the emit of the one before that, kernels of neighbouring chunks
-// fill each other's tails, and device memory holds four chunks plus the columns whatever the size of the file.  The
-// columns are sized from the first chunk (records per compressed byte x file size) and grow by copying when that was
-// too small.
+// The file is taken in chunks of 32 or 64 MiB of BGZF blocks (below).  Per chunk: H2D copy of the staged bytes, inflate,
+// per-block record counts + scans, D2H of the three totals - all on the chunk's own stream - and, once the totals are on the
+// host, a second walk of the record-length chains that leaves where every record lies and the emit kernel, one lane per
+// record, at the running offsets of the columns.  Four to eight chunks are in flight, so the copy of one overlaps the
+// inflate of the ones before and the emit of the ones before those, and device memory holds those chunks plus the columns
+// whatever the size of the file.  The columns are sized from the first chunk (records per compressed byte x file size) and
+// grow by copying when that was too small.
 static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols, const FeedConsumer *fc = nullptr)
 {
   {
     const double t0 = now_s2();
     if (file.size() == 0) throw bk_error(BK_ERR_IO, "empty file");
-    // a chunk's inflate kernel lasts as long as its slowest block (~3 ms) however few blocks it has, and kernels of
-    // neighbouring chunks mostly run one after the other: big files take bigger chunks
-    uint64_t chunk_bytes = file.size() >= (1ull << 30) ? 128ull << 20 : 64ull << 20;
+    // A chunk's inflate kernel lasts as long as its slowest block (~3 ms) however few blocks it has, so the rate comes from
+    // the chunks in flight: eight slots of 32 MiB when the process has a hardware queue for each of them (the runtime reads
+    // GPU_MAX_HW_QUEUES when it starts, default 4: streams that share a queue make each other's launches wait), else four
+    // slots of 64 MiB.  BREAKID_FEED_SLOTS / _LAG / _CHUNK_MB override.
+    const int hw_queues = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+    const bool wide = hw_queues >= 8;
+    uint64_t chunk_bytes = wide ? 32ull << 20 : 64ull << 20;
     if (const char *e = getenv("BREAKID_FEED_CHUNK_MB"))
       if (atof(e) > 0) chunk_bytes = (uint64_t) (atof(e) * 1048576.0);
     chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000) / 4096 * 4096 + 4096;  // a chunk is longer than the longest block
-    int copy_threads = 4;
+    int copy_threads = 8;
     if (const char *e = getenv("BREAKID_THREADS"))
       if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
+    static const bool stage_from_mapping = getenv("BREAKID_FEED_STAGE_MMAP") != nullptr;  // the staging threads copy out of the mapping (comparison)
     // chunks in flight; how far the driver thread runs ahead of the totals it waits for (a slot is reused LAG + 1 .. NS chunks later)
     constexpr int NS_MAX = 12;
-    int NS = 4, LAG = 2;
+    int NS = wide ? 8 : 4, LAG = wide ? 6 : 2;
     if (const char *e = getenv("BREAKID_FEED_SLOTS"))
       if (atoi(e) >= 2 && atoi(e) <= NS_MAX) NS = atoi(e);
     if (const char *e = getenv("BREAKID_FEED_LAG"))
@@ -843,7 +896,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, hdr_first_off);
     if (fc && fc->on_header) fc->on_header(fc->user, (int) h->names.size(), h->name_ptrs.data(), h->lens.data());
     uint64_t est_total = 0;
-    StagePool pool(file.data(), file.size(), chunk_bytes, copy_threads, device);
+    StagePool pool(file.data(), stage_from_mapping ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device);
     uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
     double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0, t_launch = 0, t_emit = 0, t_slot_wait = 0;
     const double t_setup_done = now_s2();
@@ -945,7 +998,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       const double tl0 = now_s2();
       t_h2d += tl0 - ta;
       HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
-      launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st);
+      launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st, true);
       BamCols none = {};
       hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, dd, db, nb, s.first_blk, s.first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, 0ull, 0ull, 0ull, none);
       hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nb, 256)), dim3(256), 0, s.st, dc, nb, nr, nc, na, de);
@@ -980,19 +1033,8 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       reserve(r, g, a);
       const double te0 = now_s2();
       t_reserve += te0 - tw0;
-      static const bool emit_by_block = getenv("BREAKID_FEED_EMIT_BY_BLOCK") != nullptr;  // the one-lane-per-block emit (comparison)
-      if (emit_by_block || s.tot[0] == 0)
-        hipLaunchKernelGGL(k_bam_blocks<1>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref,
-                           s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(), s.dna.get<uint64_t>(), n_rec, n_cig, n_aux, c);
-      else
-      {
-        // the chain of record lengths once more, leaving where every record lies; then one lane per record writes the columns
-        RecIndex *rx = s.dindex.as<RecIndex>(s.tot[0]);
-        BamCols none = {};
-        hipLaunchKernelGGL(k_bam_blocks<2>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref,
-                           s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(), s.dna.get<uint64_t>(), 0ull, 0ull, 0ull, none, nullptr, 0ull, nullptr, 0, rx);
-        hipLaunchKernelGGL(k_bam_emit, dim3((unsigned) cdiv(s.tot[0], 256)), dim3(256), 0, s.st, s.ddata.get<uint8_t>(), rx, s.tot[0], n_rec, n_cig, n_aux, c);
-      }
+      launch_emit(s.ddata.get<uint8_t>(), s.dblk.get<BgzfBlock>(), nb, s.first_blk, s.first_off, (int32_t) n_ref, s.dcnt.get<BlockCount>(), s.dnr.get<uint64_t>(), s.dnc.get<uint64_t>(),
+                  s.dna.get<uint64_t>(), n_rec, n_cig, n_aux, c, nullptr, 0ull, 0, s.tot[0], s.dindex, s.st);
       HIP_CHECK(hipEventRecord(s.ev_emit, s.st));
       n_rec = r;
       n_cig = g;
@@ -1116,7 +1158,8 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
   c.aux_off = h->aux_off.as<uint32_t>(n + 4);
   c.cigar = h->cigar.as<uint32_t>(tot[1] + 4);
   c.aux = h->aux.as<uint8_t>(tot[2] + 4);
-  hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nr, nc, na, 0ull, 0ull, 0ull, c, entry, total, nullptr);
+  DevBuf dindex;
+  launch_emit(dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nr, nc, na, 0ull, 0ull, 0ull, c, entry, total, 0, n, dindex, st);
   const uint32_t ends[2] = {(uint32_t) tot[1], (uint32_t) tot[2]};
   HIP_CHECK(hipMemcpyAsync(c.cigar_off + n, &ends[0], 4, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(c.aux_off + n, &ends[1], 4, hipMemcpyHostToDevice, st));
@@ -1205,7 +1248,7 @@ constexpr uint64_t PACKED_RESERVE = 8u << 20;  // longest record that may cross 
 
 struct PackedSlot
 {
-  DevBuf dfile, dblk, dblk2, ddata, dslab, dcnt, dnr, dnc, dna, dscan, derr, dentry, dnext, dtail;
+  DevBuf dfile, dblk, dblk2, ddata, dslab, dcnt, dnr, dnc, dna, dscan, derr, dentry, dnext, dtail, dindex;
   hipStream_t st = nullptr;
   hipEvent_t ev_emit = nullptr;
   uint64_t *tot = nullptr;  // pinned: records, CIGAR words, aux bytes, error flags, tail
@@ -1283,7 +1326,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
     HIP_CHECK(hipMemcpyAsync(db, s.blocks.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
     HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
     HIP_CHECK(hipMemsetAsync(dd + PACKED_RESERVE + s.total, 0, 64, s.st));
-    launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st);
+    launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st, true);
     s.file_hi = off;
   };
   // the carry of the chunk before is known: boundaries, counts and totals of this chunk
@@ -1351,8 +1394,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
       sink.reserve((uint64_t) (r * scale), (uint64_t) (g * scale), (uint64_t) (a * scale), quiesce);
     }
     sink.reserve(r, g, a, quiesce);
-    hipLaunchKernelGGL(k_bam_blocks<true>, dim3(cdiv(nb, 64)), dim3(64), 0, s.st, dd, db2, nb, s.first_blk, s.first_off, (int32_t) n_ref, dc, nr, nc, na, sink.n_rec, sink.n_cig, sink.n_aux, sink.c,
-                       entry, total, nullptr, last ? 0 : 1);
+    launch_emit(dd, db2, nb, s.first_blk, s.first_off, (int32_t) n_ref, dc, nr, nc, na, sink.n_rec, sink.n_cig, sink.n_aux, sink.c, entry, total, last ? 0 : 1, s.tot[0], s.dindex, s.st);
     HIP_CHECK(hipEventRecord(s.ev_emit, s.st));
     sink.n_rec = r;
     sink.n_cig = g;

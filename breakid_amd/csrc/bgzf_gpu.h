@@ -19,7 +19,9 @@ inline uint64_t bgzf_scratch_bytes(uint32_t nblk) { return (uint64_t) bgzf_scrat
 // decode (one wavefront per block) + resolve (one workgroup per block); scratch_dev = bgzf_scratch_bytes(nblk) bytes;
 // file_dev must be 4-byte aligned with >= 4 readable bytes after the last block; *err_dev |= 1 when a block is malformed
 // or does not produce isize bytes
-void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st);
+// shared_gpu: other chunks' inflate launches run beside this one (the streaming feed) - see k_bgzf_decode_shared
+void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st,
+                         bool shared_gpu = false);
 
 // A consumer of the chunked GPU feed (bam_gpu.hip: decode_chunked): the stream pass of a context runs on the records of a
 // chunk while the next chunks are still being copied and inflated (bk_bam_decode_device_ctx, api.hip).

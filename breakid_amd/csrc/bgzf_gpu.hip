@@ -524,10 +524,9 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
 }
 
 // blk[first + blockIdx.x]: literals into out, match tokens into slab block blockIdx.x, their number into ntok[blockIdx.x]
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
-                                                    unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
+__device__ __forceinline__ void decode_block(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+                                             unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err, HuffLds &s_h)
 {
-  __shared__ HuffLds s_h;
   if (blockIdx.x >= nblk) return;
   const BgzfBlock b = blk[first + blockIdx.x];
   uint32_t got = ~0u, nt = 0;
@@ -541,6 +540,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
     ntok[blockIdx.x] = bad ? 0u : nt;
     if (bad) atomicOr(err, 1u);
   }
+}
+// one launch has the GPU to itself (a whole file at once): as many waves per CU as the LDS holds (22)
+__global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+                                                    unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
+{
+  __shared__ HuffLds s_h;
+  decode_block(file, blk, first, nblk, out, slab, ntok, err, s_h);
+}
+// the chunks of the streaming feed: decoders of several chunks and the resolve blocks of others share the CUs.  Four waves per
+// SIMD (the register allocation is rounded up to enforce it) leave 45 KiB of LDS and a wave slot per SIMD with 96 registers
+// on every CU - room for a resolve block; without the cap the decoders fill the LDS (22 x 7 KiB) and the resolve blocks of
+// a chunk wait until the other chunks' decoders have drained.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
+                                                                                                      uint32_t nblk, uint8_t *__restrict__ out, unsigned long long *__restrict__ slab,
+                                                                                                      uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
+{
+  __shared__ HuffLds s_h;
+  decode_block(file, blk, first, nblk, out, slab, ntok, err, s_h);
 }
 
 // LZ77 resolution of one block by pointer jumping in LDS (file comment), a window of RES_WIN output positions at a time.
@@ -651,7 +668,7 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_bgzf_resolve(const BgzfBloc
 
 uint32_t bgzf_scratch_blocks(uint32_t nblk) { return nblk < BGZF_BATCH_BLOCKS ? nblk : BGZF_BATCH_BLOCKS; }
 
-void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st)
+void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint32_t nblk, uint8_t *out_dev, void *scratch_dev, uint32_t *err_dev, hipStream_t st, bool shared_gpu)
 {
   if (nblk == 0) return;
   static bool attr_set = false;
@@ -666,7 +683,10 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
   for (uint32_t first = 0; first < nblk; first += BGZF_BATCH_BLOCKS)
   {
     const uint32_t nb = nblk - first < BGZF_BATCH_BLOCKS ? nblk - first : BGZF_BATCH_BLOCKS;
-    hipLaunchKernelGGL(k_bgzf_decode, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
+    if (shared_gpu)
+      hipLaunchKernelGGL(k_bgzf_decode_shared, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
+    else
+      hipLaunchKernelGGL(k_bgzf_decode, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
     hipLaunchKernelGGL(k_bgzf_resolve, dim3(nb), dim3(RESOLVE_THREADS), RES_WIN * 2, st, blk_dev, first, nb, out_dev, slab, ntok);
   }
 #ifdef BGZF_STATS

@@ -251,19 +251,26 @@ def test_device_decode_in_chunks_equals_one_chunk():
         p = os.path.join(t, "a.bam")
         ds.write_bam(p, aligned=True)
         size = os.path.getsize(p)
-        for mb in (None, size / 5 / 1048576.0, 0.07):
-            if mb is None:
-                os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
-            else:
-                os.environ["BREAKID_FEED_CHUNK_MB"] = repr(mb)
+        # (chunk size, slots, lag, emit by block): the default, a fifth of the file, a few blocks per chunk; eight slots with the
+        # driver six chunks ahead (what the command line runs with); the one-lane-per-block emit kept for comparison
+        for mb, slots, lag, by_block in ((None, None, None, False), (size / 5 / 1048576.0, None, None, False), (0.07, None, None, False), (0.07, 8, 6, False),
+                                         (0.07, 3, 1, False), (size / 5 / 1048576.0, None, None, True)):
+            env = {"BREAKID_FEED_CHUNK_MB": None if mb is None else repr(mb), "BREAKID_FEED_SLOTS": None if slots is None else str(slots),
+                   "BREAKID_FEED_LAG": None if lag is None else str(lag), "BREAKID_FEED_EMIT_BY_BLOCK": "1" if by_block else None}
+            for k, v in env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             try:
                 table = capi.decode_bam_device(p)
             finally:
-                os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
+                for k in env:
+                    os.environ.pop(k, None)
             got = _device_cols(table)
             assert table.contigs == contigs
             for k, _ in abi.SOA_COLS_ALL:
-                assert np.array_equal(got[k], ref[k]), (mb, k)
+                assert np.array_equal(got[k], ref[k]), (mb, slots, lag, k)
             table.close()
 
 

@@ -2,6 +2,7 @@
 record decode on the host cores, pinned columns) -> bk_upload_records(BK_MEM_HOST) -> bk_run.  Prints the rate of
 every stage so DESIGN.md can quote the PCIe-inclusive number next to the HBM-resident one."""
 import os, struct, sys, time, zlib
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # as bench.py and the command line: one hardware queue per feed slot (read when the runtime starts)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
