@@ -872,7 +872,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     int copy_threads = 8;
     if (const char *e = getenv("BREAKID_THREADS"))
       if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
-    static const bool stage_from_mapping = getenv("BREAKID_FEED_STAGE_MMAP") != nullptr;  // the staging threads copy out of the mapping (comparison)
+    const bool stage_from_mapping = getenv("BREAKID_FEED_STAGE_MMAP") != nullptr;  // the staging threads copy out of the mapping (comparison)
     // chunks in flight; how far the driver thread runs ahead of the totals it waits for (a slot is reused LAG + 1 .. NS chunks later)
     constexpr int NS_MAX = 12;
     int NS = wide ? 8 : 4, LAG = wide ? 6 : 2;

@@ -251,12 +251,15 @@ def test_device_decode_in_chunks_equals_one_chunk():
         p = os.path.join(t, "a.bam")
         ds.write_bam(p, aligned=True)
         size = os.path.getsize(p)
-        # (chunk size, slots, lag, emit by block): the default, a fifth of the file, a few blocks per chunk; eight slots with the
-        # driver six chunks ahead (what the command line runs with); the one-lane-per-block emit kept for comparison
-        for mb, slots, lag, by_block in ((None, None, None, False), (size / 5 / 1048576.0, None, None, False), (0.07, None, None, False), (0.07, 8, 6, False),
-                                         (0.07, 3, 1, False), (size / 5 / 1048576.0, None, None, True)):
+        # (chunk size, slots, lag, emit by block, staging out of the mapping): the default, a fifth of the file, a few blocks per chunk;
+        # eight slots with the driver six chunks ahead (what the command line runs with); the one-lane-per-block emit and the staging
+        # threads copying out of the mapping (both kept for comparison; more than three chunks, so that the staging pool runs)
+        for mb, slots, lag, by_block, from_map in ((None, None, None, False, False), (size / 5 / 1048576.0, None, None, False, False), (0.07, None, None, False, False),
+                                                   (0.07, 8, 6, False, False), (0.07, 3, 1, False, False), (size / 5 / 1048576.0, None, None, True, False),
+                                                   (size / 9 / 1048576.0, None, None, False, True)):
             env = {"BREAKID_FEED_CHUNK_MB": None if mb is None else repr(mb), "BREAKID_FEED_SLOTS": None if slots is None else str(slots),
-                   "BREAKID_FEED_LAG": None if lag is None else str(lag), "BREAKID_FEED_EMIT_BY_BLOCK": "1" if by_block else None}
+                   "BREAKID_FEED_LAG": None if lag is None else str(lag), "BREAKID_FEED_EMIT_BY_BLOCK": "1" if by_block else None,
+                   "BREAKID_FEED_STAGE_MMAP": "1" if from_map else None}
             for k, v in env.items():
                 if v is None:
                     os.environ.pop(k, None)
