@@ -474,6 +474,10 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
         throw bk_error(BK_ERR_ARG, "bk_upload_records: BK_MEM_DEVICE table lives on device " + std::to_string(at.device) + ", context on device " +
                                        std::to_string(ctx->device));
       (void) hipGetLastError();
+      // the streaming kernels read the fixed columns as 16-byte vectors (four or eight records per lane)
+      for (const void *p : {(const void *) s->tid, (const void *) s->pos, (const void *) s->isize, (const void *) s->flag, (const void *) s->mapq, (const void *) s->cigar_off,
+                            (const void *) s->aux_off})
+        if (s->n && ((uintptr_t) p & 15u)) throw bk_error(BK_ERR_ARG, "bk_upload_records: BK_MEM_DEVICE columns must be 16-byte aligned");
       ctx->rec = *s;
     }
     else

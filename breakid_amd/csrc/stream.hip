@@ -731,27 +731,60 @@ __device__ __forceinline__ bool sd_elem(const uint16_t *__restrict__ flag, const
   return true;
 }
 
+// one record's term from values already loaded (sd_elem without the loads)
+__device__ __forceinline__ void sd_term(uint32_t f, int32_t v, double mean, double thr, unsigned long long &L, unsigned long long &E)
+{
+  if (!((f & 1) && (f & 2) && !(f & (0x4 | 0x100 | 0x200 | 0x400)))) return;
+  v = v < 0 ? -v : v;
+  const double a = __dsub_rn((double) v, mean);
+  const double d = __dmul_rn(a, a);
+  const double fl = floor(d);
+  L += (unsigned long long) fl;
+  const double gap = __dsub_rn(__dadd_rn(fl, 1.0), d);
+  E += gap <= thr ? 1ull : 0ull;
+}
+
+// totals of a tile of SD_TILE records (the tiling of k_sd_emit): the sums do not depend on the order inside the tile, so a
+// thread takes SD_ITEMS consecutive records with three 16-byte loads
 __global__ __launch_bounds__(256) void k_sd_count(const uint16_t *__restrict__ flag, const int32_t *__restrict__ isize, uint64_t n, double mean, double thr,
                                                   unsigned long long *__restrict__ blockL, unsigned long long *__restrict__ blockE)
 {
-  __shared__ unsigned long long lds[4];
+  static_assert(SD_ITEMS == 8, "eight records per thread: one uint4 of flags, two int4 of insert sizes");
+  __shared__ unsigned long long lds[8];
   unsigned long long L = 0, E = 0;
-  uint64_t base = (uint64_t) blockIdx.x * SD_TILE;
-#pragma unroll
-  for (int k = 0; k < SD_ITEMS; ++k)
+  const uint64_t i0 = (uint64_t) blockIdx.x * SD_TILE + (uint64_t) threadIdx.x * SD_ITEMS;
+  if (i0 + SD_ITEMS <= n)
   {
-    double d;
-    unsigned long long fd;
-    bool exc;
-    sd_elem(flag, isize, base + (uint64_t) k * 256 + threadIdx.x, n, mean, thr, d, fd, exc);
-    L += fd;
-    E += exc ? 1ull : 0ull;
+    const uint4 f8 = *reinterpret_cast<const uint4 *>(flag + i0);
+    const int4 za = *reinterpret_cast<const int4 *>(isize + i0), zb = *reinterpret_cast<const int4 *>(isize + i0 + 4);
+    sd_term(f8.x & 0xFFFFu, za.x, mean, thr, L, E);
+    sd_term(f8.x >> 16, za.y, mean, thr, L, E);
+    sd_term(f8.y & 0xFFFFu, za.z, mean, thr, L, E);
+    sd_term(f8.y >> 16, za.w, mean, thr, L, E);
+    sd_term(f8.z & 0xFFFFu, zb.x, mean, thr, L, E);
+    sd_term(f8.z >> 16, zb.y, mean, thr, L, E);
+    sd_term(f8.w & 0xFFFFu, zb.z, mean, thr, L, E);
+    sd_term(f8.w >> 16, zb.w, mean, thr, L, E);
   }
-  unsigned long long tot;
-  (void) prims::block_exclusive_scan(L, lds, tot);
-  if (threadIdx.x == 0) blockL[blockIdx.x] = tot;
-  (void) prims::block_exclusive_scan(E, lds, tot);
-  if (threadIdx.x == 0) blockE[blockIdx.x] = tot;
+  else
+    for (uint64_t i = i0; i < n && i < i0 + SD_ITEMS; ++i) sd_term(flag[i], isize[i], mean, thr, L, E);
+  for (int d = 32; d; d >>= 1)
+  {
+    L += __shfl_down(L, d, 64);
+    E += __shfl_down(E, d, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+  {
+    lds[w] = L;
+    lds[4 + w] = E;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    blockL[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    blockE[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_sd_emit(const uint16_t *__restrict__ flag, const int32_t *__restrict__ isize, uint64_t n, double mean, double thr,

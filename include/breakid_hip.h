@@ -49,6 +49,8 @@ typedef struct bk_ctx bk_ctx;
  *                                 (BreakID.cc:1424, :627-637); with this column every equal-qhash decision of the mate join
  *                                 and of the breakpoint vote is verified, and a mismatch ends the run with BK_ERR_COLLISION
  *                                 instead of a silently different call.  The BAM decoders (bk_bam_*) fill it.
+ * A table handed over in device memory (BK_MEM_DEVICE) is used in place: tid, pos, isize, flag, mapq, cigar_off and aux_off
+ * must be 16-byte aligned there (the streaming kernels read them as vectors); BK_ERR_ARG otherwise.
  */
 typedef struct bk_soa {
   uint64_t n;

@@ -72,6 +72,26 @@ def test_more_than_2_32_records_is_refused():
     ctx.close()
 
 
+def test_device_table_with_a_misaligned_column_is_refused():
+    """BK_MEM_DEVICE tables are used in place and read as 16-byte vectors: a column that does not start on 16 bytes (a slice
+    of a larger buffer, say) is an argument error, not a slow or faulting run"""
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs(200_000, 5, dev)
+    ctx = capi.Context(contigs)
+    ptrs = abi.device_ptrs(cols)
+    ctx.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])  # as generated: fine
+    shifted = torch.empty(cols["n"] + 1, dtype=torch.int32, device=dev)
+    shifted[1:] = cols["isize"]
+    bad = dict(ptrs, isize=shifted[1:].data_ptr())
+    assert bad["isize"] % 16 == 4
+    with pytest.raises(capi.BreakIDError) as e:
+        ctx.attach_device(bad, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    assert e.value.code == abi.BK_ERR_ARG and "16-byte aligned" in str(e.value)
+    ctx.close()
+
+
 def test_read_name_run_longer_than_4096_candidates_is_refused():
     contigs = [("chr1", 10_000_000), ("chr2", 10_000_000)]
     ds = synth.Dataset(contigs)
