@@ -36,7 +36,7 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_get_stream", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_timing_touched", "bk_group_stats", "bk_qname_hash", "bk_qname_check",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_decode_device_ctx", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_decode_device_part", "bk_bam_decode_device_ctx", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
            "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
@@ -109,6 +109,8 @@ def lib():
         L.bk_bam_decode.argtypes = [vp, C.POINTER(abi.Soa), C.c_char_p, C.c_size_t]
         L.bk_bam_close.argtypes = [vp]
         L.bk_bam_decode_device.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(abi.Soa), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)),
+                                           C.POINTER(C.POINTER(C.c_uint32)), C.c_char_p, C.c_size_t]
+        L.bk_bam_decode_device_part.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(abi.Soa), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)),
                                            C.POINTER(C.POINTER(C.c_uint32)), C.c_char_p, C.c_size_t]
         L.bk_bam_dev_free.argtypes = [vp]
         L.bk_bam_decode_device_ctx.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)),
@@ -348,6 +350,23 @@ def decode_bam_device(path, device=0):
     names = C.POINTER(C.c_char_p)()
     lens = C.POINTER(C.c_uint32)()
     rc = L.bk_bam_decode_device(path.encode(), device, C.byref(h), C.byref(s), C.byref(nt), C.byref(names), C.byref(lens), err, 512)
+    if rc != 0:
+        raise BreakIDError(rc, err.value.decode())
+    contigs = [(names[i].decode(), int(lens[i])) for i in range(nt.value)]
+    return DeviceBamTable(L, h, s, contigs)
+
+
+def decode_bam_device_part(path, part, parts, device=0):
+    """The records of part `part` of `parts` of a block-aligned BAM (bk_bam_decode_device_part): one rank's record range of a
+    sharded run, decoded on its own GPU."""
+    L = lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    s = abi.Soa()
+    nt = C.c_int()
+    names = C.POINTER(C.c_char_p)()
+    lens = C.POINTER(C.c_uint32)()
+    rc = L.bk_bam_decode_device_part(path.encode(), device, part, parts, C.byref(h), C.byref(s), C.byref(nt), C.byref(names), C.byref(lens), err, 512)
     if rc != 0:
         raise BreakIDError(rc, err.value.decode())
     contigs = [(names[i].decode(), int(lens[i])) for i in range(nt.value)]

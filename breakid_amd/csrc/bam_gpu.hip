@@ -622,7 +622,7 @@ struct StagePool
   Buf buf[NB];
   const uint8_t *file;
   int fd;  // >= 0: the staging threads read() the file (page cache -> buffer, no page tables to fill and to tear down again)
-  uint64_t size, chunk_bytes, nchunks, buf_bytes;
+  uint64_t size, chunk_bytes, first_k, nchunks, buf_bytes;  // chunks first_k .. nchunks - 1 are wanted; the first FIRST of them come straight from the mapping
   int threads, device;
   std::mutex mu;
   std::condition_variable cv;
@@ -630,11 +630,11 @@ struct StagePool
   bool stop = false;
   std::string error;
 
-  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev)
-      : file(f), fd(fd_), size(n), chunk_bytes(cb), nchunks((n + cb - 1) / cb), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
+  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev, uint64_t k_first, uint64_t k_end)
+      : file(f), fd(fd_), size(n), chunk_bytes(cb), first_k(k_first), nchunks(k_end), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
   {
     for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
-    if (nchunks > FIRST) producer = std::thread([this] { run(); });
+    if (nchunks > first_k + FIRST) producer = std::thread([this] { run(); });
   }
   ~StagePool() { shutdown(); }
   void shutdown()
@@ -658,7 +658,7 @@ struct StagePool
   void run()
   {
     (void) hipSetDevice(device);
-    for (uint64_t k = FIRST; k < nchunks; ++k)
+    for (uint64_t k = first_k + FIRST; k < nchunks; ++k)
     {
       Buf &b = buf[k % NB];
       {
@@ -854,7 +854,23 @@ void grow_keep(DevBuf &b, size_t used, size_t need)
 // inflate of the ones before and the emit of the ones before those, and device memory holds those chunks plus the columns
 // whatever the size of the file.  The columns are sized from the first chunk (records per compressed byte x file size) and
 // grow by copying when that was too small.
-static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols, const FeedConsumer *fc = nullptr)
+// block start >= target reached by hopping over the block headers from the block start `off` (the end of the file counts as one)
+static void bgzf_hop_to(const uint8_t *file, uint64_t n, uint64_t &off, uint64_t target)
+{
+  std::vector<BgzfBlock> tmp;
+  std::string why;
+  uint64_t total = 0;
+  while (off < n && off < target)
+  {
+    tmp.clear();
+    if (!bgzf_scan_range(file, n, off, std::min<uint64_t>(target - off, 64u << 20), tmp, total, why)) throw bk_error(BK_ERR_IO, why);
+  }
+}
+
+// part / parts: only the BGZF blocks that start in [b_lo, b_hi) are decoded, b_x = the first block start at or behind
+// x / parts of the file - every one of `parts` callers finds the same boundaries, so the parts tile the file (one rank of a
+// sharded run each, bk_bam_decode_device_part).  Records of a block-aligned file never leave their block.
+static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols, const FeedConsumer *fc = nullptr, int part = 0, int parts = 1)
 {
   {
     const double t0 = now_s2();
@@ -896,8 +912,18 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, hdr_first_off);
     if (fc && fc->on_header) fc->on_header(fc->user, (int) h->names.size(), h->name_ptrs.data(), h->lens.data());
     uint64_t est_total = 0;
-    StagePool pool(file.data(), stage_from_mapping ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device);
-    uint64_t off = 0, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
+    uint64_t b_lo = 0, b_hi = file.size();
+    if (parts > 1)
+    {
+      uint64_t o = 0;
+      bgzf_hop_to(file.data(), file.size(), o, (uint64_t) ((unsigned __int128) file.size() * (unsigned) part / (unsigned) parts));
+      b_lo = o;
+      if (part + 1 < parts) bgzf_hop_to(file.data(), file.size(), o, (uint64_t) ((unsigned __int128) file.size() * (unsigned) (part + 1) / (unsigned) parts));
+      b_hi = part + 1 < parts ? o : file.size();
+    }
+    const uint64_t k0 = b_lo / chunk_bytes, k1 = b_hi > b_lo ? (b_hi + chunk_bytes - 1) / chunk_bytes : k0;  // chunks k0 .. k1 - 1
+    StagePool pool(file.data(), stage_from_mapping ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, k0, k1);
+    uint64_t off = b_lo, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
     double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0, t_launch = 0, t_emit = 0, t_slot_wait = 0;
     const double t_setup_done = now_s2();
     std::string why;
@@ -962,14 +988,14 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       s.first_off = 0;
       const double ts00 = now_s2();
       t_slot_wait += ts00 - tsw;
-      StagePool::Buf *sb = k >= StagePool::FIRST ? &pool.get(k) : nullptr;
+      StagePool::Buf *sb = k >= k0 + StagePool::FIRST ? &pool.get(k) : nullptr;
       const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
       const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
       const double ts0 = now_s2();
       t_stage_wait += ts0 - ts00;
       // the blocks that start inside [k C, (k + 1) C); offsets are relative to the start of the range
       uint64_t total = 0, rel = off - src_lo;
-      if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+      if (rel < chunk_bytes && off < b_hi && !bgzf_scan_range(fdata, src_n, rel, std::min(chunk_bytes - rel, b_hi - off), s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
       off = src_lo + rel;
       // blocks of the header hold no records; the first record's block starts at first_off
       while (s.first_blk < s.blocks.size() && src_lo + s.blocks[s.first_blk].in_off < first_in_off) ++s.first_blk;
@@ -1026,7 +1052,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       if (first && more)
       {
         // the rest of the file at the first chunk's densities, 5 % on top
-        const double scale = 1.05 * (double) file.size() / (double) std::max<uint64_t>(first_bytes, 1);
+        const double scale = 1.05 * (double) (b_hi - b_lo) / (double) std::max<uint64_t>(first_bytes, 1);
         reserve((uint64_t) (r * scale), (uint64_t) (g * scale), (uint64_t) (a * scale));
         est_total = (uint64_t) (r * scale);
       }
@@ -1053,16 +1079,17 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       t_emit += now_s2() - te0;
     };
     // the driver thread stages chunk ci, then takes the totals of chunk ci - LAG
-    const uint64_t nchunk = pool.nchunks;
+    const uint64_t nchunk = k1 - k0;
     for (uint64_t ci = 0; ci < nchunk + LAG; ++ci)
     {
-      if (ci < nchunk) stage(slot[ci % NS], ci);
-      if (ci == 0) first_bytes = off;
+      if (ci < nchunk) stage(slot[ci % NS], k0 + ci);
+      if (ci == 0) first_bytes = off - b_lo;
       if (ci >= LAG) finish(slot[(ci - LAG) % NS], ci == LAG, ci - LAG + 1 < nchunk);
     }
-    if (off != file.size()) throw bk_error(BK_ERR_IO, "BGZF blocks do not end at the end of the file");
+    if (off != b_hi) throw bk_error(BK_ERR_IO, "BGZF blocks do not end at the end of the file");
     const double t_end_loop = now_s2();
-    reserve(n_rec, n_cig, n_aux);  // (an empty file still gets its end entries)
+    if (cap_rec == 0) reserve(n_rec + 1, n_cig + 1, n_aux + 1);  // no record at all (an empty part): the columns exist all the same, with their end entries
+    reserve(n_rec, n_cig, n_aux);
     sync_all();
     const uint32_t ends[2] = {(uint32_t) n_cig, (uint32_t) n_aux};
     HIP_CHECK(hipMemcpy(c.cigar_off + n_rec, &ends[0], 4, hipMemcpyHostToDevice));
@@ -1452,11 +1479,11 @@ static bool first_block_is_record_aligned(const MappedFile &file)
 extern "C" int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                                     char *err, size_t errlen)
 {
-  return bam_decode_device_impl(path, device, out, cols, n_targets, names, lens, err, errlen, nullptr);
+  return bam_decode_device_impl(path, device, out, cols, n_targets, names, lens, err, errlen, nullptr, 0, 1);
 }
 
 int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens, char *err,
-                           size_t errlen, const FeedConsumer *fc)
+                           size_t errlen, const FeedConsumer *fc, int part, int parts)
 {
   bk_bam_dev *h = nullptr;
   try
@@ -1466,15 +1493,19 @@ int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_so
     HIP_CHECK(hipSetDevice(device));
     MappedFile file(path);  // mapped, not read: the header hop touches 18 bytes per block and the H2D copies stream the rest
     h = new bk_bam_dev();
+    if (parts < 1 || part < 0 || part >= parts) throw bk_error(BK_ERR_ARG, "bk_bam_decode_device_part: part must lie in [0, parts)");
     bool packed = !first_block_is_record_aligned(file);
+    // a part of a file can only be cut at BGZF blocks that start with a record
+    if (packed && parts > 1) throw bk_error(BK_ERR_IO, "records run across BGZF blocks: a part of this file cannot be decoded on its own (use the host decoder)");
     if (!packed)
     {
       try
       {
-        decode_chunked(file, device, h, cols, fc);
+        decode_chunked(file, device, h, cols, fc, part, parts);
       }
       catch (const not_block_aligned &)
       {
+        if (parts > 1) throw bk_error(BK_ERR_IO, "records run across BGZF blocks: a part of this file cannot be decoded on its own (use the host decoder)");
         HIP_CHECK(hipDeviceSynchronize());
         if (fc && fc->on_reset) fc->on_reset(fc->user);
         delete h;
@@ -1517,6 +1548,12 @@ int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_so
     if (err && errlen) snprintf(err, errlen, "%s", ex.what());
     return ex.code;
   }
+}
+
+extern "C" int bk_bam_decode_device_part(const char *path, int device, int part, int parts, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names,
+                                         const uint32_t **lens, char *err, size_t errlen)
+{
+  return bam_decode_device_impl(path, device, out, cols, n_targets, names, lens, err, errlen, nullptr, part, parts);
 }
 
 extern "C" void bk_bam_dev_free(bk_bam_dev *h) { delete h; }

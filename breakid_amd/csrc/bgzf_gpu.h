@@ -39,4 +39,4 @@ struct FeedConsumer
   void (*on_reset)(void *user) = nullptr;
 };
 int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens, char *err,
-                           size_t errlen, const FeedConsumer *fc);
+                           size_t errlen, const FeedConsumer *fc, int part = 0, int parts = 1);

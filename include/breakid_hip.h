@@ -273,6 +273,13 @@ void bk_bam_close(bk_bam *b);
 typedef struct bk_bam_dev bk_bam_dev;
 int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                          char *err, size_t errlen);
+/* One part of a file whose records stay inside their BGZF blocks: the blocks that start in [b(part), b(part + 1)), where b(k)
+ * is the first block start at or behind k / parts of the file's bytes (found by hopping over the block headers, so every caller
+ * finds the same boundaries and the parts tile the file) - the record range of one rank of a sharded run (bk_shard_*), decoded on
+ * that rank's own GPU; the ranks' record counts give their rec_base.  The header is parsed by every part.  BK_ERR_IO for files
+ * whose records run across blocks (they have no such cut points: take the host decoder). */
+int bk_bam_decode_device_part(const char *path, int device, int part, int parts, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names,
+                              const uint32_t **lens, char *err, size_t errlen);
 void bk_bam_dev_free(bk_bam_dev *h);
 /* Feed and hot path overlapped: the reference reads the BAM twice, one pass after the other (BreakID.cc:1929,
  * :1414); here the file is read once, and the record-level kernel of the hot path (insert-size sums, discordant filter,
