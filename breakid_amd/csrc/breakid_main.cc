@@ -338,14 +338,9 @@ int main(int argc, char *argv[])
     }
     fclose(probe);
   }
-  const bool multi = n_gpus >= 1;  // the sharded run takes the host table and splits it over the ranks
+  const bool multi = n_gpus >= 1;  // the sharded run: every rank decodes its part of the file on its own GPU (below), or takes its range of the host table
   bk_ctx *ctx = nullptr;
-  // one read of the file: BGZF inflate + record decode on the device, the stream pass of the hot path running on the chunks
-  // already decoded while the rest of the file is still arriving (the reference reads the BAM twice, BreakID.cc:1929, :1414)
-  if (!multi && !getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device_ctx(inp_file.c_str(), device, qual, &dbam, &ctx, &nt, &names, &lens, err, sizeof err) == BK_OK)
-    soa_where = BK_MEM_DEVICE;
-  else
-  {
+  auto host_decode = [&] {
     dbam = nullptr;
     if (bk_bam_open(inp_file.c_str(), &bam, err, sizeof err) != BK_OK)
     {
@@ -358,7 +353,14 @@ int main(int argc, char *argv[])
       std::cerr << "Error: " << err << std::endl;
       exit(1);
     }
-  }
+  };
+  const bool multi_from_file = multi && !getenv("BREAKID_HOST_DECODE");
+  // one read of the file: BGZF inflate + record decode on the device, the stream pass of the hot path running on the chunks
+  // already decoded while the rest of the file is still arriving (the reference reads the BAM twice, BreakID.cc:1929, :1414)
+  if (!multi && !getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device_ctx(inp_file.c_str(), device, qual, &dbam, &ctx, &nt, &names, &lens, err, sizeof err) == BK_OK)
+    soa_where = BK_MEM_DEVICE;
+  else if (!multi_from_file)
+    host_decode();
   {
     std::ifstream rn((nib_dir + "/ref_names.txt").c_str());
     if (!rn.is_open())
@@ -387,7 +389,15 @@ int main(int argc, char *argv[])
   if (multi)
   {
     // one sample over n_gpus GPUs: record ranges per rank, RCCL (or in-process) exchange of the small tables
-    rc = bk_multi_run(&soa, lens, names, nt, n_gpus, transport, qual, fast ? 1 : 0, &w, &n_clustered, &ctx, err, sizeof err);
+    // the GPU feed per rank first (bk_bam_decode_device_part); files it cannot cut into parts (records across BGZF blocks) and
+    // anything else it refuses go through the host decoder and the record ranges of its table
+    rc = BK_ERR_IO;
+    if (multi_from_file) rc = bk_multi_run_bam(inp_file.c_str(), n_gpus, transport, qual, fast ? 1 : 0, &w, &n_clustered, &ctx, &nt, &names, &lens, err, sizeof err);
+    if (rc != BK_OK && (!multi_from_file || rc == BK_ERR_IO || rc == BK_ERR_LIMIT))
+    {
+      host_decode();
+      rc = bk_multi_run(&soa, lens, names, nt, n_gpus, transport, qual, fast ? 1 : 0, &w, &n_clustered, &ctx, err, sizeof err);
+    }
     if (rc != BK_OK)
     {
       std::cerr << (rc == BK_ERR_CIGAR ? "error cigar: " : err) << std::endl;

@@ -416,21 +416,31 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
 }
 }  // namespace
 
-extern "C" int bk_multi_run(const bk_soa *tab, const uint32_t *target_len, const char *const *target_name, int n_targets, int n_gpus, int transport, int mapq_min, int fast,
-                            double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, char *err, size_t errlen)
+// the orchestration both entry points share: W rank threads, each with its transport and its context; `load` gives rank r's
+// context its records (and creates the context: the host-table entry knows the targets up front, the BAM entry learns them
+// from the file) and returns the rank's record count; the counts give every rank its rec_base.
+namespace
+{
+struct RankInput
+{
+  bk_ctx *ctx = nullptr;
+  uint64_t n = 0;
+};
+template <class Load, class Release>
+int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, char *err, size_t errlen, const char *who,
+                     Load &&load, Release &&release_rank)
 {
   auto fail = [&](int code, const std::string &m) {
     if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
     return code;
   };
-  if (!tab || !ctx0_out || n_gpus < 1 || n_gpus > 64) return fail(BK_ERR_ARG, "bk_multi_run: bad arguments");
+  if (!ctx0_out || n_gpus < 1 || n_gpus > 64) return fail(BK_ERR_ARG, std::string(who) + ": bad arguments");
   *ctx0_out = nullptr;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_ERR_NO_DEVICE, "bk_multi_run: no HIP device (this library has no CPU path)");
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_ERR_NO_DEVICE, std::string(who) + ": no HIP device (this library has no CPU path)");
   if (transport == BK_TRANSPORT_AUTO) transport = ndev >= n_gpus ? BK_TRANSPORT_RCCL : BK_TRANSPORT_LOCAL;
-  if (transport == BK_TRANSPORT_RCCL && ndev < n_gpus) return fail(BK_ERR_ARG, "bk_multi_run: RCCL needs one device per rank (use --comm local to share a GPU)");
+  if (transport == BK_TRANSPORT_RCCL && ndev < n_gpus) return fail(BK_ERR_ARG, std::string(who) + ": RCCL needs one device per rank (use --comm local to share a GPU)");
   const int W = n_gpus;
-  const uint64_t n = tab->n;
   std::vector<bk_ctx *> ctxs(W, nullptr);
   std::vector<std::string> errs(W);
   std::vector<int> codes(W, BK_OK);
@@ -443,7 +453,6 @@ extern "C" int bk_multi_run(const bk_soa *tab, const uint32_t *target_len, const
   std::vector<std::thread> th;
   for (int r = 0; r < W; ++r)
     th.emplace_back([&, r] {
-      bk_ctx *ctx = nullptr;
       std::unique_ptr<Transport> T;
       try
       {
@@ -465,29 +474,17 @@ extern "C" int bk_multi_run(const bk_soa *tab, const uint32_t *target_len, const
           t->world = W;
           t->hub = &hub;
         }
-        if (bk_init(dev, target_len, target_name, n_targets, &ctx) != BK_OK) throw bk_error(BK_ERR_NO_DEVICE, bk_last_error(nullptr));
+        const RankInput in = load(r, W, dev);
+        bk_ctx *ctx = in.ctx;
         ctxs[r] = ctx;
-        // contiguous record range of this rank; the CIGAR / aux offsets of a slice are rebased to its own blobs
-        const uint64_t lo = n * r / W, hi = n * (r + 1) / W, m = hi - lo;
-        std::vector<uint32_t> coff(m + 1), aoff(m + 1);
-        const uint32_t c0 = n ? tab->cigar_off[lo] : 0, a0 = n ? tab->aux_off[lo] : 0;
-        for (uint64_t i = 0; i <= m; ++i)
-        {
-          coff[i] = (n ? tab->cigar_off[lo + i] : 0) - c0;
-          aoff[i] = (n ? tab->aux_off[lo + i] : 0) - a0;
-        }
-        bk_soa s = *tab;
-        s.n = m;
-        s.tid += lo; s.pos += lo; s.mtid += lo; s.mpos += lo; s.isize += lo; s.flag += lo; s.mapq += lo; s.qhash += lo;
-        if (s.qcheck) s.qcheck += lo;
-        s.cigar_off = coff.data();
-        s.aux_off = aoff.data();
-        s.cigar = tab->cigar + c0;
-        s.aux = tab->aux + a0;
-        s.n_cigar_words = coff[m];
-        s.n_aux_bytes = aoff[m];
-        BK_CALL(bk_upload_records(ctx, &s, BK_MEM_HOST));
-        run_rank(ctx, *T, lo, mapq_min, fast, &ws[r], &ncl[r], keeps[r]);
+        // rec_base = records of the ranks in front of this one
+        void *stv = nullptr;
+        BK_CALL(bk_get_stream(ctx, &stv));
+        std::vector<uint64_t> counts(W);
+        T->allgather_host(&in.n, 8, counts.data(), (hipStream_t) stv);
+        uint64_t base = 0;
+        for (int k = 0; k < r; ++k) base += counts[k];
+        run_rank(in.ctx, *T, base, mapq_min, fast, &ws[r], &ncl[r], keeps[r]);
       }
       catch (const bk_error &e)
       {
@@ -513,17 +510,116 @@ extern "C" int bk_multi_run(const bk_soa *tab, const uint32_t *target_len, const
     }
   // the gathered tables a context points at must outlive it: they are released after every context
   for (int r = 1; r < W; ++r)
+  {
     if (ctxs[r]) bk_free(ctxs[r]);
+    release_rank(r);
+  }
   if (rc != BK_OK)
   {
     if (ctxs[0]) bk_free(ctxs[0]);
+    release_rank(0);
     return fail(rc, msg);
   }
-  // rank 0's context keeps pointing at its gathered tables: hand their ownership to a registry that lives as long as the process
+  // rank 0's context keeps pointing at its gathered tables (and at its records): their ownership goes to a registry that lives
+  // as long as the process
   static std::vector<Keep> *registry = new std::vector<Keep>();
   registry->push_back(std::move(keeps[0]));
   if (w_out) *w_out = ws[0];
   if (n_clustered_total) *n_clustered_total = ncl[0];
   *ctx0_out = ctxs[0];
   return BK_OK;
+}
+}  // namespace
+
+extern "C" int bk_multi_run(const bk_soa *tab, const uint32_t *target_len, const char *const *target_name, int n_targets, int n_gpus, int transport, int mapq_min, int fast,
+                            double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, char *err, size_t errlen)
+{
+  if (!tab)
+  {
+    if (err && errlen) snprintf(err, errlen, "bk_multi_run: bad arguments");
+    return BK_ERR_ARG;
+  }
+  const uint64_t n = tab->n;
+  auto load = [&](int r, int W, int dev) {
+    RankInput in;
+    if (bk_init(dev, target_len, target_name, n_targets, &in.ctx) != BK_OK) throw bk_error(BK_ERR_NO_DEVICE, bk_last_error(nullptr));
+    // contiguous record range of this rank; the CIGAR / aux offsets of a slice are rebased to its own blobs
+    const uint64_t lo = n * r / W, hi = n * (r + 1) / W, m = hi - lo;
+    std::vector<uint32_t> coff(m + 1), aoff(m + 1);
+    const uint32_t c0 = n ? tab->cigar_off[lo] : 0, a0 = n ? tab->aux_off[lo] : 0;
+    for (uint64_t i = 0; i <= m; ++i)
+    {
+      coff[i] = (n ? tab->cigar_off[lo + i] : 0) - c0;
+      aoff[i] = (n ? tab->aux_off[lo + i] : 0) - a0;
+    }
+    bk_soa s = *tab;
+    s.n = m;
+    s.tid += lo; s.pos += lo; s.mtid += lo; s.mpos += lo; s.isize += lo; s.flag += lo; s.mapq += lo; s.qhash += lo;
+    if (s.qcheck) s.qcheck += lo;
+    s.cigar_off = coff.data();
+    s.aux_off = aoff.data();
+    s.cigar = tab->cigar + c0;
+    s.aux = tab->aux + a0;
+    s.n_cigar_words = coff[m];
+    s.n_aux_bytes = aoff[m];
+    const int urc = bk_upload_records(in.ctx, &s, BK_MEM_HOST);
+    if (urc != BK_OK)
+    {
+      const bk_error e(urc, bk_last_error(in.ctx));
+      bk_free(in.ctx);
+      throw e;
+    }
+    in.n = m;
+    return in;
+  };
+  return multi_run_common(n_gpus, transport, mapq_min, fast, w_out, n_clustered_total, ctx0_out, err, errlen, "bk_multi_run", load, [](int) {});
+}
+
+// the same with every rank decoding its own part of the file on its own GPU (bk_bam_decode_device_part)
+extern "C" int bk_multi_run_bam(const char *path, int n_gpus, int transport, int mapq_min, int fast, double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out,
+                                int *n_targets, const char *const **names, const uint32_t **lens, char *err, size_t errlen)
+{
+  if (!path || n_gpus < 1 || n_gpus > 64)
+  {
+    if (err && errlen) snprintf(err, errlen, "bk_multi_run_bam: bad arguments");
+    return BK_ERR_ARG;
+  }
+  std::vector<bk_bam_dev *> bams(n_gpus, nullptr);
+  std::vector<int> nts(n_gpus, 0);
+  std::vector<const char *const *> nms(n_gpus, nullptr);
+  std::vector<const uint32_t *> lns(n_gpus, nullptr);
+  auto load = [&](int r, int W, int dev) {
+    RankInput in;
+    bk_soa cols;
+    char e[512] = {0};
+    const int drc = bk_bam_decode_device_part(path, dev, r, W, &bams[r], &cols, &nts[r], &nms[r], &lns[r], e, sizeof e);
+    if (drc != BK_OK) throw bk_error(drc, e);
+    if (bk_init(dev, lns[r], nms[r], nts[r], &in.ctx) != BK_OK) throw bk_error(BK_ERR_NO_DEVICE, bk_last_error(nullptr));
+    const int urc = bk_upload_records(in.ctx, &cols, BK_MEM_DEVICE);
+    if (urc != BK_OK)
+    {
+      const bk_error ex(urc, bk_last_error(in.ctx));
+      bk_free(in.ctx);
+      throw ex;
+    }
+    in.n = cols.n;
+    return in;
+  };
+  // the records of a rank live in its bk_bam_dev: released behind its context (multi_run_common does that for rank 0 only when
+  // the run failed: after a good run rank 0's records stay with the context that is handed out, for the life of the process)
+  static std::vector<bk_bam_dev *> *kept = new std::vector<bk_bam_dev *>();
+  auto release_rank = [&](int r) {
+    if (bams[r]) bk_bam_dev_free(bams[r]);
+    bams[r] = nullptr;
+  };
+  const int rc = multi_run_common(n_gpus, transport, mapq_min, fast, w_out, n_clustered_total, ctx0_out, err, errlen, "bk_multi_run_bam", load, release_rank);
+  const bool ok = rc == BK_OK;
+  if (ok)
+  {
+    kept->push_back(bams[0]);
+    if (n_targets) *n_targets = nts[0];
+    if (names) *names = nms[0];
+    if (lens) *lens = lns[0];
+  }
+  return rc;
 }

@@ -13,7 +13,8 @@
  *   BK_TRANSPORT_LOCAL  the same sequence between contexts of one process by device-to-device copies (several contexts may
  *                       share one GPU: this is how a single-GPU box exercises the N-rank code path; RCCL refuses two ranks
  *                       on one device).
- * The BreakID command line reaches it through `--gpus N [--comm rccl|local]`.
+ * The BreakID command line reaches it through `--gpus N [--comm rccl|local]` (bk_multi_run_bam, falling back to the host
+ * decoder + bk_multi_run).
  */
 #ifndef BREAKID_MULTI_H
 #define BREAKID_MULTI_H
@@ -34,6 +35,13 @@ extern "C" {
  * n_clustered_total = pairs that survived clustering over all groups (what decides whether the index / refGene are opened). */
 int bk_multi_run(const bk_soa *host_table, const uint32_t *target_len, const char *const *target_name, int n_targets, int n_gpus, int transport, int mapq_min,
                  int fast, double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, char *err, size_t errlen);
+
+/* The same from the file: rank r decodes part r of n_gpus of the BAM on its own GPU (bk_bam_decode_device_part: BGZF inflate and
+ * record decode on the device, no host table) and takes the records in place; the ranks' record counts give their rec_base.
+ * n_targets / names / lens receive the file's reference list (owned by the library, valid for the life of the process).
+ * BK_ERR_IO for files whose records run across BGZF blocks (no cut points): decode on the host and call bk_multi_run then. */
+int bk_multi_run_bam(const char *path, int n_gpus, int transport, int mapq_min, int fast, double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, int *n_targets,
+                     const char *const **names, const uint32_t **lens, char *err, size_t errlen);
 
 #ifdef __cplusplus
 }

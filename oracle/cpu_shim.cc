@@ -159,8 +159,19 @@ int bk_bam_decode_device_ctx(const char *, int, int, bk_bam_dev **, bk_ctx **, i
   if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
   return BK_ERR_NO_DEVICE;
 }
+int bk_bam_decode_device_part(const char *, int, int, int, bk_bam_dev **, bk_soa *, int *, const char *const **, const uint32_t **, char *err, size_t errlen)
+{
+  if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
+  return BK_ERR_NO_DEVICE;
+}
 void bk_bam_dev_free(bk_bam_dev *) {}
 int bk_multi_run(const bk_soa *, const uint32_t *, const char *const *, int, int, int, int, int, double *, uint64_t *, bk_ctx **, char *err, size_t errlen)
+{
+  if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
+  return BK_ERR_NO_DEVICE;
+}
+
+int bk_multi_run_bam(const char *, int, int, int, int, double *, uint64_t *, bk_ctx **, int *, const char *const **, const uint32_t **, char *err, size_t errlen)
 {
   if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
   return BK_ERR_NO_DEVICE;

@@ -72,23 +72,33 @@ def test_cli_fatal_paths_match_the_reference_messages():
     check_fatal_paths(BIN)
 
 
-@pytest.mark.parametrize("name,mode,ranks,comm", [("small", "fast", 1, "rccl"), ("edge", "ahc", 1, "rccl"), ("small", "fast", 2, "local"), ("ties", "ahc", 2, "local"),
-                                                   ("edge", "fast", 3, "local"), ("g1", "fast", 4, "local")])
-def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, ranks, comm):
+@pytest.mark.parametrize("name,mode,ranks,comm,feed", [("small", "fast", 1, "rccl", "gpu"), ("edge", "ahc", 1, "rccl", "gpu"), ("small", "fast", 2, "local", "gpu"),
+                                                        ("ties", "ahc", 2, "local", "gpu"), ("edge", "fast", 3, "local", "gpu"), ("g1", "fast", 4, "local", "gpu"),
+                                                        ("g1", "fast", 5, "local", "gpu-small-chunks"), ("small", "fast", 2, "local", "host"), ("edge", "fast", 3, "local", "across"),
+                                                        ("ties", "ahc", 1, "rccl", "host")])
+def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, ranks, comm, feed):
     """`BreakID -gpus N`: one sample over N contexts, orchestrated in C++ (csrc/multi_gpu.hip, include/breakid_multi.h).
     -comm rccl issues the collectives through librccl directly (world size 1 on this one-GPU box: ncclAllGather / grouped
     ncclBroadcast / ncclSend+ncclRecv / ncclAllReduce all run); -comm local puts N contexts on one GPU and moves the same
     tables by device-to-device copies - the N-rank code path (record ranges, routed all-to-alls, LPT group ownership, vote
-    slices) against the reference's txt files."""
+    slices) against the reference's txt files.  feed: "gpu" = every rank decodes its part of the file on the GPU
+    (bk_multi_run_bam / bk_bam_decode_device_part; "-small-chunks": several feed chunks per part), "host" = the host decoder's
+    table cut into record ranges (bk_multi_run, BREAKID_HOST_DECODE=1), "across" = a file whose records run across BGZF blocks:
+    the GPU feed cannot cut it into parts and the command line falls back to the host decoder by itself."""
     ds, refgene = _dataset(name)
     with tempfile.TemporaryDirectory() as tmp:
         bam = os.path.join(tmp, name + ".bam")
-        ds.write_bam(bam, aligned=True)
+        ds.write_bam(bam, aligned=feed != "across")
         open(bam + ".bai", "wb").close()
         side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
         prefix = os.path.join(tmp, "out")
         cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all", "-gpus", str(ranks), "-comm", comm] + (["-fast"] if mode == "fast" else [])
-        r = subprocess.run(cmd, env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, BREAKID_INSTALLDIR=side["install"])
+        if feed == "host":
+            env["BREAKID_HOST_DECODE"] = "1"
+        if feed == "gpu-small-chunks":
+            env["BREAKID_FEED_CHUNK_MB"] = repr(os.path.getsize(bam) / 23 / 1048576.0)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         for suffix in ("_fusion.txt", "_fusion_all.txt"):
             got = open(prefix + suffix).read()
