@@ -1299,8 +1299,9 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   uint64_t chunk_bytes = 64ull << 20;
   if (const char *e = getenv("BREAKID_FEED_CHUNK_MB"))
     if (atof(e) > 0) chunk_bytes = (uint64_t) (atof(e) * 1048576.0);
-  chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000);
-  constexpr int NS = 3;
+  chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000) / 4096 * 4096 + 4096;  // a chunk is longer than the longest block
+  // the inflates run LAG chunks ahead of the record phases (which follow each other: a chunk starts with the carry of the one before)
+  constexpr int NS = 4, LAG = 2;
   PackedSlot slot[NS];
   for (auto &s : slot)
   {
@@ -1325,36 +1326,49 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   auto quiesce = [&]() {
     for (auto &s : slot) HIP_CHECK(hipStreamSynchronize(s.st));
   };
-  // chunk -> slot: hop over its block headers, copy, inflate behind the reserve
-  auto stage = [&](PackedSlot &s) {
+  int copy_threads = 8;
+  if (const char *e = getenv("BREAKID_THREADS"))
+    if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
+  // the bytes of chunk k = file range [k C, (k + 1) C + slack) arrive in page-locked staging buffers, read() by the pool's threads
+  // (the first three straight from the mapping while the buffers are being registered) - as in the aligned case
+  const uint64_t nchunks = (file.size() + chunk_bytes - 1) / chunk_bytes;
+  StagePool pool(file.data(), getenv("BREAKID_FEED_STAGE_MMAP") ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, 0, nchunks);
+  // chunk k -> slot: the blocks that start inside it: hop over their headers in the staged bytes, copy, inflate behind the reserve
+  auto stage = [&](PackedSlot &s, uint64_t k) {
     if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
     s.used = true;
     s.blocks.clear();
     s.total = 0;
     s.first_blk = 0;
     s.first_off = 0;
-    const uint64_t lo = off;
-    if (!bgzf_scan_range(file.data(), file.size(), off, chunk_bytes, s.blocks, s.total, why, 1)) throw bk_error(BK_ERR_IO, why);
+    StagePool::Buf *sb = k >= StagePool::FIRST ? &pool.get(k) : nullptr;
+    const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
+    const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
+    uint64_t rel = off - src_lo;  // offsets are relative to the start of the range from here on
+    if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, s.total, why, 1)) throw bk_error(BK_ERR_IO, why);
+    off = src_lo + rel;
     const uint32_t nb = (uint32_t) s.blocks.size();
     nblk_all += nb;
-    while (s.first_blk < nb && s.blocks[s.first_blk].in_off < first_in_off) ++s.first_blk;
-    if (s.first_blk < nb && s.blocks[s.first_blk].in_off == first_in_off) s.first_off = hdr_first_off;
-    for (auto &b : s.blocks)
+    while (s.first_blk < nb && src_lo + s.blocks[s.first_blk].in_off < first_in_off) ++s.first_blk;
+    if (s.first_blk < nb && src_lo + s.blocks[s.first_blk].in_off == first_in_off) s.first_off = hdr_first_off;
+    for (auto &b : s.blocks) b.out_off += PACKED_RESERVE;
+    s.file_hi = off;
+    if (nb == 0)
     {
-      b.in_off -= lo;
-      b.out_off += PACKED_RESERVE;
+      if (sb) pool.release(*sb, s.st);
+      return;
     }
-    uint8_t *df = s.dfile.as<uint8_t>(off - lo + 8);
+    uint8_t *df = s.dfile.as<uint8_t>(rel + 8);
     BgzfBlock *db = s.dblk.as<BgzfBlock>((uint64_t) nb + 1);
     uint8_t *dd = s.ddata.as<uint8_t>(PACKED_RESERVE + s.total + 64);
     uint32_t *de = s.derr.as<uint32_t>(1);
     uint8_t *slab = s.dslab.as<uint8_t>(bgzf_scratch_bytes(nb));
-    HIP_CHECK(hipMemcpyAsync(df, file.data() + lo, off - lo, hipMemcpyHostToDevice, s.st));
+    HIP_CHECK(hipMemcpyAsync(df, fdata, rel, hipMemcpyHostToDevice, s.st));
+    if (sb) pool.release(*sb, s.st);
     HIP_CHECK(hipMemcpyAsync(db, s.blocks.data(), (size_t) nb * sizeof(BgzfBlock), hipMemcpyHostToDevice, s.st));
     HIP_CHECK(hipMemsetAsync(de, 0, 4, s.st));
     HIP_CHECK(hipMemsetAsync(dd + PACKED_RESERVE + s.total, 0, 64, s.st));
     launch_bgzf_inflate(df, db, nb, dd, slab, de, s.st, true);
-    s.file_hi = off;
   };
   // the carry of the chunk before is known: boundaries, counts and totals of this chunk
   auto records = [&](PackedSlot &s, bool last) {
@@ -1427,19 +1441,16 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
     sink.n_cig = g;
     sink.n_aux = a;
   };
-  // the inflate of chunk c + 1 is queued before the host waits for the totals of chunk c
-  bool have = false;
-  int cur = 0;
-  while (off < file.size())
+  // the inflates of chunks c + 1 .. c + LAG are queued before the host waits for the totals of chunk c
+  nchunk = nchunks;
+  for (uint64_t k = 0; k < nchunks + LAG; ++k)
   {
-    const int nxt = (int) (nchunk % NS);
-    stage(slot[nxt]);
-    ++nchunk;
-    if (have) records(slot[cur], false);
-    cur = nxt;
-    have = true;
+    if (k < nchunks) stage(slot[k % NS], k);
+    // (the last chunk with blocks is the one whose hop reached the end of the file: chunks behind it hold no block start)
+    if (k >= (uint64_t) LAG) records(slot[(k - LAG) % NS], slot[(k - LAG) % NS].file_hi == file.size());
   }
-  if (have) records(slot[cur], true);
+  if (off != file.size()) throw bk_error(BK_ERR_IO, "BGZF blocks do not end at the end of the file");
+  if (carry_len) throw bk_error(BK_ERR_IO, "truncated BAM record at the end of the file");
   sink.reserve(sink.n_rec, sink.n_cig, sink.n_aux, quiesce);
   quiesce();
   sink.finish(cols);
@@ -1515,24 +1526,27 @@ int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_so
     }
     if (packed)
     {
-      // one batch when file image + inflated stream fit in HBM (BREAKID_FEED_PACKED_CHUNKS=1: always in chunks)
-      bool in_chunks = getenv("BREAKID_FEED_PACKED_CHUNKS") != nullptr;
-      if (!in_chunks)
+      // in chunks (the faster variant since its inflates run ahead of the record phases: 75-93 ms against 170 for the 1 GB test
+      // file); as one batch - file image + inflated stream in HBM - when a record longer than the 8 MiB reserve crosses a chunk
+      // (BK_ERR_LIMIT) or BREAKID_FEED_PACKED_BATCH=1 asks for it; BREAKID_FEED_PACKED_CHUNKS=1: in chunks or not at all
+      const bool force_chunks = getenv("BREAKID_FEED_PACKED_CHUNKS") != nullptr;
+      bool batch = !force_chunks && getenv("BREAKID_FEED_PACKED_BATCH") != nullptr;
+      if (!batch)
       {
         try
         {
-          decode_packed(file, device, h, cols);
+          decode_packed_chunked(file, device, h, cols);
         }
         catch (const bk_error &e)
         {
-          if (e.code != BK_ERR_LIMIT) throw;
+          if (e.code != BK_ERR_LIMIT || force_chunks) throw;
           HIP_CHECK(hipDeviceSynchronize());
           delete h;
           h = new bk_bam_dev();
-          in_chunks = true;
+          batch = true;
         }
       }
-      if (in_chunks) decode_packed_chunked(file, device, h, cols);
+      if (batch) decode_packed(file, device, h, cols);
     }
     if (packed && fc && fc->on_header) fc->on_header(fc->user, (int) h->names.size(), h->name_ptrs.data(), h->lens.data());
     if (n_targets) *n_targets = (int) h->names.size();

@@ -264,12 +264,13 @@ void bk_bam_close(bk_bam *b);
 
 /* The same feed on the GPU: BGZF blocks are inflated on the device (bgzf_gpu.hip) and the records are decoded into
  * device-resident columns (cols holds device pointers: bk_upload_records(ctx, cols, BK_MEM_DEVICE)).
- * Files whose records stay inside their BGZF blocks (htslib / samtools writers) are mapped and streamed in chunks
- * (BREAKID_FEED_CHUNK_MB, default 64-128 MiB, up to four in flight): device memory holds the chunks in flight and the
+ * Files whose records stay inside their BGZF blocks (htslib / samtools writers) are streamed in chunks
+ * (BREAKID_FEED_CHUNK_MB, default 32-64 MiB, four to eight in flight): device memory holds the chunks in flight and the
  * columns.  Files whose records run across blocks (htsjdk / Picard / GATK writers, long reads): record boundaries are
- * guessed per block and verified to chain; one batch (file image + inflated stream in HBM) when that fits, else in chunks
- * that start at the record carried over from the chunk before.  BK_ERR_IO when the boundaries cannot be established,
- * BK_ERR_LIMIT when a record longer than 8 MiB crosses a chunk - take bk_bam_open / bk_bam_decode then. */
+ * guessed per block and verified to chain, in chunks that start at the record carried over from the chunk before; a record
+ * longer than 8 MiB that crosses a chunk sends the file to a one-batch variant (file image + inflated stream in HBM).
+ * BK_ERR_IO when the boundaries cannot be established, BK_ERR_LIMIT when neither variant can take the file - take
+ * bk_bam_open / bk_bam_decode then. */
 typedef struct bk_bam_dev bk_bam_dev;
 int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names, const uint32_t **lens,
                          char *err, size_t errlen);

@@ -67,13 +67,23 @@ def test_device_decode_matches_generator_and_pipeline():
     table.close()
 
 
-def test_device_decode_of_records_across_blocks_and_of_the_golden_shapes():
+@pytest.fixture(params=["chunks", "batch"])
+def packed_variant(request, monkeypatch):
+    """files whose records run across BGZF blocks are decoded in chunks (the default: a chunk starts with the record carried
+    over from the one before) or, BREAKID_FEED_PACKED_BATCH=1, as one batch (also what the chunked variant falls back to when a
+    record longer than 8 MiB crosses a chunk)"""
+    if request.param == "batch":
+        monkeypatch.setenv("BREAKID_FEED_PACKED_BATCH", "1")
+    return request.param
+
+
+def test_device_decode_of_records_across_blocks_and_of_the_golden_shapes(packed_variant):
     contigs, ds = _dataset()
     ref = ds.to_soa()
     with tempfile.TemporaryDirectory() as t:
         p = os.path.join(t, "u.bam")
         ds.write_bam(p)                 # fixed-size blocks: records straddle them (htsjdk / Picard style)
-        table = capi.decode_bam_device(p)   # one batch: record boundaries guessed per block, verified to chain
+        table = capi.decode_bam_device(p)   # record boundaries guessed per block, verified to chain
         got = _device_cols(table)
         assert table.contigs == contigs
         for k, _ in abi.SOA_COLS_ALL:
@@ -315,7 +325,7 @@ def test_parts_of_a_file_tile_its_record_table(parts):
         assert e.value.code == abi.BK_ERR_ARG
 
 
-def test_device_decode_of_records_longer_than_a_block():
+def test_device_decode_of_records_longer_than_a_block(packed_variant):
     """long reads: a record spans several BGZF blocks, some blocks hold no record start at all"""
     from breakid_amd import bamio
     contigs = [("chr1", 3_000_000), ("chr2", 2_000_000)]
