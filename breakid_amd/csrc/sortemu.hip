@@ -901,7 +901,10 @@ __device__ __forceinline__ void sort_heap_lds_q(uint32_t *slot1, const uint32_t 
 //     (if that leaf is L, the value is also the leaf of the next launch); a lane whose children are in O loads them from
 //     there (slots beyond m read the zeros behind the heap) over the zeros its clamped LDS read returned;
 //   * the leaf to detach is in O: it is requested right after the launch before (two to three iterations ahead of its use)
-//     and zeroed there by the launch.
+//     and zeroed there by the launch.  When a lane finishes ON that leaf meanwhile, its value replaces the requested one in
+//     v58 - behind a wait for the request, which would otherwise land in v58 afterwards with the slot's old content (the
+//     hardware does not order a load's register write against a later VALU write: one payload lost, another doubled, in a few
+//     per cent of the runs over a 53 K-element heap before this wait was there).
 // Runs the m - CAP pops that bring the heap down to CAP slots, waits for the pops in flight and returns; the caller carries
 // on with sort_heap_lds_q on the LDS part.  0.6 us per pop (everything in global memory) -> ~0.25.
 #define BK_HEAP32H_SLOW(TAG)                                                                                                  \
@@ -919,6 +922,7 @@ __device__ __forceinline__ void sort_heap_lds_q(uint32_t *slot1, const uint32_t 
   "s_ff1_i32_b64 s70, s[54:55]\n"                                                                                          \
   "s_nop 3\n"                                                                                                              \
   "v_readlane_b32 s69, v71, s70\n"                                                                                         \
+  "s_waitcnt vmcnt(0)\n"                                                                                                   \
   "v_mov_b32 v58, s69\n"                                                                                                   \
   "BK_HS1_" TAG "_%=:\n"                                                                                                          \
   "v_cmp_lt_u32_e64 s[50:51], s66, v40\n"                                                                                  \
@@ -2056,6 +2060,59 @@ __global__ __launch_bounds__(256) void k_se_window_sort(uint32_t *__restrict__ k
 }
 }  // namespace
 
+// BK_SORT_CHECK=1 (debugging): is idx still a permutation of 0 .. n-1 and does every element still carry its own key?
+// (callers whose idx is not such a permutation must not set it)
+__global__ __launch_bounds__(256) void k_chk_count(const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ cnt, uint32_t *__restrict__ bad)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t x = idx[p];
+  if (x >= n)
+  {
+    atomicAdd(&bad[0], 1u);
+    atomicMin(&bad[2], p);
+    return;
+  }
+  if (atomicAdd(&cnt[x], 1u) != 0u)
+  {
+    atomicAdd(&bad[1], 1u);
+    atomicMin(&bad[3], p);
+  }
+}
+__global__ __launch_bounds__(256) void k_chk_keys(const uint32_t *__restrict__ key, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ key0, uint32_t n, uint32_t *__restrict__ bad)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t x = idx[p];
+  if (x < n && key0[x] != key[p])
+  {
+    atomicAdd(&bad[4], 1u);
+    atomicMin(&bad[5], p);
+  }
+}
+static void sort_check(const char *phase, const uint32_t *key, const uint32_t *idx, const uint32_t *key0, uint32_t n, const uint64_t *goff, uint32_t ng, hipStream_t st)
+{
+  static DevBuf cnt, bad;
+  uint32_t *c = cnt.as<uint32_t>(n), *bd = bad.as<uint32_t>(8);
+  const uint32_t init[8] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0, 0};
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemset(c, 0, (size_t) n * 4));
+  HIP_CHECK(hipMemcpy(bd, init, 32, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_chk_count, dim3(cdiv(n, 256)), dim3(256), 0, st, idx, n, c, bd);
+  hipLaunchKernelGGL(k_chk_keys, dim3(cdiv(n, 256)), dim3(256), 0, st, key, idx, key0, n, bd);
+  uint32_t h[8];
+  HIP_CHECK(hipMemcpyAsync(h, bd, 32, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (h[0] || h[1] || h[4])
+  {
+    std::vector<uint64_t> go((size_t) ng + 1);
+    HIP_CHECK(hipMemcpy(go.data(), goff, ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost));
+    auto grp = [&](uint32_t p) { return p == 0xFFFFFFFFu ? -1 : (int) (std::upper_bound(go.begin(), go.end(), (uint64_t) p) - go.begin()) - 1; };
+    fprintf(stderr, "[sortemu] CHECK FAILED %s: %u payloads out of range (first at %u), %u duplicated payloads (first at position %u, group %d), %u elements whose key is not their own (first at %u, group %d); n=%u\n",
+            phase, h[0], h[2], h[1], h[3], grp(h[3]), h[4], h[5], grp(h[5]), n);
+  }
+}
+
 void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const uint64_t *goff, uint32_t ng, uint64_t n64, SortEmuBufs &b, hipStream_t st)
 {
   if (n64 == 0 || ng == 0) return;
@@ -2070,6 +2127,22 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     pipe_flag_set = true;
   }
   const uint32_t n = (uint32_t) n64;
+  static const bool chk = getenv("BK_SORT_CHECK") != nullptr;
+  static DevBuf chk_key0, chk_idx0;
+  uint32_t *key0 = nullptr;
+  if (chk)
+  {
+    // key0[idx] = the key that belongs to payload idx (as the sort receives them)
+    key0 = chk_key0.as<uint32_t>(n);
+    std::vector<uint32_t> hk(n), hx(n), k0(n);
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpy(hk.data(), key, (size_t) n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hx.data(), idx, (size_t) n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+      if (hx[i] < n) k0[hx[i]] = hk[i];
+    HIP_CHECK(hipMemcpy(key0, k0.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+    sort_check("at entry", key, idx, key0, n, goff, ng, st);
+  }
   unsigned long long *cnt = b.cnt.as<unsigned long long>((uint64_t) (n / 8 + ng) + 32);
   if (const char *dump = getenv("BK_DEBUG_SORT_DUMP"))
   {
@@ -2232,6 +2305,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
+  if (chk) sort_check("after the partition levels", key, idx, key0, n, goff, ng, st);
   // What is left: (1) segments of at most FIN_MAX elements - the rest of their introsort loop runs in LDS, one workgroup
   // each (the finisher; it may add small segments to the heap list) - and (2) the segments that exhausted introsort's
   // depth limit in the level loop, which are heapsorted (they are final: no children).  The longest heap segment is the
@@ -2453,6 +2527,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   }
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
+  if (chk) sort_check("after the heaps and the finisher", key, idx, key0, n, goff, ng, st);
   // __final_insertion_sort == stable sort by key of what the introsort loop left: two tilings of 32-element windows
   static const bool radix_final = getenv("BK_FINAL_RADIX") != nullptr;  // the general stable radix sort (debugging)
   if (!radix_final)

@@ -268,6 +268,21 @@ def test_std_sort_emulation_matches_libstdcxx(case):
     ctx.close()
 
 
+def test_heap_beyond_the_lds_gives_the_same_order_every_time():
+    """A 53 325-element heap segment (killer of 233 512 elements with ties: LDS part + leaves in global memory) sorted 200 times:
+    the order must be libstdc++'s every time.  (A lane that finishes ON the leaf the next pop detaches hands its value over in a
+    register; without a wait for the earlier request of that leaf from memory the request landed afterwards with the slot's
+    old content - one payload lost, one doubled, in 2-4 % of the runs.)"""
+    key = _median3_killer(233512, 3)[:233512]
+    off = np.array([0, len(key)], np.uint64)
+    exp = pyoracle.unit_std_sort(key, off)
+    ctx = capi.Context([("chr1", 1000)])
+    for rep in range(200):
+        got = ctx.debug_std_sort(key, off)
+        assert np.array_equal(got, exp), (rep, int((got != exp).sum()), bool(np.array_equal(np.sort(got), np.arange(len(key)))))
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", DATASETS)
 def test_ahc_matches_reference_dump_and_oracle(golden_dir, name):
     contigs, cols = refdump.load_soa(golden_dir, name)

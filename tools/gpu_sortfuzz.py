@@ -68,4 +68,6 @@ for case in range(cases):
     if not np.array_equal(got, exp):
         bad += 1
         print("MISMATCH case", case, "sizes", sizes, "first diff", np.nonzero(got != exp)[0][:5], flush=True)
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez_compressed("gpurun_out/sortfuzz_fail_%d.npz" % case, key=key, off=off, got=got, exp=exp)
 print("sort fuzz done: %d cases, %d bad" % (cases, bad), flush=True)
