@@ -593,6 +593,15 @@ int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, 
     }
     {
       Scope s(ctx, "mate_join");
+      // discovery indices are record indices: of this table when the candidates are its own, of the whole sample (32 bits) when
+      // they came from other shards
+      ctx->jb.rec_bits = 32;
+      if (!ctx->ext_cand && ctx->rec_base == 0)
+      {
+        int bits = 1;
+        while (bits < 32 && (1ull << bits) < ctx->rec.n) ++bits;
+        ctx->jb.rec_bits = bits;
+      }
       join_candidates(ctx->cand_ptr(), ctx->hc.n_cand, w, ctx->d_tprefix.get<uint32_t>(), ctx->nt, ctx->jb, ctx->st, ctx->jr);
     }
     finish_groups(ctx, nullptr);

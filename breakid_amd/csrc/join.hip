@@ -125,7 +125,7 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
 __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ cand, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, double w,
                                                     const uint32_t *__restrict__ tprefix, int32_t nt, bk_pair *__restrict__ out, uint64_t *__restrict__ okey,
                                                     uint32_t *__restrict__ oval, unsigned long long cap, unsigned long long *__restrict__ counter,
-                                                    uint32_t *__restrict__ err)
+                                                    uint32_t *__restrict__ err, int rbits)
 {
   // Pairs are appended through ONE counter: a returning atomic per wave tops out near 90 per microsecond on this part
   // (15 M pairs from 480 K waves: 5.3 ms, the whole kernel).  The first pair of every lane is therefore counted in LDS
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ can
     {
       out[slot] = p;
       uint64_t gk = (uint64_t) (uint32_t) (p.p1_tid + 1) * (uint64_t) (nt + 1) + (uint64_t) (uint32_t) (p.p2_tid + 1);
-      okey[slot] = (gk << 32) | p.rec;
+      okey[slot] = (gk << rbits) | p.rec;
       oval[slot] = (uint32_t) slot;
     }
   };
@@ -167,24 +167,24 @@ __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ can
       const bk_pair &p = first_pair;
       out[slot] = p;
       uint64_t gk = (uint64_t) (uint32_t) (p.p1_tid + 1) * (uint64_t) (nt + 1) + (uint64_t) (uint32_t) (p.p2_tid + 1);
-      okey[slot] = (gk << 32) | p.rec;
+      okey[slot] = (gk << rbits) | p.rec;
       oval[slot] = (uint32_t) slot;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void k_gather_pairs(const bk_pair *__restrict__ in, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key, uint64_t n,
-                                                      bk_pair *__restrict__ out, uint32_t *__restrict__ gflag)
+                                                      bk_pair *__restrict__ out, uint32_t *__restrict__ gflag, int rbits)
 {
   uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = in[perm[i]];
-  gflag[i] = (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) ? 1u : 0u;
+  gflag[i] = (i == 0 || (key[i] >> rbits) != (key[i - 1] >> rbits)) ? 1u : 0u;
 }
 
 // gscan = exclusive scan of gflag: group index (numeric key order) of element i is gscan[i] + gflag[i] - 1
 __global__ __launch_bounds__(256) void k_group_starts(const uint32_t *__restrict__ gflag, const uint32_t *__restrict__ gscan, const uint64_t *__restrict__ key, uint64_t n,
-                                                      uint64_t *__restrict__ gstart, uint32_t *__restrict__ gkey, uint32_t *__restrict__ gof)
+                                                      uint64_t *__restrict__ gstart, uint32_t *__restrict__ gkey, uint32_t *__restrict__ gof, int rbits)
 {
   uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_group_starts(const uint32_t *__restrict
   if (gflag[i])
   {
     gstart[g] = i;
-    gkey[g] = (uint32_t) (key[i] >> 32);
+    gkey[g] = (uint32_t) (key[i] >> rbits);
   }
   if (i == n - 1) gstart[g + 1] = n;
 }
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(256) void k_assign_ids(bk_pair *__restrict__ pairs,
   pairs[i].id = (uint32_t) (i - gstart[g]);
 }
 // sort key of a pair: (numeric chr-pair key, discovery index)
-__global__ __launch_bounds__(256) void k_pair_keys(const bk_pair *__restrict__ p, uint64_t n, int32_t nt, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval)
+__global__ __launch_bounds__(256) void k_pair_keys(const bk_pair *__restrict__ p, uint64_t n, int32_t nt, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval, int rbits)
 {
   uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t gk = (uint64_t) (uint32_t) (p[i].p1_tid + 1) * (uint64_t) (nt + 1) + (uint64_t) (uint32_t) (p[i].p2_tid + 1);
-  okey[i] = (gk << 32) | p[i].rec;
+  okey[i] = (gk << rbits) | p[i].rec;
   oval[i] = (uint32_t) i;
 }
 // dst[off[g] + rank inside group g] = src: groups leave for their destination rank as contiguous blocks
@@ -315,7 +315,7 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
       prims::radix_sort_pairs(key, val, n_cand, attempt == 0 ? 32 : 0, 64, b.radix, st, &ks, &vs);
       if (attempt == 0) hipLaunchKernelGGL(k_join_fix_runs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, ks, vs, n_cand, err);
       hipLaunchKernelGGL(k_join_pairs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, ks, vs, n_cand, w, tprefix, nt, unsorted, okey, oval,
-                         (unsigned long long) cap, counter, err);
+                         (unsigned long long) cap, counter, err, b.rec_bits);
     }
     HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -347,10 +347,11 @@ static void group_sorted(const bk_pair *unsorted, uint64_t *okey, uint32_t *oval
   while ((1ull << gbits) < (uint64_t) (nt + 1) * (uint64_t) (nt + 1) && gbits < 32) ++gbits;
   uint64_t *ks;
   uint32_t *vs;
-  prims::radix_sort_pairs(okey, oval, np, 0, 32 + gbits, b.radix, st, &ks, &vs);
+  const int rbits = b.rec_bits;
+  prims::radix_sort_pairs(okey, oval, np, 0, rbits + gbits, b.radix, st, &ks, &vs);
   uint32_t *gflag = b.gflag.as<uint32_t>(np + 1);
   uint32_t *gscan = b.gscan.as<uint32_t>(np + 1);
-  hipLaunchKernelGGL(k_gather_pairs, dim3(cdiv(np, 256)), dim3(256), 0, st, unsorted, vs, ks, np, pairs, gflag);
+  hipLaunchKernelGGL(k_gather_pairs, dim3(cdiv(np, 256)), dim3(256), 0, st, unsorted, vs, ks, np, pairs, gflag, rbits);
   prims::exclusive_scan<uint32_t>(gflag, gscan, np, b.scan_tmp, st);
   uint32_t ng = 0;
   HIP_CHECK(hipMemcpyAsync(&ng, gscan + np, 4, hipMemcpyDeviceToHost, st));
@@ -358,7 +359,7 @@ static void group_sorted(const bk_pair *unsorted, uint64_t *okey, uint32_t *oval
   res.n_groups = ng;
   uint64_t *gstart = b.gstart.as<uint64_t>((uint64_t) ng + 1);
   uint32_t *gkey = b.gkey.as<uint32_t>((uint64_t) ng + 1);
-  hipLaunchKernelGGL(k_group_starts, dim3(cdiv(np, 256)), dim3(256), 0, st, gflag, gscan, ks, np, gstart, gkey, gof);
+  hipLaunchKernelGGL(k_group_starts, dim3(cdiv(np, 256)), dim3(256), 0, st, gflag, gscan, ks, np, gstart, gkey, gof, rbits);
   res.gstart = gstart;
   res.gkey = gkey;
 }
@@ -374,7 +375,7 @@ void group_pairs(const bk_pair *raw, uint64_t np, int32_t nt, JoinBufs &b, hipSt
   if (np > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 pairs");
   uint64_t *okey = b.okey.as<uint64_t>(np + 1);
   uint32_t *oval = b.oval.as<uint32_t>(np + 1);
-  if (np) hipLaunchKernelGGL(k_pair_keys, dim3(cdiv(np, 256)), dim3(256), 0, st, raw, np, nt, okey, oval);
+  if (np) hipLaunchKernelGGL(k_pair_keys, dim3(cdiv(np, 256)), dim3(256), 0, st, raw, np, nt, okey, oval, b.rec_bits);
   group_sorted(raw, okey, oval, np, nt, b, st, res);
 }
 
