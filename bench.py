@@ -67,6 +67,26 @@ def from_bam_side_line(n_pairs, device, fast):
             "rest_of_hot_path_s": round(min(rest), 4), "file_to_calls_s": round(min(total), 4), "file_to_calls_M_records_per_s": round(n / min(total) / 1e6, 1)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: N fresh rank processes over RCCL on this node."""
+    import socket
+    import subprocess
+    import torch  # device_count() does not initialise the GPU (it must not: the children are started from here)
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node: refusing to run (a line with fewer ranks "
+                         "than asked for would be mislabelled)\n" % (n, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +105,13 @@ def main():
                     help="N > 1: strong = configs[2], the --records sample sharded over the ranks (default); weak = one sample of N x --records")
     ap.add_argument("--sharded", type=int, default=-1, help="1: one sample sharded over the ranks (default when --gpus > 1), 0: plain single-table run")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started by hand as `python bench.py --gpus N`: this process never touches a GPU, it starts the N ranks as fresh child
+        # processes (one per GPU, torch.distributed.run = what the driver would have started), relays rank 0's line and ends
+        # with their status
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -95,8 +122,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it starts its own ranks) or under "
+                         "torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks asked for, %d GPU(s) visible: one rank per GPU, no rank shares a device" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_shards = args.sharded == 1 or (args.sharded < 0 and world > 1)
@@ -217,7 +249,7 @@ def main():
         value = (n_total * args.steps) / dt / 1e6
         out = {
             "metric": "M reads/s clustered+split-scanned", "value": round(value, 3), "unit": "M records/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "int32/u8 (+f64 sd replay)",
             "data": "synthetic",
             "config": {"workload": (("configs[2]: the " if use_shards and args.scaling == "strong" and world > 1 else "configs[1]: ") + "30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" if args.workload == "wgs" else
@@ -238,6 +270,8 @@ def main():
                                  "hot path / sum of stage times / 8 TB/s (the sort emulation and the joins add time, no algorithmic bytes)",
                          "stages": stages},
             "stage_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in per.items()},
+            "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "devices_visible": torch.cuda.device_count()},
         }
         # CPU baseline: the oracle port on a bounded sample of the same workload (rank 0, N = 1 only)
         if world == 1 and not use_shards and args.cpu_sample > 0:

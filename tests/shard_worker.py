@@ -33,7 +33,9 @@ def main():
     n_per_rank, seed, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     routed = (sys.argv[4] if len(sys.argv) > 4 else "routed") == "routed"
     backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"  # "nccl" = RCCL: one rank per GPU (world size 1 on a one-GPU box)
-    dev = torch.device("cuda", 0)
+    # every rank on cuda:0 (one-GPU box) unless the test asks for a device per rank (RCCL with more than one rank)
+    one_each = os.environ.get("SHARD_WORKER_ONE_GPU_PER_RANK") == "1"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if one_each else 0)
     if backend == "nccl":
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", device_id=dev)
@@ -44,7 +46,7 @@ def main():
     comm = sharded.Comm(dev)
     counts = comm.all_gather_scalars([cols["n"]])[:, 0].tolist()
     rec_base = int(sum(counts[:rank]))
-    ctx = capi.Context(contigs, device=0)
+    ctx = capi.Context(contigs, device=dev.index)
     ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
     run = sharded.ShardedRun(ctx, comm, routed=routed)
     w = run.run(rec_base, qual=20, fast=(mode == "fast"))

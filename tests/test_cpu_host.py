@@ -86,3 +86,18 @@ def test_qname_hash_matches_python():
 
 def test_abi_struct_sizes():
     assert abi.PAIR.itemsize == 48 and abi.SPLIT.itemsize == 80 and abi.CLUSTER.itemsize == 72
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """bench.py --gpus N must never print a line for fewer ranks than it was asked for (this container has no GPU: N = 2 is refused
+    before anything is imported that could touch one; a launcher whose WORLD_SIZE disagrees with --gpus is refused as well)"""
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(n, 2))], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to run" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout

@@ -104,3 +104,15 @@ def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, rank
             got = open(prefix + suffix).read()
             exp = open(os.path.join(golden_dir, "%s.%s%s" % (name, mode, suffix))).read()
             assert got == exp, (suffix, got[:600], exp[:600])
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs >= 2 GPUs: RCCL takes one device per rank")
+@pytest.mark.parametrize("name,mode,feed", [("small", "fast", "gpu"), ("edge", "ahc", "gpu"), ("g1", "fast", "host")])
+def test_cli_two_rccl_ranks_match_reference(golden_dir, name, mode, feed):
+    """`BreakID -gpus 2 -comm rccl` on a node with two devices: librccl with two ranks (threads of one process, one GPU each)"""
+    test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, 2, "rccl", feed)

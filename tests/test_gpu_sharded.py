@@ -76,3 +76,47 @@ def test_bench_sharded_path_runs_over_rccl():
     line = json.loads(r.stdout.strip().split("\n")[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["valid_clusters"] > 100 and "RCCL" in line["config"]["sharding"]
     assert line["roofline"]["path_frac"] > 0 and any(s["stage"] == "k_stream" for s in line["roofline"]["stages"])
+
+
+# ---- more than one RCCL rank: one GPU per rank, so these need a node with >= 2 devices (skipped on the one-GPU box) ----------
+_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL takes one device per rank")
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts its own N ranks (fresh processes, nothing re-executed after a GPU call); with fewer
+    than N devices it must end non-zero and print no line at all - never a line that says n_gpus 1"""
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--records", "3000000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to run" in r.stderr and "{" not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    # and the flag must agree with the launcher's world size
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout
+
+
+@_two_gpus
+@pytest.mark.parametrize("mode,exchange", [("fast", "routed"), ("ahc", "routed"), ("fast", "replicated")])
+def test_two_rccl_ranks_on_two_gpus_match_oracle(mode, exchange):
+    """ShardedRun over backend nccl (= RCCL over xGMI) with two ranks, one GPU each, against the CPU oracle on the whole sample"""
+    port = {"fastrouted": "29631", "ahcrouted": "29632", "fastreplicated": "29633"}[mode + exchange]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_WORKER_ONE_GPU_PER_RANK="1")
+    n = "600000" if mode == "fast" else "150000"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "tests", "shard_worker.py"), n, "81", mode, exchange, "nccl"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@_two_gpus
+def test_bench_two_gpus_starts_its_own_ranks():
+    """the way the driver's scaling run may start it: `python bench.py --gpus 2` with no launcher around it"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--records", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["backend"] == "nccl" and line["value"] > 0
+    assert line["config"]["valid_clusters"] > 100 and "RCCL" in line["config"]["sharding"]
