@@ -190,3 +190,75 @@ def write_bam_from_soa(path: str, contigs: Sequence[Tuple[str, int]], cols, qnam
                     body += b"SAZ" + a + b"\0"
             yield pack_core(32 + len(body), tid[i], p, len(name), mapq[i], b, len(c), flag[i], 0, mtid[i], mpos[i], isize[i]) + body
     write_bam(path, contigs, gen(), aligned=aligned)
+
+
+def write_bai(bam_path: str, bai_path: Optional[str] = None) -> str:
+    """Index of a coordinate-sorted BAM in the BAI format of the SAM specification (5.2: bins with their chunk lists, the 16 kb
+    linear index, n_no_coor), made by reading the file back: what `samtools index` leaves next to it.  The reference refuses to
+    call breakpoints without a loadable index (BreakID.cc:411-416), so the command-line tests give it a real one."""
+    raw = open(bam_path, "rb").read()
+    # BGZF blocks -> one inflated stream + the file offset / inflated offset of every block
+    blocks, data, off = [], bytearray(), 0
+    while off < len(raw):
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        blocks.append((off, len(data)))
+        data += zlib.decompress(raw[off + 18:off + bsize - 8], -15)
+        off += bsize
+    starts = [b[1] for b in blocks]
+
+    import bisect
+
+    def voffset(p: int) -> int:
+        i = bisect.bisect_right(starts, p) - 1
+        # a position at the very end of a block belongs to the start of the next one, as htslib's bgzf_tell reports it
+        while i + 1 < len(blocks) and blocks[i + 1][1] == p and p > blocks[i][1]:
+            i += 1
+        return (blocks[i][0] << 16) | (p - blocks[i][1])
+
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, p)[0]
+        p += 8 + l_name
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    n_no_coor = 0
+    while p + 4 <= len(data):
+        bs = struct.unpack_from("<i", data, p)[0]
+        tid, pos, l_name, _mq, _bin, n_cig, flag = struct.unpack_from("<iiBBHHH", data, p + 4)
+        beg_v, end_v = voffset(p), voffset(p + 4 + bs)
+        if tid < 0:
+            n_no_coor += 1
+        else:
+            cig = struct.unpack_from("<%dI" % n_cig, data, p + 36 + l_name) if n_cig else ()
+            rl = cigar_reflen(cig) if cig and not flag & 4 else 0
+            end = pos + (rl if rl > 0 else 1)
+            b = reg2bin(pos, end)
+            ch = bins[tid].setdefault(b, [])
+            if ch and ch[-1][1] == beg_v:
+                ch[-1][1] = end_v
+            else:
+                ch.append([beg_v, end_v])
+            for wdw in range(pos >> 14, ((end - 1) >> 14) + 1):
+                lin[tid].setdefault(wdw, beg_v)
+        p += 4 + bs
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        out += struct.pack("<i", len(bins[t]))
+        for b in sorted(bins[t]):
+            out += struct.pack("<Ii", b, len(bins[t][b]))
+            for c in bins[t][b]:
+                out += struct.pack("<QQ", c[0], c[1])
+        n_intv = (max(lin[t]) + 1) if lin[t] else 0
+        out += struct.pack("<i", n_intv)
+        last = 0
+        for wdw in range(n_intv):
+            last = lin[t].get(wdw, last)
+            out += struct.pack("<Q", last)
+    out += struct.pack("<Q", n_no_coor)
+    bai_path = bai_path or bam_path + ".bai"
+    with open(bai_path, "wb") as f:
+        f.write(out)
+    return bai_path

@@ -639,7 +639,7 @@ static void run_lane(const bk_pair *pairs, const uint32_t *gof, const uint64_t *
 static int lanes_wanted()
 {
   static const int want = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 1;
-  return want < 1 ? 1 : (want > 8 ? 8 : want);
+  return want < 1 ? 1 : (want > 26 ? 26 : want);
 }
 static bool lanes_apply(const bk_ctx *ctx, int fast)
 {
@@ -666,6 +666,11 @@ struct LanePlan
 {
   std::vector<int> lane_of;
 };
+static bool lane_bulk()
+{
+  static const bool b = getenv("BREAKID_LANE_BULK") && atoi(getenv("BREAKID_LANE_BULK")) != 0;
+  return b;
+}
 static LanePlan plan_blind(const bk_ctx *ctx, int K)
 {
   const uint32_t ng = ctx->jr.n_groups;
@@ -682,6 +687,22 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
   // sharded sample: this rank only masks and clusters the groups it owns (bk_shard_own_groups); the others belong to no lane
   const bool owned_only = !ctx->own_groups.empty();
   if (owned_only && ctx->own_groups.size() != ng) throw bk_error(BK_ERR_ARG, "bk_shard_own_groups: group count changed");
+  // lane 0 = the many groups of ordinary size (their sorts end after a few partition levels), lanes 1 .. K-1 = the outliers in size
+  // (on a WGS sample the same-chromosome groups: the ones whose sorts run into introsort's depth limit, i.e. ~36 launch-bound
+  // levels and lone-wave heaps): a lane that holds one of them pays those levels for all of its groups
+  const bool bulk = lane_bulk() && K >= 3;
+  uint64_t median = 0;
+  if (bulk)
+  {
+    std::vector<uint64_t> sz;
+    for (uint32_t g = 0; g < ng; ++g)
+      if (size_of(g) && !(owned_only && !ctx->own_groups[g])) sz.push_back(size_of(g));
+    if (!sz.empty())
+    {
+      std::nth_element(sz.begin(), sz.begin() + sz.size() / 2, sz.end());
+      median = sz[sz.size() / 2];
+    }
+  }
   for (uint32_t i = 0; i < ng; ++i)
   {
     const uint32_t g = order[i];
@@ -691,7 +712,19 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
       continue;
     }
     int l;
-    if ((int) i < solo)
+    if (bulk)
+    {
+      if (size_of(g) > 2 * median && size_of(g) > 16384)
+      {
+        l = 1;
+        for (int k = 2; k < K; ++k)
+          if (load[k] < load[l]) l = k;
+        load[l] += std::pow((double) size_of(g), wexp);
+      }
+      else
+        l = 0;
+    }
+    else if ((int) i < solo)
       l = (int) i;
     else
     {
@@ -724,15 +757,23 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
   p.lane_of.assign(ng, 0);
   std::vector<double> mx(K, 0.0), my(K, 0.0), pairs(K, 0.0);
   auto cost = [&](int l) { return mx[l] + my[l] + per_pair * pairs[l]; };
+  const bool bulk = lane_bulk() && K >= 3;
   for (uint32_t g : order)
   {
-    int best = 0;
+    if (bulk && hx[g] == 0 && hy[g] == 0)
+    {
+      p.lane_of[g] = 0;  // never ran into the depth limit: stays with the groups whose sorts end after a few levels
+      pairs[0] += (double) sizes[g];
+      continue;
+    }
+    const int l0 = bulk ? 1 : 0;
+    int best = l0;
     double best_cost = 0;
-    for (int l = 0; l < K; ++l)
+    for (int l = l0; l < K; ++l)
     {
       const double c = std::max(mx[l], heap_cost(hx[g])) + std::max(my[l], heap_cost(hy[g])) + per_pair * (pairs[l] + (double) sizes[g]);
       // the lane whose own cost ends lowest takes the group (ties: the emptier lane)
-      if (l == 0 || c < best_cost || (c == best_cost && cost(l) < cost(best)))
+      if (l == l0 || c < best_cost || (c == best_cost && cost(l) < cost(best)))
       {
         best = l;
         best_cost = c;
@@ -843,6 +884,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       cb.heavy_x.assign(ng, 0u);
       cb.heavy_y.assign(ng, 0u);
       cb.observe = true;
+      cb.se.heavy_all = lane_bulk();
       remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>(), ctx->gstart_host.data(), keep[l].data());
       cb.heavy_x.assign(ng, 0u);  // the third sort (by x, on the masked list) is the one that tells about the fifth
       remove_isolated_end(pairs, lane_list(l), cb, lane_st(l));

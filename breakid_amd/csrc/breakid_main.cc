@@ -19,8 +19,109 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/breakid_hip.h"
 #include "../../include/breakid_multi.h"
+
+// bam_index_load (htslib-1.3.1 sam.h:302 -> hts.c:2042 hts_idx_load, :1580 hts_idx_load_local, :1528 hts_idx_load_core): the index is
+// <bam>.csi, <bam with its extension replaced>.csi, <bam>.bai, <...>.bai - the first that can be opened - and it must parse to the
+// end: magic, counts, every bin's chunk list and every linear index (a truncated or foreign file gives NULL, i.e. the reference's
+// "please index bam-file first" exit, BreakID.cc:411-416).  The hot path streams the whole file and does not use the offsets; what is
+// reproduced here is which files the reference accepts.  gzread() reads plain and (B)GZF-compressed files alike, as bgzf_read does.
+static bool index_loads(const std::string &bam)
+{
+  auto candidate = [&](const char *ext) -> std::string {
+    std::string a = bam + ext;
+    if (FILE *f = fopen(a.c_str(), "rb"))
+    {
+      fclose(f);
+      return a;
+    }
+    size_t i = bam.size();
+    while (i > 1 && bam[i - 1] != '.') --i;  // hts_idx_getfn: the last '.' at an index > 0
+    if (i > 1)
+    {
+      a = bam.substr(0, i - 1) + ext;
+      if (FILE *f = fopen(a.c_str(), "rb"))
+      {
+        fclose(f);
+        return a;
+      }
+    }
+    return std::string();
+  };
+  std::string fn = candidate(".csi");
+  if (fn.empty()) fn = candidate(".bai");
+  if (fn.empty()) return false;
+  gzFile fp = gzopen(fn.c_str(), "rb");
+  if (!fp) return false;
+  auto rd = [&](void *dst, size_t n) { return n == 0 || gzread(fp, dst, (unsigned) n) == (int) n; };
+  auto skip = [&](uint64_t n) {
+    char buf[65536];
+    while (n)
+    {
+      const size_t k = n < sizeof buf ? (size_t) n : sizeof buf;
+      if (!rd(buf, k)) return false;
+      n -= k;
+    }
+    return true;
+  };
+  bool ok = false;
+  do
+  {
+    uint8_t magic[4];
+    if (!rd(magic, 4)) break;
+    int fmt;  // 0 CSI, 1 BAI, 2 TBI
+    int32_t n_ref = 0;
+    if (!memcmp(magic, "CSI\1", 4))
+    {
+      uint32_t x[3];
+      if (!rd(x, 12) || !skip(x[2]) || !rd(&n_ref, 4)) break;
+      fmt = 0;
+    }
+    else if (!memcmp(magic, "TBI\1", 4))
+    {
+      uint32_t x[8];
+      if (!rd(x, 32) || !skip(x[7])) break;
+      n_ref = (int32_t) x[0];
+      fmt = 2;
+    }
+    else if (!memcmp(magic, "BAI\1", 4))
+    {
+      if (!rd(&n_ref, 4)) break;
+      fmt = 1;
+    }
+    else
+      break;
+    bool good = true;
+    for (int32_t i = 0; i < n_ref && good; ++i)
+    {
+      int32_t n_bin;
+      if (!rd(&n_bin, 4))
+      {
+        good = false;
+        break;
+      }
+      std::set<uint32_t> seen;
+      for (int32_t j = 0; j < n_bin && good; ++j)
+      {
+        uint32_t key;
+        int32_t n_chunk;
+        uint64_t loff;
+        good = rd(&key, 4) && seen.insert(key).second && (fmt != 0 || rd(&loff, 8)) && rd(&n_chunk, 4) && n_chunk >= 0 && skip((uint64_t) n_chunk << 4);
+      }
+      if (good && fmt != 0)
+      {
+        int32_t n_intv;
+        good = rd(&n_intv, 4) && n_intv >= 0 && skip((uint64_t) n_intv << 3);
+      }
+    }
+    ok = good;  // (the trailing n_no_coor is optional: hts.c:1575)
+  } while (false);
+  gzclose(fp);
+  return ok;
+}
 
 #ifndef BREAKID_INSTALLDIR
 #define BREAKID_INSTALLDIR "."
@@ -378,9 +479,8 @@ int main(int argc, char *argv[])
   clock_t scan_start = clock(), scan_end = scan_start, cluster_start = scan_start, cluster_end = scan_start, bp_start = scan_start, bp_end = scan_start;
   uint64_t n_pairs = 0, n_clustered = 0, n_valid = 0, n_clusters = 0;
   uint32_t n_groups = 0;
-  auto need_index = [&] {  // findEncompassingReadsAndBreakPointInfo opens the index for every group that reaches it (:405-416)
-    std::ifstream bai((inp_file + ".bai").c_str());
-    if (!bai.is_open())
+  auto need_index = [&] {  // findEncompassingReadsAndBreakPointInfo loads the index for every group that reaches it (:405-416)
+    if (!index_loads(inp_file))
     {
       std::cerr << "Error: please index bam-file first:\t" << inp_file << std::endl;
       exit(1);

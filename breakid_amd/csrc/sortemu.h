@@ -11,6 +11,7 @@ struct SortEmuBufs
   // optional observer (host): heavy[g] = largest heapsort segment (elements) any sort through these buffers left to group g's
   // lone-wave heap kernels - what the lanes of api.hip balance on.  Set by the caller around the sorts it wants recorded.
   std::vector<uint32_t> *heavy = nullptr;
+  bool heavy_all = false;  // record every segment the level loop left to the heapsort kernels (a group that has one went through all ~2 lg n levels), not only the long ones
   // the three size classes of the heapsort branch run side by side (fork/join around the caller's stream)
   static constexpr int N_AUX = 5;
   hipStream_t aux[N_AUX] = {};

@@ -2350,7 +2350,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
     ++used;
   };
-  if (b.heavy && nh1 && max1 > HEAP_RANKED_MIN)
+  if (b.heavy && nh1 && (max1 > HEAP_RANKED_MIN || b.heavy_all))
   {
     // the caller balances its lanes of groups on the longest heap segment per group
     std::vector<HeapSeg> hh(nh1);
@@ -2362,7 +2362,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     for (const HeapSeg &h : hh)
     {
       const uint32_t m = h.last - h.first;
-      if (m <= HEAP_RANKED_MIN) continue;
+      if (m <= HEAP_RANKED_MIN && !b.heavy_all) continue;
       const uint32_t g = (uint32_t) (std::upper_bound(go.begin(), go.end(), (uint64_t) h.first) - go.begin()) - 1;
       if (g < ng && (*b.heavy)[g] < m) (*b.heavy)[g] = m;
     }

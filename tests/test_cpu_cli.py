@@ -10,6 +10,7 @@ import tempfile
 import pytest
 
 from breakid_amd import synth
+from breakid_amd import bamio
 from tools import make_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,7 +36,7 @@ def run_cli(binary, name, mode, golden_dir, aligned=True):
     with tempfile.TemporaryDirectory() as tmp:
         bam = os.path.join(tmp, name + ".bam")
         ds.write_bam(bam, aligned=aligned)
-        open(bam + ".bai", "wb").close()
+        bamio.write_bai(bam)  # the reference loads the index before it calls breakpoints (BreakID.cc:411-416)
         side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
         prefix = os.path.join(tmp, "out")
         cmd = [binary, "-i", bam, "-o", prefix, "-n", side["nib"], "-all"] + (["-fast"] if mode == "fast" else [])
@@ -83,10 +84,20 @@ def fatal_cases(tmp, ds, refgene):
     :411-416, RefSeqTranscript.cc:212-216"""
     bam = os.path.join(tmp, "in.bam")
     ds.write_bam(bam, aligned=True)
-    open(bam + ".bai", "wb").close()
+    bamio.write_bai(bam)  # the reference loads the index before it calls breakpoints (BreakID.cc:411-416)
     side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
     noidx = os.path.join(tmp, "noidx.bam")
     ds.write_bam(noidx, aligned=True)
+    # an index that is there but does not load (hts_idx_load_local: short read of the magic / foreign magic / file ends inside the
+    # bin count of a reference) is the same fatal path as no index at all; an index named <stem>.bai is found like <bam>.bai
+    bad = {}
+    for what, content in (("emptyidx", b""), ("foreignidx", b"XYZ\1" + bytes(64)), ("shortidx", b"BAI\1" + (len(ds.contigs)).to_bytes(4, "little") + bytes(2))):
+        bad[what] = os.path.join(tmp, what + ".bam")
+        ds.write_bam(bad[what], aligned=True)
+        open(bad[what] + ".bai", "wb").write(content)
+    stem = os.path.join(tmp, "stem.bam")
+    ds.write_bam(stem, aligned=True)
+    bamio.write_bai(stem, os.path.join(tmp, "stem.bai"))
     empty_nib = os.path.join(tmp, "empty_nib")
     os.makedirs(empty_nib)
     no_inst = os.path.join(tmp, "no_install")
@@ -100,6 +111,10 @@ def fatal_cases(tmp, ds, refgene):
          "Error: can not open bam-file: " + os.path.join(tmp, "nope.bam")),
         ("missing ref_names.txt", ["-i", bam, "-o", os.path.join(tmp, "o"), "-n", empty_nib], ok_env, 1, "Error: cannot open reference names file."),
         ("missing index", ["-i", noidx, "-o", os.path.join(tmp, "o"), "-n", side["nib"], "-fast"], ok_env, 1, "Error: please index bam-file first:\t" + noidx),
+        ("empty index", ["-i", bad["emptyidx"], "-o", os.path.join(tmp, "o"), "-n", side["nib"], "-fast"], ok_env, 1, "Error: please index bam-file first:\t" + bad["emptyidx"]),
+        ("foreign index", ["-i", bad["foreignidx"], "-o", os.path.join(tmp, "o"), "-n", side["nib"], "-fast"], ok_env, 1, "Error: please index bam-file first:\t" + bad["foreignidx"]),
+        ("truncated index", ["-i", bad["shortidx"], "-o", os.path.join(tmp, "o"), "-n", side["nib"], "-fast"], ok_env, 1, "Error: please index bam-file first:\t" + bad["shortidx"]),
+        ("index named after the stem", ["-i", stem, "-o", os.path.join(tmp, "o2"), "-n", side["nib"], "-fast"], ok_env, 0, ""),
         ("missing refGene.txt", ["-i", bam, "-o", os.path.join(tmp, "o"), "-n", side["nib"], "-fast"], {"BREAKID_INSTALLDIR": no_inst}, 1,
          "Error: cannot open \t" + os.path.join(no_inst, "ref_files", "refGene.txt")),
     ]

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from breakid_amd import abi, capi, synth
+from breakid_amd import bamio
 from tests import bigcases
 
 pytestmark = pytest.mark.gpu
@@ -46,7 +47,7 @@ def test_cli_on_large_inputs_matches_reference_txt(name, mode):
     with tempfile.TemporaryDirectory() as tmp:
         bam = os.path.join(tmp, name + ".bam")
         fx.write_bam(bam)
-        open(bam + ".bai", "wb").close()
+        bamio.write_bai(bam)  # the reference loads the index before it calls breakpoints (BreakID.cc:411-416)
         side = synth.write_side_files(fx.contigs, tmp, refgene_lines=fx.refgene, max_nib_len=60_000_000)
         prefix = os.path.join(tmp, "out")
         cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all"] + (["-fast"] if mode == "fast" else [])

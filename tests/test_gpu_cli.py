@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from breakid_amd import synth
+from breakid_amd import bamio
 from tests import refdump
 from tools import make_golden
 
@@ -32,7 +33,7 @@ def test_cli_txt_outputs_match_reference(golden_dir, name, mode):
         aligned = mode == "fast"   # blocks as htslib writes them -> the streaming GPU decoder; fixed-size blocks (records across
         ds.write_bam(bam, aligned=aligned)  # blocks, as htsjdk writes them) -> its one-batch variant, or the host decoder when forced
         host = name in ("g2", "ties") and not aligned
-        open(bam + ".bai", "wb").close()  # the hot path streams the BAM; only the presence of the index is part of the CLI contract
+        bamio.write_bai(bam)  # the reference loads the index before it calls breakpoints (BreakID.cc:411-416)
         side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
         prefix = os.path.join(tmp, "out")
         cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all"] + (["-fast"] if mode == "fast" else [])
@@ -89,7 +90,7 @@ def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, rank
     with tempfile.TemporaryDirectory() as tmp:
         bam = os.path.join(tmp, name + ".bam")
         ds.write_bam(bam, aligned=feed != "across")
-        open(bam + ".bai", "wb").close()
+        bamio.write_bai(bam)  # the reference loads the index before it calls breakpoints (BreakID.cc:411-416)
         side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
         prefix = os.path.join(tmp, "out")
         cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all", "-gpus", str(ranks), "-comm", comm] + (["-fast"] if mode == "fast" else [])
