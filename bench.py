@@ -7,7 +7,8 @@ breakpoints) over one synthetic WGS-shape record table that is already resident 
 region starts.  Workload at N=1 = BASELINE.json configs[1] (30x WGS shape, hg19, 2x150 bp); for N>1 it is configs[2]:
 the SAME sample sharded over the ranks - every rank holds a contiguous range of its coordinate-sorted records, candidates
 and pairs travel to their owners by RCCL all-to-all (breakid_amd/sharded.py) - so the total work stays fixed (strong
-scaling; `--scaling weak` shards one sample of N x that size instead, capped below 2^32 records).
+scaling; `--scaling weak` shards one sample of N x that size instead: record indices of a sample are 64-bit, only one
+rank's table stays below 2^32 records).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--records R]
 
@@ -19,10 +20,10 @@ import os
 import sys
 import time
 
-# two lanes of chromosome-pair groups in bk_mask_and_cluster (csrc/api.hip) need more hardware queues than ROCm's default of 4
-# (the heap kernels of both lanes sit on side streams); the runtime reads this when it starts, i.e. before torch touches the GPU
+# the lanes of chromosome-pair groups in bk_mask_and_cluster (csrc/api.hip; the library's default) need more hardware queues than
+# ROCm's default of 4 (every lane's heap kernels sit on side streams); the runtime reads this when it starts, i.e. before torch
+# touches the GPU (importing breakid_amd.capi sets it as well)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-os.environ.setdefault("BREAKID_GROUP_LANES", "2")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -142,8 +143,6 @@ def main():
     n_rec = args.records
     if use_shards and args.scaling == "strong":
         n_rec = max(1_000_000, n_rec // world)
-    elif use_shards:
-        n_rec = min(n_rec, (0xFFFF0000 // max(world, 1)) // 1_000_000 * 1_000_000)  # the whole sample stays below 2^32 records (536 M per rank at 8 ranks)
     while n_rec * 110 > free_b and n_rec > 1_000_000:
         n_rec //= 2
     t0 = time.time()

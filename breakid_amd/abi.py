@@ -10,9 +10,9 @@ STAGE_SCAN, STAGE_ISO, STAGE_CLUSTERED, STAGE_SPLITS, STAGE_CLUSTERS, STAGE_GROU
 
 PAIR = np.dtype([("x", "<u4"), ("y", "<u4"), ("p1_pos", "<u4"), ("p2_pos", "<u4"), ("p1_tid", "<i4"),
                  ("p2_tid", "<i4"), ("p1_flag", "<u2"), ("p2_flag", "<u2"), ("p1_mapq", "u1"), ("p2_mapq", "u1"),
-                 ("p1_rev", "u1"), ("p2_rev", "u1"), ("rec", "<u4"), ("id", "<u4"), ("cluster", "<i4"),
-                 ("group", "<u4")])
-SPLIT = np.dtype([("rec", "<u4"), ("tid", "<i4"), ("pos", "<i4"), ("endpos", "<i4"), ("qhash", "<u8"),
+                 ("p1_rev", "u1"), ("p2_rev", "u1"), ("rec", "<u8"), ("id", "<u4"), ("cluster", "<i4"),
+                 ("group", "<u4"), ("reserved", "<u4")])
+SPLIT = np.dtype([("rec", "<u8"), ("tid", "<i4"), ("pos", "<i4"), ("endpos", "<i4"), ("reserved", "<u4"), ("qhash", "<u8"),
                   ("prim_chr", "<i4"), ("sec_chr", "<i4"), ("prim_start", "<u4"), ("prim_end", "<u4"),
                   ("prim_bp", "<u4"), ("sec_start", "<u4"), ("sec_end", "<u4"), ("sec_bp", "<u4"),
                   ("prim_cigar", "<u8"), ("sec_cigar", "<u8"), ("flags", "<u4"), ("qcheck", "<u4")])
@@ -21,7 +21,7 @@ CLUSTER = np.dtype([("group", "<u4"), ("id", "<i4"), ("p1_tid", "<i4"), ("p2_tid
                     ("p1_exact", "<u4"), ("p2_exact", "<i4"), ("n_drp", "<u4"), ("n_sr", "<u4"), ("depth1", "<u4"),
                     ("depth2", "<u4"), ("type_mask", "<u4"), ("flags", "<u4")])
 GROUP_KEY = np.dtype([("p1_tid", "<i4"), ("p2_tid", "<i4")])
-assert PAIR.itemsize == 48 and SPLIT.itemsize == 80 and CLUSTER.itemsize == 72
+assert PAIR.itemsize == 56 and SPLIT.itemsize == 88 and CLUSTER.itemsize == 72
 
 STAGE_DTYPE = {STAGE_SCAN: PAIR, STAGE_ISO: PAIR, STAGE_CLUSTERED: PAIR, STAGE_SPLITS: SPLIT,
                STAGE_CLUSTERS: CLUSTER, STAGE_GROUP_KEYS: GROUP_KEY}

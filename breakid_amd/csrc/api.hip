@@ -47,6 +47,11 @@ struct StageTimer
 };
 }  // namespace
 
+// the runtime's hardware-queue count as far as this library can know it: GPU_MAX_HW_QUEUES as the environment had it when the
+// first context was made (bk_init sets 16 when it is unset - that only helps when no HIP call came before; ROCm's default is 4)
+static int g_hw_queues_at_init = 0;
+static bool g_hw_queues_set_here = false;
+
 struct bk_ctx
 {
   int device = 0;
@@ -369,7 +374,14 @@ void ensure_splits_sorted(bk_ctx *c)
   if (c->splits_sorted) return;
   Scope s(c, "split_sort");
   bk_split *sorted = c->d_split.as<bk_split>(c->hc.n_split + 1);
-  sort_splits(const_cast<bk_split *>(c->split_raw_ptr()), c->hc.n_split, sorted, c->bb, c->st);
+  // tuples of this table carry its own record indices; a sharded sample's carry rec_base + i of every rank (64 bits)
+  int bits = 64;
+  if (!c->ext_split && c->rec_base == 0)
+  {
+    bits = 1;
+    while (bits < 32 && (1ull << bits) < c->rec.n) ++bits;
+  }
+  sort_splits(const_cast<bk_split *>(c->split_raw_ptr()), c->hc.n_split, sorted, c->bb, c->st, bits);
   c->splits_sorted = true;
 }
 }  // namespace
@@ -378,6 +390,23 @@ extern "C" {
 
 int bk_init(int device, const uint32_t *target_len, const char *const *target_name, int n_targets, bk_ctx **out)
 {
+  {
+    // the lanes of bk_mask_and_cluster and the chunk streams of the GPU feed want more hardware queues than ROCm's default of 4;
+    // the runtime reads the variable when it starts, so this helps a caller whose first HIP call is this one (a caller that has
+    // initialised HIP already keeps what it had: lanes_apply tells it once on stderr)
+    static bool once = false;
+    if (!once)
+    {
+      once = true;
+      const char *q = getenv("GPU_MAX_HW_QUEUES");
+      g_hw_queues_at_init = q ? atoi(q) : 4;
+      if (!q)
+      {
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        g_hw_queues_set_here = true;
+      }
+    }
+  }
   if (!out || n_targets < 0 || (n_targets && (!target_len || !target_name)))
   {
     g_init_error = "bk_init: bad arguments";
@@ -593,9 +622,9 @@ int bk_discordant_pairs(bk_ctx *ctx, int mapq_min, double w, uint64_t *n_pairs, 
     }
     {
       Scope s(ctx, "mate_join");
-      // discovery indices are record indices: of this table when the candidates are its own, of the whole sample (32 bits) when
-      // they came from other shards
-      ctx->jb.rec_bits = 32;
+      // discovery indices are record indices: of this table when the candidates are its own, of the whole sample (up to 64 bits:
+      // rec_base + i) when they came from other shards
+      ctx->jb.rec_bits = -1;
       if (!ctx->ext_cand && ctx->rec_base == 0)
       {
         int bits = 1;
@@ -638,13 +667,32 @@ static void run_lane(const bk_pair *pairs, const uint32_t *gof, const uint64_t *
 
 static int lanes_wanted()
 {
-  static const int want = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 1;
+  // four lanes unless the caller says otherwise (BREAKID_GROUP_LANES=1: one pass); lanes_apply decides from the data whether they
+  // pay.  Measured on the 30x WGS shape with the segment-per-workgroup tail of the level loop: 2 lanes 42.0 ms, 3 lanes 42.6,
+  // 4 lanes 39.6, 5 lanes 48.5 (more lanes shorten a lane's "longest heap of any of its groups" per sort, and cost a level loop,
+  // a ranking and a finisher chain of their own, each ~100 launches that wait for each other across lanes)
+  static const int want = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 4;
   return want < 1 ? 1 : (want > 26 ? 26 : want);
 }
 static bool lanes_apply(const bk_ctx *ctx, int fast)
 {
   static const uint64_t min_pairs = getenv("BREAKID_LANES_MIN_PAIRS") ? strtoull(getenv("BREAKID_LANES_MIN_PAIRS"), nullptr, 10) : (1ull << 20);  // below: launch-bound anyway
-  return lanes_wanted() >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->jr.n_pairs >= min_pairs;
+  // picked from the data: lanes pay when at least two groups are large enough to run into long sorts side by side
+  uint32_t large = 0;
+  const uint64_t big = std::max<uint64_t>(2, min_pairs >> 6);  // 16 K pairs with the default threshold
+  for (uint32_t g = 0; g < ctx->jr.n_groups && g + 1 < ctx->gstart_host.size(); ++g) large += ctx->gstart_host[g + 1] - ctx->gstart_host[g] >= big ? 1u : 0u;
+  const bool yes = lanes_wanted() >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->jr.n_pairs >= min_pairs && large >= 2;
+  if (yes)
+  {
+    static bool told = false;
+    if (!told && g_hw_queues_at_init < 8 && !g_hw_queues_set_here && !getenv("BREAKID_QUIET"))
+    {
+      told = true;
+      fprintf(stderr, "[breakid] GPU_MAX_HW_QUEUES=%d: the lanes of chromosome-pair groups (bk_mask_and_cluster) and their heap kernels will share hardware queues; "
+                        "set GPU_MAX_HW_QUEUES=16 in the environment before the process makes its first HIP call (or BREAKID_GROUP_LANES=1)\n", g_hw_queues_at_init);
+    }
+  }
+  return yes;
 }
 
 // K lanes of groups.  A lane's time is (a) per sort the LONGEST heapsort segment of any of its groups - a serial chain of one wave
@@ -1301,6 +1349,7 @@ int bk_shard_group_pairs(bk_ctx *ctx, const void *pairs_dev, uint64_t n, const u
     if ((n && !pairs_dev) || (n_all_keys && !all_keys)) throw bk_error(BK_ERR_ARG, "bk_shard_group_pairs: null input");
     {
       Scope s(ctx, "group_pairs");
+      ctx->jb2.rec_bits = -1;  // the pairs carry the discovery indices of the whole sample
       group_pairs((const bk_pair *) pairs_dev, n, ctx->nt, ctx->jb2, ctx->st, ctx->jr);
     }
     std::vector<uint32_t> keys(all_keys, all_keys + n_all_keys);
@@ -1704,7 +1753,7 @@ int bk_debug_vote(bk_ctx *ctx, const bk_split *side1, uint32_t n1, const bk_spli
     put(side2, n2, p2_tid, pos2, 1000);
     // tuples must be in coordinate order
     std::stable_sort(t.begin(), t.end(), [](const bk_split &a, const bk_split &b) { return (uint32_t) a.tid != (uint32_t) b.tid ? (uint32_t) a.tid < (uint32_t) b.tid : a.pos < b.pos; });
-    for (size_t i = 0; i < t.size(); ++i) t[i].rec = (uint32_t) i;
+    for (size_t i = 0; i < t.size(); ++i) t[i].rec = i;
     bk_cluster c;
     memset(&c, 0, sizeof c);
     c.p1_tid = p1_tid;

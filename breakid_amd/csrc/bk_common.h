@@ -1,5 +1,7 @@
 // Internal definitions shared by the HIP translation units of libbreakid_hip.so (gfx950 only).
 #pragma once
+#include <cstdlib>
+#include <execinfo.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -65,7 +67,18 @@ struct DevBuf
     {
       release();
       size_t want = bytes + bytes / 8 + 256;
-      HIP_CHECK(hipMalloc(&p, want));
+      if (hipMalloc(&p, want) != hipSuccess)
+      {
+        p = nullptr;
+        (void) hipGetLastError();
+        if (getenv("BK_ABORT_ON_BAD_ALLOC"))  // (debugging: who asked - resolve the offsets with llvm-symbolizer -e libbreakid_hip.so)
+        {
+          void *bt[24];
+          const int nb = backtrace(bt, 24);
+          backtrace_symbols_fd(bt, nb, 2);
+        }
+        throw bk_error(BK_ERR_HIP, "hipMalloc of " + std::to_string(want) + " bytes failed (out of device memory, or a size that was computed from a bad count)");
+      }
       cap = want;
     }
     return p;
@@ -80,12 +93,11 @@ static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned) ((a + b 
 struct Cand
 {
   uint64_t qhash;
-  uint32_t rec;
+  uint64_t rec;  // index of the record in the whole sample (rec_base of its shard + index in the shard)
   int32_t tid, pos, mtid, mpos;
   uint16_t flag;
   uint8_t mapq, pad;
   uint32_t qcheck;  // second hash of the read name (0 = table without a qcheck column)
-  uint32_t pad2;
 };
 static_assert(sizeof(Cand) == 40, "Cand must be 40 bytes");
 

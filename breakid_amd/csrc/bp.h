@@ -36,7 +36,8 @@ struct BpBufs
 
 // clusters with a voted breakpoint pair (flags bit 1), counted on the device
 uint64_t count_valid_clusters(const bk_cluster *cl, uint64_t ncl, BpBufs &b, hipStream_t st);
-void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st);
+// rec_bits = bits of the largest record index a tuple may carry (the sort key)
+void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st, int rec_bits);
 // returns the number of clusters that passed the near-diagonal filter; clusters_out holds them in (group key order, id) order
 uint64_t cluster_summary(const bk_pair *pairs, const uint32_t *idx, const uint32_t *gof, const uint32_t *cl, uint64_t n, uint32_t ng, const uint32_t *gkey,
                          const uint32_t *glex, int32_t nt, double w, DevBuf &clusters_out, BpBufs &b, hipStream_t st);

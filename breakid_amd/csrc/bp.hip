@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_split_gather(const bk_split *__restrict
 
 static inline unsigned nb(uint64_t n) { return cdiv(n ? n : 1, 256); }
 
-void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st)
+void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hipStream_t st, int rec_bits)
 {
   if (n == 0) return;
   uint64_t *key = b.key.as<uint64_t>(n);
@@ -683,7 +683,7 @@ void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hi
   hipLaunchKernelGGL(k_split_keys, dim3(nb(n)), dim3(256), 0, st, unsorted, n, key, val);
   uint64_t *ks;
   uint32_t *vs;
-  prims::radix_sort_pairs(key, val, n, 0, 32, b.radix, st, &ks, &vs);
+  prims::radix_sort_pairs(key, val, n, 0, rec_bits, b.radix, st, &ks, &vs);
   hipLaunchKernelGGL(k_split_gather, dim3(nb(n)), dim3(256), 0, st, unsorted, vs, n, sorted);
 }
 

@@ -381,7 +381,6 @@ int main(int argc, char *argv[])
   // two lanes of chromosome-pair groups (csrc/api.hip: bk_mask_and_cluster) need more hardware queues than ROCm's default 4;
   // both are read when the runtime starts / at the first stage call, so they are set before anything touches the GPU
   setenv("GPU_MAX_HW_QUEUES", "16", 0);
-  setenv("BREAKID_GROUP_LANES", "2", 0);
   static struct option longopts[] = {{"help", 0, 0, 'h'}, {"i", 1, 0, 1}, {"o", 1, 0, 2}, {"q", 1, 0, 3}, {"n", 1, 0, 4},
                                      {"fast", 0, 0, 5},   {"t", 0, 0, 6}, {"all", 0, 0, 7}, {"gpu", 1, 0, 8}, {"gpus", 1, 0, 9},
                                      {"comm", 1, 0, 10},  {0, 0, 0, 0}};
@@ -503,7 +502,12 @@ int main(int argc, char *argv[])
       std::cerr << (rc == BK_ERR_CIGAR ? "error cigar: " : err) << std::endl;
       exit(rc == BK_ERR_CIGAR ? -1 : 1);
     }
+    double mean = 0, sd = 0;
+    (void) bk_multi_stats(ctx, &mean, &sd, nullptr, nullptr);
+    std::cout << "the insert size mean: " << mean << ", the insert size sd:" << sd << " .\n";
     std::cout << "cluster_dist = span_dist = mask_dist = scan_dist = " << w << " .\n";
+    std::cout << "Scanning discordant read pairs ...\n";
+    std::cout << "Scanning discordant read pairs done.\n";
     if (n_clustered) need_index();
   }
   else
@@ -617,7 +621,8 @@ int main(int argc, char *argv[])
     // LAST such group returned (:131-136; the reference leaves it uninitialised when no group qualifies - 0 here)
     const bk_group_stat *gs = nullptr;
     uint32_t ngs = 0;
-    if (!multi && (rc = bk_group_stats(ctx, &gs, &ngs)) != BK_OK) die(rc);  // (a sharded run keeps these per rank: the counters stay 0)
+    if (!multi && (rc = bk_group_stats(ctx, &gs, &ngs)) != BK_OK) die(rc);
+    if (multi && (rc = bk_multi_stats(ctx, nullptr, nullptr, &gs, &ngs)) != BK_OK) die(rc);  // (summed over the ranks)
     int removed_isolated_pair_count = 0, root_cluster_num = 0;
     for (uint32_t g = 0; g < ngs; ++g)
       if (gs[g].n_isolated_removed >= 2)
@@ -632,7 +637,10 @@ int main(int argc, char *argv[])
       << "\t" << (cluster_end - cluster_start) / double(CLOCKS_PER_SEC) << "\t" << (bp_end - bp_start) / double(CLOCKS_PER_SEC) << "\t"
       << (end - start) / double(CLOCKS_PER_SEC) << std::endl;
   }
-  bk_free(ctx);
+  if (multi)
+    bk_multi_free(ctx);
+  else
+    bk_free(ctx);
   if (bam) bk_bam_close(bam);
   if (dbam) bk_bam_dev_free(dbam);
   return 0;

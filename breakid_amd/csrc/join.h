@@ -6,11 +6,14 @@
 
 struct JoinBufs
 {
-  DevBuf counter, unsorted, okey, oval, key, val, pairs, gof, gflag, gscan, gstart, gkey, scan_tmp, route_cand, route_cnt, route_pairs, route_off;
+  DevBuf counter, unsorted, okey, oval, key, val, pairs, gof, gflag, gscan, gstart, gkey, scan_tmp, route_cand, route_cnt, route_pairs, route_off, maxrec;
   prims::RadixBufs radix;
   // bits a record index needs (the caller's table: records of the whole sample); the pair sort key is (chr-pair key << rec_bits) |
   // discovery index, so that the sort runs over rec_bits + key bits instead of 32 + key bits
+  // < 0: a sharded sample - the indices are rec_base + i of other ranks too (64 bits in Cand / bk_pair): the bits are taken from the
+  // largest index among the candidates / pairs at hand
   int rec_bits = 32;
+  int rec_bits_eff = 32;  // what the last join / grouping used
 };
 
 struct JoinResult

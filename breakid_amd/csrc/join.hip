@@ -116,6 +116,7 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
     p.id = 0;
     p.cluster = -1;
     p.group = 0;
+    p.reserved = 0;
     append(p);
   }
 }
@@ -207,6 +208,30 @@ __global__ __launch_bounds__(256) void k_assign_ids(bk_pair *__restrict__ pairs,
   pairs[i].group = glex[g];
   pairs[i].id = (uint32_t) (i - gstart[g]);
 }
+// the largest discovery index among candidates / pairs (a sharded sample: the indices are the whole sample's, the table at hand does
+// not tell how many bits they need)
+__global__ __launch_bounds__(256) void k_max_rec_cand(const Cand *__restrict__ c, uint64_t n, unsigned long long *__restrict__ out)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = i < n ? (unsigned long long) c[i].rec : 0ull;
+  for (int d = 32; d >= 1; d >>= 1)
+  {
+    const unsigned long long o = __shfl_xor(v, d, 64);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+__global__ __launch_bounds__(256) void k_max_rec_pair(const bk_pair *__restrict__ p, uint64_t n, unsigned long long *__restrict__ out)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = i < n ? (unsigned long long) p[i].rec : 0ull;
+  for (int d = 32; d >= 1; d >>= 1)
+  {
+    const unsigned long long o = __shfl_xor(v, d, 64);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
 // sort key of a pair: (numeric chr-pair key, discovery index)
 __global__ __launch_bounds__(256) void k_pair_keys(const bk_pair *__restrict__ p, uint64_t n, int32_t nt, uint64_t *__restrict__ okey, uint32_t *__restrict__ oval, int rbits)
 {
@@ -291,9 +316,32 @@ __global__ __launch_bounds__(256) void k_join_fix_runs(uint64_t *__restrict__ ke
   }
 }
 
+// bits of the discovery index in the pair sort key: what the caller knows (its own table), or - rec_bits < 0, a sharded sample -
+// what the largest index at hand needs; together with the chr-pair key it must fit the 64-bit sort key
+template <class T, class K> static int effective_rec_bits(const T *items, uint64_t n, K kernel, int32_t nt, JoinBufs &b, hipStream_t st)
+{
+  int bits = b.rec_bits;
+  if (bits < 0)
+  {
+    unsigned long long *m = b.maxrec.as<unsigned long long>(1), h = 0;
+    HIP_CHECK(hipMemsetAsync(m, 0, 8, st));
+    if (n) hipLaunchKernelGGL(kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, items, n, m);
+    HIP_CHECK(hipMemcpyAsync(&h, m, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    bits = 1;
+    while (bits < 63 && (1ull << bits) <= h) ++bits;
+  }
+  int gbits = 1;
+  while ((1ull << gbits) < (uint64_t) (nt + 1) * (uint64_t) (nt + 1) && gbits < 32) ++gbits;
+  if (bits + gbits > 64) throw bk_error(BK_ERR_LIMIT, "pair sort key: chromosome-pair key and record index need more than 64 bits");
+  b.rec_bits_eff = bits;
+  return bits;
+}
+
 static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, const uint32_t *tprefix, int32_t nt, JoinBufs &b, hipStream_t st)
 {
   if (n_cand > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 discordant candidates");
+  const int rec_bits = effective_rec_bits(cand, n_cand, k_max_rec_cand, nt, b, st);
   unsigned long long *counter = b.counter.as<unsigned long long>(2);
   uint32_t *err = (uint32_t *) (counter + 1);
   HIP_CHECK(hipMemsetAsync(counter, 0, 16, st));
@@ -315,7 +363,7 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
       prims::radix_sort_pairs(key, val, n_cand, attempt == 0 ? 32 : 0, 64, b.radix, st, &ks, &vs);
       if (attempt == 0) hipLaunchKernelGGL(k_join_fix_runs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, ks, vs, n_cand, err);
       hipLaunchKernelGGL(k_join_pairs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, ks, vs, n_cand, w, tprefix, nt, unsorted, okey, oval,
-                         (unsigned long long) cap, counter, err, b.rec_bits);
+                         (unsigned long long) cap, counter, err, rec_bits);
     }
     HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -347,7 +395,7 @@ static void group_sorted(const bk_pair *unsorted, uint64_t *okey, uint32_t *oval
   while ((1ull << gbits) < (uint64_t) (nt + 1) * (uint64_t) (nt + 1) && gbits < 32) ++gbits;
   uint64_t *ks;
   uint32_t *vs;
-  const int rbits = b.rec_bits;
+  const int rbits = b.rec_bits_eff;
   prims::radix_sort_pairs(okey, oval, np, 0, rbits + gbits, b.radix, st, &ks, &vs);
   uint32_t *gflag = b.gflag.as<uint32_t>(np + 1);
   uint32_t *gscan = b.gscan.as<uint32_t>(np + 1);
@@ -375,7 +423,8 @@ void group_pairs(const bk_pair *raw, uint64_t np, int32_t nt, JoinBufs &b, hipSt
   if (np > 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 pairs");
   uint64_t *okey = b.okey.as<uint64_t>(np + 1);
   uint32_t *oval = b.oval.as<uint32_t>(np + 1);
-  if (np) hipLaunchKernelGGL(k_pair_keys, dim3(cdiv(np, 256)), dim3(256), 0, st, raw, np, nt, okey, oval, b.rec_bits);
+  const int rec_bits = effective_rec_bits(raw, np, k_max_rec_pair, nt, b, st);
+  if (np) hipLaunchKernelGGL(k_pair_keys, dim3(cdiv(np, 256)), dim3(256), 0, st, raw, np, nt, okey, oval, rec_bits);
   group_sorted(raw, okey, oval, np, nt, b, st, res);
 }
 

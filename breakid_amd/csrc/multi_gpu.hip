@@ -7,6 +7,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -40,59 +43,9 @@ struct Transport
   virtual void allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) = 0;
 };
 
-// ---- RCCL: one rank per GPU --------------------------------------------------------------------------------------------------
-struct RcclTransport : Transport
-{
-  ncclComm_t comm = nullptr;
-  DevBuf sin, sout;
-  ~RcclTransport() override
-  {
-    if (comm) (void) ncclCommDestroy(comm);
-  }
-  void allgather_host(const void *in, size_t bytes, void *out, hipStream_t st) override
-  {
-    void *di = sin.ensure(bytes + 16), *dout = sout.ensure(bytes * world + 16);
-    HIP_CHECK(hipMemcpyAsync(di, in, bytes, hipMemcpyHostToDevice, st));
-    NCCL_CHECK(ncclAllGather(di, dout, bytes, ncclChar, comm, st));
-    HIP_CHECK(hipMemcpyAsync(out, dout, bytes * world, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-  }
-  void allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) override
-  {
-    // one broadcast per root inside a group: no padding to the largest rank, no staging copy
-    size_t off = 0;
-    NCCL_CHECK(ncclGroupStart());
-    for (int r = 0; r < world; ++r)
-    {
-      if (sizes[r])
-      {
-        char *dst = (char *) recv + off;
-        NCCL_CHECK(ncclBroadcast(r == rank ? send : (const void *) dst, dst, sizes[r], ncclChar, r, comm, st));
-      }
-      off += sizes[r];
-    }
-    NCCL_CHECK(ncclGroupEnd());
-  }
-  void alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) override
-  {
-    size_t so = 0, ro = 0;
-    NCCL_CHECK(ncclGroupStart());
-    for (int r = 0; r < world; ++r)
-    {
-      if (sb[r]) NCCL_CHECK(ncclSend((const char *) send + so, sb[r], ncclChar, r, comm, st));
-      if (rb[r]) NCCL_CHECK(ncclRecv((char *) recv + ro, rb[r], ncclChar, r, comm, st));
-      so += sb[r];
-      ro += rb[r];
-    }
-    NCCL_CHECK(ncclGroupEnd());
-  }
-  void allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) override
-  {
-    if (count) NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclUint32, ncclSum, comm, st));
-  }
-};
-
-// ---- contexts of one process: device-to-device copies, threads meet at a barrier ------------------------------------------------
+// ---- the rank threads of this process meet here: before every exchange (both transports), so that a rank that failed on its own
+// (a corrupt block in its part of the file, out of memory on its GPU, an error raised in its shard) takes the others out with
+// "another rank failed" instead of leaving them inside a collective nobody else will enter ---------------------------------------
 struct LocalHub
 {
   int world;
@@ -127,6 +80,71 @@ struct LocalHub
     cv.notify_all();
   }
 };
+// ---- RCCL: one rank per GPU --------------------------------------------------------------------------------------------------
+struct RcclTransport : Transport
+{
+  ncclComm_t comm = nullptr;
+  LocalHub *hub = nullptr;
+  std::atomic<bool> aborted{false};
+  DevBuf sin, sout;
+  ~RcclTransport() override
+  {
+    if (comm && !aborted.exchange(true)) (void) ncclCommDestroy(comm);
+  }
+  // a collective is only queued when every rank thread has arrived in front of it in good health (LocalHub::barrier throws on
+  // all of them otherwise); what is left is a failure INSIDE a librccl call, for which the failing rank aborts every communicator
+  void abort_comm()
+  {
+    if (comm && !aborted.exchange(true)) (void) ncclCommAbort(comm);
+  }
+  void allgather_host(const void *in, size_t bytes, void *out, hipStream_t st) override
+  {
+    hub->barrier();
+    void *di = sin.ensure(bytes + 16), *dout = sout.ensure(bytes * world + 16);
+    HIP_CHECK(hipMemcpyAsync(di, in, bytes, hipMemcpyHostToDevice, st));
+    NCCL_CHECK(ncclAllGather(di, dout, bytes, ncclChar, comm, st));
+    HIP_CHECK(hipMemcpyAsync(out, dout, bytes * world, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  void allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) override
+  {
+    // one broadcast per root inside a group: no padding to the largest rank, no staging copy
+    hub->barrier();
+    size_t off = 0;
+    NCCL_CHECK(ncclGroupStart());
+    for (int r = 0; r < world; ++r)
+    {
+      if (sizes[r])
+      {
+        char *dst = (char *) recv + off;
+        NCCL_CHECK(ncclBroadcast(r == rank ? send : (const void *) dst, dst, sizes[r], ncclChar, r, comm, st));
+      }
+      off += sizes[r];
+    }
+    NCCL_CHECK(ncclGroupEnd());
+  }
+  void alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) override
+  {
+    hub->barrier();
+    size_t so = 0, ro = 0;
+    NCCL_CHECK(ncclGroupStart());
+    for (int r = 0; r < world; ++r)
+    {
+      if (sb[r]) NCCL_CHECK(ncclSend((const char *) send + so, sb[r], ncclChar, r, comm, st));
+      if (rb[r]) NCCL_CHECK(ncclRecv((char *) recv + ro, rb[r], ncclChar, r, comm, st));
+      so += sb[r];
+      ro += rb[r];
+    }
+    NCCL_CHECK(ncclGroupEnd());
+  }
+  void allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) override
+  {
+    hub->barrier();
+    if (count) NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclUint32, ncclSum, comm, st));
+  }
+};
+
+// ---- contexts of one process: device-to-device copies between the meetings ------------------------------------------------------
 struct LocalTransport : Transport
 {
   LocalHub *hub = nullptr;
@@ -245,7 +263,12 @@ uint64_t gather_table(bk_ctx *ctx, Transport &T, int which, Keep &keep, hipStrea
   return total / eb;
 }
 
-void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, double *w_out, uint64_t *n_clustered_total, Keep &keep)
+struct RankSummary
+{
+  double mean = 0, sd = 0;
+  std::vector<bk_group_stat> groups;  // every group of the sample in the reference's order, summed over the ranks (a group lives on one)
+};
+void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, double *w_out, uint64_t *n_clustered_total, Keep &keep, RankSummary &sum)
 {
   void *stv = nullptr;
   BK_CALL(bk_get_stream(ctx, &stv));
@@ -380,6 +403,63 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
     T.allgather_host(&n_clustered, 8, all.data(), st);
     if (n_clustered_total) *n_clustered_total = std::accumulate(all.begin(), all.end(), (uint64_t) 0);
   }
+  {
+    // per-group counters (the _performance.txt columns of BreakID.cc:175-191): every context lists all groups of the sample in the
+    // same order and holds the pairs of the groups it owns, so the rows add up over the ranks
+    const bk_group_stat *gs = nullptr;
+    uint32_t ngs = 0;
+    BK_CALL(bk_group_stats(ctx, &gs, &ngs));
+    sum.mean = mean;
+    sum.sd = sd;
+    sum.groups.assign(gs, gs + ngs);
+    if (W > 1)
+    {
+      // a rank that received no pairs lists no groups: every rank sends as many rows as the longest list (the others padded), the
+      // longest list gives the order, the counters are summed by chromosome pair
+      uint64_t mine = ngs;
+      std::vector<uint64_t> cnts(W);
+      T.allgather_host(&mine, 8, cnts.data(), st);
+      const uint64_t mx = *std::max_element(cnts.begin(), cnts.end());
+      if (mx)
+      {
+        std::vector<bk_group_stat> send((size_t) mx), all((size_t) W * mx);
+        for (uint64_t g = 0; g < mx; ++g)
+        {
+          if (g < ngs)
+            send[g] = gs[g];
+          else
+          {
+            send[g] = bk_group_stat{};
+            send[g].p1_tid = send[g].p2_tid = INT32_MIN;
+          }
+        }
+        T.allgather_host(send.data(), (size_t) mx * sizeof(bk_group_stat), all.data(), st);
+        int lead = 0;
+        while (cnts[lead] != mx) ++lead;
+        sum.groups.assign(all.begin() + (size_t) lead * mx, all.begin() + (size_t) (lead + 1) * mx);
+        std::map<std::pair<int32_t, int32_t>, size_t> at;
+        for (size_t g = 0; g < sum.groups.size(); ++g)
+        {
+          bk_group_stat &o = sum.groups[g];
+          at[{o.p1_tid, o.p2_tid}] = g;
+          o.n_scan = o.n_isolated_removed = o.n_clustered = 0;
+          o.cluster_id_end = 0;
+        }
+        for (int r = 0; r < W; ++r)
+          for (uint64_t g = 0; g < cnts[r]; ++g)
+          {
+            const bk_group_stat &x = all[(size_t) r * mx + g];
+            auto it = at.find({x.p1_tid, x.p2_tid});
+            if (it == at.end()) continue;
+            bk_group_stat &o = sum.groups[it->second];
+            o.n_scan += x.n_scan;
+            o.n_isolated_removed += x.n_isolated_removed;
+            o.n_clustered += x.n_clustered;
+            o.cluster_id_end = std::max(o.cluster_id_end, x.cluster_id_end);
+          }
+      }
+    }
+  }
   // evidence tuples and cluster summaries to everybody
   gather_table(ctx, T, BK_BUF_TUPLES, keep, st);
   const uint64_t ncl = gather_table(ctx, T, BK_BUF_CLUSTERS, keep, st);
@@ -421,6 +501,23 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
 // from the file) and returns the rank's record count; the counts give every rank its rec_base.
 namespace
 {
+// what the context handed out by bk_multi_run / bk_multi_run_bam points at (gathered tables, rank 0's decoded records)
+struct Owned
+{
+  Keep keep;
+  bk_bam_dev *bam = nullptr;
+  RankSummary sum;
+};
+std::map<bk_ctx *, Owned> &owned()
+{
+  static std::map<bk_ctx *, Owned> *m = new std::map<bk_ctx *, Owned>();
+  return *m;
+}
+std::mutex &owned_m()
+{
+  static std::mutex *m = new std::mutex();
+  return *m;
+}
 struct RankInput
 {
   bk_ctx *ctx = nullptr;
@@ -450,6 +547,15 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
   if (transport == BK_TRANSPORT_RCCL && ncclGetUniqueId(&id) != ncclSuccess) return fail(BK_ERR_HIP, "ncclGetUniqueId failed");
   LocalHub hub(W);
   std::vector<Keep> keeps(W);
+  std::vector<RankSummary> sums(W);
+  std::vector<RcclTransport *> rccl(W, nullptr);
+  std::mutex rccl_m;
+  auto fail_all = [&] {
+    hub.fail();
+    std::lock_guard<std::mutex> l(rccl_m);
+    for (RcclTransport *t : rccl)
+      if (t) t->abort_comm();
+  };
   std::vector<std::thread> th;
   for (int r = 0; r < W; ++r)
     th.emplace_back([&, r] {
@@ -464,7 +570,10 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
           T.reset(t);
           t->rank = r;
           t->world = W;
+          t->hub = &hub;
           NCCL_CHECK(ncclCommInitRank(&t->comm, W, id, r));
+          std::lock_guard<std::mutex> l(rccl_m);
+          rccl[r] = t;
         }
         else
         {
@@ -484,19 +593,23 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
         T->allgather_host(&in.n, 8, counts.data(), (hipStream_t) stv);
         uint64_t base = 0;
         for (int k = 0; k < r; ++k) base += counts[k];
-        run_rank(in.ctx, *T, base, mapq_min, fast, &ws[r], &ncl[r], keeps[r]);
+        run_rank(in.ctx, *T, base, mapq_min, fast, &ws[r], &ncl[r], keeps[r], sums[r]);
       }
       catch (const bk_error &e)
       {
         codes[r] = e.code;
         errs[r] = e.msg;
-        hub.fail();
+        fail_all();
       }
       catch (const std::exception &e)
       {
         codes[r] = BK_ERR_HIP;
         errs[r] = e.what();
-        hub.fail();
+        fail_all();
+      }
+      {
+        std::lock_guard<std::mutex> l(rccl_m);  // (the transport dies with this thread)
+        rccl[r] = nullptr;
       }
     });
   for (auto &t : th) t.join();
@@ -520,10 +633,13 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
     release_rank(0);
     return fail(rc, msg);
   }
-  // rank 0's context keeps pointing at its gathered tables (and at its records): their ownership goes to a registry that lives
-  // as long as the process
-  static std::vector<Keep> *registry = new std::vector<Keep>();
-  registry->push_back(std::move(keeps[0]));
+  // rank 0's context keeps pointing at its gathered tables (and at its records): they are parked under the context and released
+  // by bk_multi_free
+  {
+    std::lock_guard<std::mutex> l(owned_m());
+    owned()[ctxs[0]].keep = std::move(keeps[0]);
+    owned()[ctxs[0]].sum = std::move(sums[0]);
+  }
   if (w_out) *w_out = ws[0];
   if (n_clustered_total) *n_clustered_total = ncl[0];
   *ctx0_out = ctxs[0];
@@ -607,7 +723,6 @@ extern "C" int bk_multi_run_bam(const char *path, int n_gpus, int transport, int
   };
   // the records of a rank live in its bk_bam_dev: released behind its context (multi_run_common does that for rank 0 only when
   // the run failed: after a good run rank 0's records stay with the context that is handed out, for the life of the process)
-  static std::vector<bk_bam_dev *> *kept = new std::vector<bk_bam_dev *>();
   auto release_rank = [&](int r) {
     if (bams[r]) bk_bam_dev_free(bams[r]);
     bams[r] = nullptr;
@@ -616,10 +731,47 @@ extern "C" int bk_multi_run_bam(const char *path, int n_gpus, int transport, int
   const bool ok = rc == BK_OK;
   if (ok)
   {
-    kept->push_back(bams[0]);
+    {
+      std::lock_guard<std::mutex> l(owned_m());
+      owned()[*ctx0_out].bam = bams[0];
+    }
     if (n_targets) *n_targets = nts[0];
     if (names) *names = nms[0];
     if (lens) *lens = lns[0];
   }
   return rc;
+}
+
+// releases the context of a finished bk_multi_run / bk_multi_run_bam together with the tables it points at (gathered tuples /
+// clusters, rank 0's decoded records and reference names); a context of plain bk_init is simply freed
+extern "C" void bk_multi_free(bk_ctx *ctx)
+{
+  if (!ctx) return;
+  Owned o;
+  bool found = false;
+  {
+    std::lock_guard<std::mutex> l(owned_m());
+    auto it = owned().find(ctx);
+    if (it != owned().end())
+    {
+      o = std::move(it->second);
+      owned().erase(it);
+      found = true;
+    }
+  }
+  bk_free(ctx);  // first the context, then what it pointed at
+  if (found && o.bam) bk_bam_dev_free(o.bam);
+}
+
+// insert-size statistics and per-group counters of the finished run behind `ctx` (what bk_isize_stats / bk_group_stats give for one GPU)
+extern "C" int bk_multi_stats(bk_ctx *ctx, double *mean, double *sd, const bk_group_stat **groups, uint32_t *n_groups)
+{
+  std::lock_guard<std::mutex> l(owned_m());
+  auto it = owned().find(ctx);
+  if (it == owned().end()) return BK_ERR_ARG;
+  if (mean) *mean = it->second.sum.mean;
+  if (sd) *sd = it->second.sum.sd;
+  if (groups) *groups = it->second.sum.groups.data();
+  if (n_groups) *n_groups = (uint32_t) it->second.sum.groups.size();
+  return BK_OK;
 }

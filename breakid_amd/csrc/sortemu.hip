@@ -22,6 +22,7 @@
 #include "prims.h"
 #include "sortemu.h"
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -79,12 +80,14 @@ __device__ __forceinline__ void fin_append(FinSeg *__restrict__ fl, uint32_t *__
 }
 
 // cnt entries: (#segments) | (#elements in them) << 32, scanned together
-__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsigned long long *__restrict__ cnt, FinSeg *__restrict__ fl, uint32_t *__restrict__ fin)
+__global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsigned long long *__restrict__ cnt, FinSeg *__restrict__ fl, uint32_t *__restrict__ fin,
+                          uint32_t *__restrict__ max_size)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   uint64_t sz = goff[g + 1] - goff[g];
   cnt[g] = sz > FIN_MAX ? (1ull | (sz << 32)) : 0ull;
+  if (sz > FIN_MAX) atomicMax(max_size, (uint32_t) sz);  // largest live segment of level 0
   if (sz > 16 && sz <= FIN_MAX) fin_append(fl, fin, (uint32_t) goff[g], (uint32_t) goff[g + 1], 2 * (63 - __clzll((long long) sz)));
 }
 __global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs, uint32_t *__restrict__ tile_seg)
@@ -1409,20 +1412,15 @@ __device__ __forceinline__ uint32_t lv_flags(const Seg &sg, uint32_t c, uint32_t
   }
   return v;
 }
-__global__ __launch_bounds__(256) void k_lv_count(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na, unsigned long long *__restrict__ tile_cnt,
-                                                  const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
+// one tile of a level pass: vb = tile number (blockIdx.x in the per-level launches, a loop variable in k_lv_persist); the shared
+// scratch belongs to the caller; every thread of the 256-thread workgroup calls it, ns / na are the level's live counts
+__device__ __forceinline__ void lv_count_tile(const Seg *segs, uint32_t ns, const uint32_t *key, uint32_t na, unsigned long long *tile_cnt,
+                                              const uint32_t *tile_seg, uint32_t vb, LvTile *sh, uint32_t *s_scan)
 {
-  __shared__ LvTile sh;
-  __shared__ uint32_t s_scan[prims::WAVES];
-  if (lvl)
-  {
-    ns = lvl[0];
-    na = lvl[1];
-  }
-  const uint32_t c0 = blockIdx.x * LV_TILE;
+  const uint32_t c0 = vb * LV_TILE;
   if (c0 >= na) return;
-  lv_tile_setup(segs, ns, c0, &sh, tile_seg);
-  const Seg A = sh.a, B = sh.b;
+  lv_tile_setup(segs, ns, c0, sh, tile_seg);
+  const Seg A = sh->a, B = sh->b;
   uint32_t acc = 0;
 #pragma unroll
   for (uint32_t k = 0; k < LV_EPT; ++k)
@@ -1436,21 +1434,28 @@ __global__ __launch_bounds__(256) void k_lv_count(const Seg *__restrict__ segs, 
   }
   uint32_t tot;
   (void) prims::block_exclusive_scan(acc, s_scan, tot);
-  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (unsigned long long) (tot & 0xFFFFu) | ((unsigned long long) (tot >> 16) << 32);
+  if (threadIdx.x == 0) tile_cnt[vb] = (unsigned long long) (tot & 0xFFFFu) | ((unsigned long long) (tot >> 16) << 32);
 }
-constexpr uint32_t LV_SUM_THREADS = 1024;
-__global__ __launch_bounds__(LV_SUM_THREADS) void k_lv_sums(unsigned long long *__restrict__ tile_cnt, uint32_t ns, uint32_t na, unsigned long long *__restrict__ segbase,
-                                                            const uint32_t *__restrict__ lvl)
+__global__ __launch_bounds__(256) void k_lv_count(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na, unsigned long long *__restrict__ tile_cnt,
+                                                  const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
 {
-  __shared__ unsigned long long wsum[LV_SUM_THREADS / 64];
+  __shared__ LvTile sh;
+  __shared__ uint32_t s_scan[prims::WAVES];
   if (lvl)
   {
     ns = lvl[0];
     na = lvl[1];
   }
+  lv_count_tile(segs, ns, key, na, tile_cnt, tile_seg, blockIdx.x, &sh, s_scan);
+}
+constexpr uint32_t LV_SUM_THREADS = 1024;
+// exclusive scan of the tile totals by ONE workgroup of T threads (wsum: T / 64 entries)
+template <uint32_t T> __device__ __forceinline__ void lv_sums_body(unsigned long long *tile_cnt, uint32_t ns, uint32_t na, unsigned long long *segbase,
+                                                                   unsigned long long *wsum)
+{
   const uint32_t nt = (na + LV_TILE - 1) / LV_TILE, t = threadIdx.x, lane = t & 63, w = t >> 6;
   unsigned long long carry = 0;
-  for (uint32_t base = 0; base < nt; base += LV_SUM_THREADS)
+  for (uint32_t base = 0; base < nt; base += T)
   {
     const uint32_t i = base + t;
     const unsigned long long v = i < nt ? tile_cnt[i] : 0ull;
@@ -1458,7 +1463,7 @@ __global__ __launch_bounds__(LV_SUM_THREADS) void k_lv_sums(unsigned long long *
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     unsigned long long pre = 0, tot = 0;
-    for (uint32_t j = 0; j < LV_SUM_THREADS / 64; ++j)
+    for (uint32_t j = 0; j < T / 64; ++j)
     {
       const unsigned long long x = wsum[j];
       if (j < w) pre += x;
@@ -1470,23 +1475,28 @@ __global__ __launch_bounds__(LV_SUM_THREADS) void k_lv_sums(unsigned long long *
   }
   if (t == 0) segbase[ns] = carry;
 }
-__global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
-                                                  const unsigned long long *__restrict__ tile_base, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR,
-                                                  unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
+__global__ __launch_bounds__(LV_SUM_THREADS) void k_lv_sums(unsigned long long *__restrict__ tile_cnt, uint32_t ns, uint32_t na, unsigned long long *__restrict__ segbase,
+                                                            const uint32_t *__restrict__ lvl)
 {
-  __shared__ LvTile sh;
-  __shared__ uint32_t s_scan[prims::WAVES];
-  __shared__ uint32_t s_key[LV_TILE + LV_TILE / 32];  // one pad word per 32: a thread's LV_EPT consecutive keys spread over the banks
+  __shared__ unsigned long long wsum[LV_SUM_THREADS / 64];
   if (lvl)
   {
     ns = lvl[0];
     na = lvl[1];
   }
-  const uint32_t c0 = blockIdx.x * LV_TILE;
+  lv_sums_body<LV_SUM_THREADS>(tile_cnt, ns, na, segbase, wsum);
+}
+constexpr uint32_t LV_KEYS_LDS = LV_TILE + LV_TILE / 32;  // one pad word per 32: a thread's LV_EPT consecutive keys spread over the banks
+__device__ __forceinline__ void lv_lists_tile(const Seg *segs, uint32_t ns, const uint32_t *key, uint32_t na,
+                                              const unsigned long long *tile_base, uint32_t *posL, uint32_t *posR,
+                                              unsigned long long *segbase, const uint32_t *tile_seg, uint32_t vb, LvTile *sh, uint32_t *s_scan,
+                                              uint32_t *s_key)
+{
+  const uint32_t c0 = vb * LV_TILE;
   if (c0 >= na) return;
-  lv_tile_setup(segs, ns, c0, &sh, tile_seg);
-  const Seg A = sh.a, B = sh.b;
-  const uint32_t s0 = sh.s0;
+  lv_tile_setup(segs, ns, c0, sh, tile_seg);
+  const Seg A = sh->a, B = sh->b;
+  const uint32_t s0 = sh->s0;
 #pragma unroll
   for (uint32_t k = 0; k < LV_EPT; ++k)
   {
@@ -1510,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, 
   }
   uint32_t tot;
   const uint32_t ex = prims::block_exclusive_scan(sum, s_scan, tot);
-  const unsigned long long tb = tile_base[blockIdx.x];
+  const unsigned long long tb = tile_base[vb];
   uint32_t runL = (uint32_t) tb + (ex & 0xFFFFu), runR = (uint32_t) (tb >> 32) + (ex >> 16);
 #pragma unroll
   for (uint32_t k = 0; k < LV_EPT; ++k)
@@ -1525,22 +1535,29 @@ __global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, 
     if (f[k] >> 16) posR[runR++] = p;
   }
 }
-__global__ __launch_bounds__(256) void k_lv_swap(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
-                                                 const unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR,
-                                                 const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
+__global__ __launch_bounds__(256) void k_lv_lists(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
+                                                  const unsigned long long *__restrict__ tile_base, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR,
+                                                  unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
 {
   __shared__ LvTile sh;
-  __shared__ unsigned long long s_base[3];
+  __shared__ uint32_t s_scan[prims::WAVES];
+  __shared__ uint32_t s_key[LV_KEYS_LDS];
   if (lvl)
   {
     ns = lvl[0];
     na = lvl[1];
   }
-  const uint32_t c0 = blockIdx.x * LV_TILE;
+  lv_lists_tile(segs, ns, key, na, tile_base, posL, posR, segbase, tile_seg, blockIdx.x, &sh, s_scan, s_key);
+}
+__device__ __forceinline__ void lv_swap_tile(Seg *segs, uint32_t ns, uint32_t *key, uint32_t *idx, uint32_t na,
+                                             const unsigned long long *segbase, const uint32_t *posL, const uint32_t *posR,
+                                             const uint32_t *tile_seg, uint32_t vb, LvTile *sh, unsigned long long *s_base)
+{
+  const uint32_t c0 = vb * LV_TILE;
   if (c0 >= na) return;
-  lv_tile_setup(segs, ns, c0, &sh, tile_seg);
-  const Seg A = sh.a, B = sh.b;
-  const uint32_t s0 = sh.s0;
+  lv_tile_setup(segs, ns, c0, sh, tile_seg);
+  const Seg A = sh->a, B = sh->b;
+  const uint32_t s0 = sh->s0;
   if (threadIdx.x < 3) s_base[threadIdx.x] = s0 + threadIdx.x <= ns ? segbase[s0 + threadIdx.x] : 0ull;
   __syncthreads();
 #pragma unroll
@@ -1584,6 +1601,19 @@ __global__ __launch_bounds__(256) void k_lv_swap(Seg *__restrict__ segs, uint32_
         segs[s].cut = lj < rprev ? lj : rprev;  // cut = min(l_J, r_{J-1})
     }
   }
+}
+__global__ __launch_bounds__(256) void k_lv_swap(Seg *__restrict__ segs, uint32_t ns, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
+                                                 const unsigned long long *__restrict__ segbase, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR,
+                                                 const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ tile_seg)
+{
+  __shared__ LvTile sh;
+  __shared__ unsigned long long s_base[3];
+  if (lvl)
+  {
+    ns = lvl[0];
+    na = lvl[1];
+  }
+  lv_swap_tile(segs, ns, key, idx, na, segbase, posL, posR, tile_seg, blockIdx.x, &sh, s_base);
 }
 
 __global__ void k_se_child_count(const Seg *__restrict__ segs, uint32_t ns, unsigned long long *__restrict__ cnt)
@@ -1638,17 +1668,15 @@ __global__ void k_se_child_write(const Seg *__restrict__ segs, uint32_t ns, cons
 // launches in one) and leaves the next level's {segments, elements} in lvl, so that the host can queue several levels
 // before it looks (the level kernels read lvl; their grids are sized for bounds).
 constexpr uint32_t CHILD_THREADS = 1024, CHILD_PER = 8, CHILD_FUSED = CHILD_THREADS * CHILD_PER;
-__global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *__restrict__ segs, uint32_t *__restrict__ lvl, Seg *__restrict__ out, FinSeg *__restrict__ fl,
-                                                                     uint32_t *__restrict__ fin, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
-                                                                     uint2 *__restrict__ heap_list, uint32_t *__restrict__ tile_seg)
+template <uint32_t T> __device__ __forceinline__ void children_small_body(const Seg *segs, uint32_t *lvl, Seg *out, FinSeg *fl,
+                                                                          uint32_t *fin, uint32_t *key, uint32_t *idx, uint32_t *err,
+                                                                          uint2 *heap_list, uint32_t *tile_seg, unsigned long long *wsum, uint32_t *s_max)
 {
-  __shared__ unsigned long long wsum[CHILD_THREADS / 64];
-  __shared__ uint32_t s_max;
-  if (threadIdx.x == 0) s_max = 0;
+  if (threadIdx.x == 0) *s_max = 0;
   const uint32_t ns = lvl[0];
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
   // thread t takes segments [t * per, (t + 1) * per): one each while they are few
-  const uint32_t per = (ns + CHILD_THREADS - 1) / CHILD_THREADS;
+  const uint32_t per = (ns + T - 1) / T;
   unsigned long long v = 0;
   uint32_t lmax = 0;  // largest live child (lvl[2]: the host hands the tail of the loop to k_se_tail once it is small)
   for (uint32_t k = 0; k < per; ++k)
@@ -1670,10 +1698,10 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
     if ((int) lane >= d) inc += o;
   }
   if (lane == 63) wsum[w] = inc;
-  if (lmax) atomicMax(&s_max, lmax);
+  if (lmax) atomicMax(s_max, lmax);
   __syncthreads();  // (every thread has read lvl[0] by now)
   unsigned long long base = 0, tot = 0;
-  for (uint32_t i = 0; i < CHILD_THREADS / 64; ++i)
+  for (uint32_t i = 0; i < T / 64; ++i)
   {
     const unsigned long long x = wsum[i];
     if (i < w) base += x;
@@ -1683,7 +1711,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
   {
     lvl[0] = (uint32_t) tot;
     lvl[1] = (uint32_t) (tot >> 32);
-    lvl[2] = s_max;
+    lvl[2] = *s_max;
   }
   const unsigned long long off = base + inc - v;
   uint32_t o = (uint32_t) off, cb = (uint32_t) (off >> 32);
@@ -1718,6 +1746,342 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
     }
     else if (b > 16)
       fin_append(fl, fin, sg.cut, sg.last, sg.depth);
+  }
+}
+__global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *__restrict__ segs, uint32_t *__restrict__ lvl, Seg *__restrict__ out, FinSeg *__restrict__ fl,
+                                                                     uint32_t *__restrict__ fin, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t *__restrict__ err,
+                                                                     uint2 *__restrict__ heap_list, uint32_t *__restrict__ tile_seg)
+{
+  __shared__ unsigned long long wsum[CHILD_THREADS / 64];
+  __shared__ uint32_t s_max;
+  children_small_body<CHILD_THREADS>(segs, lvl, out, fl, fin, key, idx, err, heap_list, tile_seg, wsum, &s_max);
+}
+
+// ---- every remaining level of the loop in ONE launch --------------------------------------------------------------------------
+// Once a level holds at most CHILD_FUSED segments the five launches of a level are bound by launch latency, not by work (a level
+// of a few tiles costs ~50 us of dependent launches and a host look every sixth level; the sorts of a WGS sample spend 25-30 of
+// their ~36 levels there).  k_lv_persist plays the same five phases - the same tile functions - for all levels that are left, in a
+// grid of at most LVP_MAX_WG resident workgroups that meet at a counter in global memory between the phases (~2-3.5 us for 8-32
+// workgroups, tools/ubench/gridbar.hip; a dependent launch costs ~10 us here).  The number of workgroups that take part follows
+// the live elements down (it never grows): a workgroup that is not needed any more leaves for good, and the last one runs the
+// tail of the loop with workgroup barriers only.
+constexpr uint32_t LVP_MAX_WG = 32, LVP_TILES_PER_WG = 4;
+struct LvPersist
+{
+  Seg *segs, *segs2;
+  uint32_t *lvl;  // [0] live segments [1] live elements [2] largest live segment [3] out: 1 when the loop ran out of levels
+  uint32_t *key, *idx;
+  unsigned long long *tile_cnt, *segbase;
+  uint32_t *posL, *posR, *tile_seg;
+  FinSeg *fl;
+  uint32_t *fin, *err;
+  uint2 *heap_list;
+  uint32_t *bar;  // zeroed by the host before the launch
+  uint32_t max_levels;
+};
+__device__ __forceinline__ void lvp_barrier(uint32_t *bar, uint32_t active, uint32_t &target)
+{
+  if (active == 1)
+  {
+    __syncthreads();  // one workgroup: its own stores are visible to it behind a workgroup barrier
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  target += active;
+  if (threadIdx.x == 0)
+  {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__global__ __launch_bounds__(256) void k_lv_persist(LvPersist a)
+{
+  __shared__ LvTile sh;
+  __shared__ uint32_t s_scan[prims::WAVES];
+  __shared__ uint32_t s_key[LV_KEYS_LDS];
+  __shared__ unsigned long long s_base[3];
+  __shared__ unsigned long long wsum[256 / 64];
+  __shared__ uint32_t s_max;
+  Seg *cur = a.segs, *nxt = a.segs2;
+  uint32_t active = gridDim.x, target = 0;
+  const uint32_t b = blockIdx.x;
+  for (uint32_t level = 0;; ++level)
+  {
+    // (behind the barrier of the level before: WG 0 has left the counts of this level)
+    const uint32_t ns = __hip_atomic_load(a.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), na = __hip_atomic_load(a.lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ns == 0) return;
+    if (level >= a.max_levels)
+    {
+      if (b == 0 && threadIdx.x == 0) a.lvl[3] = 1;
+      return;
+    }
+    const uint32_t nt = (na + LV_TILE - 1) / LV_TILE;
+    uint32_t want = (nt + LVP_TILES_PER_WG - 1) / LVP_TILES_PER_WG;
+    want = want < 1 ? 1 : (want > active ? active : want);
+    if (b >= want) return;  // every workgroup computes the same `want` from the same counts: the barriers below count `want` arrivals
+    active = want;
+    for (uint32_t vb = b; vb < nt; vb += active)
+    {
+      lv_count_tile(cur, ns, a.key, na, a.tile_cnt, a.tile_seg, vb, &sh, s_scan);
+      __syncthreads();
+    }
+    lvp_barrier(a.bar, active, target);
+    if (b == 0) lv_sums_body<256>(a.tile_cnt, ns, na, a.segbase, wsum);
+    lvp_barrier(a.bar, active, target);
+    for (uint32_t vb = b; vb < nt; vb += active)
+    {
+      lv_lists_tile(cur, ns, a.key, na, a.tile_cnt, a.posL, a.posR, a.segbase, a.tile_seg, vb, &sh, s_scan, s_key);
+      __syncthreads();
+    }
+    lvp_barrier(a.bar, active, target);
+    for (uint32_t vb = b; vb < nt; vb += active)
+    {
+      lv_swap_tile(cur, ns, a.key, a.idx, na, a.segbase, a.posL, a.posR, a.tile_seg, vb, &sh, s_base);
+      __syncthreads();
+    }
+    lvp_barrier(a.bar, active, target);
+    if (b == 0) children_small_body<256>(cur, a.lvl, nxt, a.fl, a.fin, a.key, a.idx, a.err, a.heap_list, a.tile_seg, wsum, &s_max);
+    lvp_barrier(a.bar, active, target);
+    Seg *t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+}
+
+#ifndef TL_UNROLL_N
+#define TL_UNROLL_N 24
+#endif
+// ---- the rest of the loop, one workgroup per live segment, in rounds -------------------------------------------------------------
+// The device-wide level loop pays five dependent launches per level (~45-70 us whatever the level holds) for up to 2 lg n
+// levels; on a WGS sample 25-30 of them exist only for a few dozen degenerate segments that lose a few per cent per level.  Here a
+// workgroup of 1024 threads takes ONE live segment and follows its SPINE: it partitions the segment (the same partition as
+// k_lv_count / _lists / _swap: stoppers counted per wave over contiguous chunks, their positions written to the segment's own
+// slice of posL / posR by wave ballots, pair j swapped while l_j < r_j, cut = min(l_J, r_{J-1})), hands the SMALLER side on - to
+// the finisher list, to the heap list when the depth budget is used up (both exactly as the level loop does), or, if it is still
+// larger than FIN_MAX, to the segment list of the next round - and carries on with the larger side.  A segment that is handed on is
+// at most half of its parent, so floor(lg(largest / FIN_MAX)) + 1 rounds finish every tree whatever its shape, each round one
+// launch sized for the bound na / FIN_MAX with the actual count read on the device (no host look in between); a degenerate chain
+// of 30 partitions is 30 nodes of ONE workgroup (~8 us each: two passes over the keys and a handful of workgroup barriers)
+// instead of 30 levels of five launches.  The sides of a partition never interact, so the order in which the tree is walked does
+// not matter for the result.
+constexpr uint32_t TL_THREADS = 1024, TL_WAVES = TL_THREADS / 64, TL_UNROLL = TL_UNROLL_N;
+// child [first, last) of a node with `depth` left (one lane): 0 = nothing left to do here (went to the finisher list, to the heap list
+// or is at most 16 long), 1 = still live: c holds it with its pivot picked
+__device__ __forceinline__ int tl_child(uint32_t first, uint32_t last, int32_t depth, uint32_t *key, uint32_t *idx, uint32_t *err, uint2 *heap_list, FinSeg *fl, uint32_t *fin, Seg &c)
+{
+  const uint32_t sz = last - first;
+  if (sz > FIN_MAX)
+  {
+    c = Seg{};
+    c.first = first;
+    c.last = last;
+    c.depth = depth;
+    pivot_one(c, key, idx, err, heap_list);  // depth 0: the segment goes to the heap list (c.depth = -1)
+    return c.depth >= 0 ? 1 : 0;
+  }
+  if (sz > 16) fin_append(fl, fin, first, last, depth);
+  return 0;
+}
+__global__ __launch_bounds__(TL_THREADS) void k_se_tail_round(const Seg *__restrict__ in, const uint32_t *__restrict__ n_in, Seg *__restrict__ out, uint32_t *__restrict__ n_out,
+                                                              uint32_t out_cap, uint32_t *key, uint32_t *idx, uint32_t *posL, uint32_t *posR, FinSeg *fl, uint32_t *fin, uint32_t *err,
+                                                              uint2 *heap_list)
+{
+  __shared__ Seg s_cur;
+  __shared__ Seg s_kid[2];
+  __shared__ int s_live[2];
+  __shared__ uint32_t s_cnt[2][TL_WAVES];
+  __shared__ uint32_t s_cut;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (blockIdx.x >= *n_in) return;
+  if (tid == 0)
+  {
+    s_cur = in[blockIdx.x];
+    s_cut = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  if (s_cur.depth < 0) return;  // (k_se_pivot sent it to the heap list)
+  for (;;)
+  {
+    const Seg sg = s_cur;
+    const uint32_t first = sg.first, last = sg.last, pivot = sg.pivot;
+    // stoppers among (first, last): key >= pivot stops the scan from the left, key <= pivot the scan from the right; wave w owns
+    // a contiguous chunk (rows of 64 consecutive positions)
+    const uint32_t lo = first + 1, total = last - lo;
+    const uint32_t chunk = (((total + TL_WAVES - 1) / TL_WAVES) + 63u) & ~63u;
+    const uint32_t wbeg = lo + min(total, w * chunk), wend = lo + min(total, (w + 1) * chunk);
+    uint32_t cL = 0, cR = 0;
+    {
+      // (TL_UNROLL rows in flight per wave: a single CU has to stream a segment of 10^5 keys in a few microseconds)
+      uint32_t p = wbeg + lane;
+      for (; p + (TL_UNROLL - 1) * 64 < wend; p += TL_UNROLL * 64)
+      {
+        uint32_t k[TL_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < TL_UNROLL; ++u) k[u] = key[p + u * 64];
+#pragma unroll
+        for (uint32_t u = 0; u < TL_UNROLL; ++u)
+        {
+          cL += k[u] >= pivot ? 1u : 0u;
+          cR += k[u] <= pivot ? 1u : 0u;
+        }
+      }
+      for (; p < wend; p += 64)
+      {
+        const uint32_t k = key[p];
+        cL += k >= pivot ? 1u : 0u;
+        cR += k <= pivot ? 1u : 0u;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+      cL += __shfl_xor(cL, d, 64);
+      cR += __shfl_xor(cR, d, 64);
+    }
+    if (lane == 0)
+    {
+      s_cnt[0][w] = cL;
+      s_cnt[1][w] = cR;
+    }
+    __syncthreads();
+    uint32_t runL = 0, runR = 0, nL = 0, nR = 0;
+    for (uint32_t i = 0; i < TL_WAVES; ++i)
+    {
+      const uint32_t a = s_cnt[0][i], b = s_cnt[1][i];
+      if (i < w)
+      {
+        runL += a;
+        runR += b;
+      }
+      nL += a;
+      nR += b;
+    }
+    // the segment's own slice of the position lists: at most last - first - 1 entries each
+    uint32_t *pL = posL + first, *pR = posR + first;
+    {
+      auto place = [&](uint32_t p, bool valid, uint32_t k) {
+        const bool fL = valid && k >= pivot, fR = valid && k <= pivot;
+        const unsigned long long mL = __ballot(fL), mR = __ballot(fR);
+        const uint32_t bL = __builtin_amdgcn_mbcnt_hi((uint32_t) (mL >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mL, 0u));
+        const uint32_t bR = __builtin_amdgcn_mbcnt_hi((uint32_t) (mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mR, 0u));
+        if (fL) pL[runL + bL] = p;
+        if (fR) pR[runR + bR] = p;
+        runL += (uint32_t) __popcll(mL);
+        runR += (uint32_t) __popcll(mR);
+      };
+      uint32_t p0 = wbeg;
+      for (; p0 + TL_UNROLL * 64 <= wend; p0 += TL_UNROLL * 64)
+      {
+        uint32_t k[TL_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < TL_UNROLL; ++u) k[u] = key[p0 + u * 64 + lane];
+#pragma unroll
+        for (uint32_t u = 0; u < TL_UNROLL; ++u) place(p0 + u * 64 + lane, true, k[u]);
+      }
+      for (; p0 < wend; p0 += 64)
+      {
+        const uint32_t p = p0 + lane;
+        const bool valid = p < wend;
+        place(p, valid, valid ? key[p] : 0u);
+      }
+    }
+    __syncthreads();
+    // pair j = (l_j, r_j): swapped while l_j < r_j; the first pair that is not gives the cut (k_lv_swap, one pair per index)
+    const uint32_t mm = nL < nR ? nL : nR;
+    // the pairs are swapped until they cross: l_j < r_j holds for j < J only, so the first batch without a swap ends a thread's work
+    // early (J is a few per cent of the segment on a degenerate one); four pairs in flight per thread
+    constexpr uint32_t SW = 4;
+    for (uint32_t j0 = tid; j0 <= mm; j0 += SW * TL_THREADS)
+    {
+      uint32_t lj[SW], rj[SW];
+      bool sw[SW];
+#pragma unroll
+      for (uint32_t u = 0; u < SW; ++u)
+      {
+        const uint32_t j = j0 + u * TL_THREADS;
+        lj[u] = j < nL ? pL[j] : 0xFFFFFFFFu;
+        rj[u] = j < nR ? pR[nR - 1 - j] : first;
+      }
+      uint32_t k1[SW], k2[SW], x1[SW], x2[SW];
+#pragma unroll
+      for (uint32_t u = 0; u < SW; ++u)
+      {
+        const uint32_t j = j0 + u * TL_THREADS;
+        sw[u] = j <= mm && (j < nL) && (j < nR) && (lj[u] < rj[u]);
+        if (sw[u])
+        {
+          k1[u] = key[lj[u]];
+          k2[u] = key[rj[u]];
+          x1[u] = idx[lj[u]];
+          x2[u] = idx[rj[u]];
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < SW; ++u)
+        if (sw[u])
+        {
+          key[lj[u]] = k2[u];
+          key[rj[u]] = k1[u];
+          idx[lj[u]] = x2[u];
+          idx[rj[u]] = x1[u];
+        }
+#pragma unroll
+      for (uint32_t u = 0; u < SW; ++u)
+      {
+        const uint32_t j = j0 + u * TL_THREADS;
+        if (j > mm || sw[u]) continue;
+        const uint32_t ljj = lj[u];
+        bool prev_cont = false;
+        uint32_t rprev = 0;
+        if (j > 0)
+        {
+          const uint32_t lp = pL[j - 1];
+          rprev = pR[nR - j];
+          prev_cont = lp < rprev;
+        }
+        if (j == 0)
+          s_cut = ljj;
+        else if (prev_cont)
+          s_cut = ljj < rprev ? ljj : rprev;
+      }
+    }
+    __syncthreads();
+    const uint32_t cut = s_cut;
+    if (cut == 0xFFFFFFFFu || cut <= first || cut > last)
+    {
+      if (tid == 0) atomicOr(err, 8u);  // (a partition always yields a cut inside the segment: reported, never silent)
+      return;
+    }
+    // the two sides, one lane each (their pivots are two dependent round trips apiece): side 0 = [first, cut), side 1 = [cut, last)
+    if (lane == 0 && w < 2)
+    {
+      Seg c;
+      s_live[w] = tl_child(w == 0 ? first : cut, w == 0 ? cut : last, sg.depth, key, idx, err, heap_list, fl, fin, c);
+      s_kid[w] = c;
+    }
+    __syncthreads();
+    const int big = (cut - first) >= (last - cut) ? 0 : 1;  // carry on with the larger side, hand the smaller one on
+    const bool go_on = s_live[big] != 0;
+    if (tid == 0)
+    {
+      if (s_live[1 - big])
+      {
+        const uint32_t slot = atomicAdd(n_out, 1u);
+        if (slot < out_cap)
+          out[slot] = s_kid[1 - big];
+        else
+          atomicOr(err, 8u);
+      }
+      if (go_on)
+      {
+        s_cur = s_kid[big];
+        s_cut = 0xFFFFFFFFu;
+      }
+    }
+    __syncthreads();
+    if (!go_on) return;
   }
 }
 
@@ -2090,10 +2454,9 @@ __global__ __launch_bounds__(256) void k_chk_keys(const uint32_t *__restrict__ k
     atomicMin(&bad[5], p);
   }
 }
-static void sort_check(const char *phase, const uint32_t *key, const uint32_t *idx, const uint32_t *key0, uint32_t n, const uint64_t *goff, uint32_t ng, hipStream_t st)
+static void sort_check(const char *phase, const uint32_t *key, const uint32_t *idx, const uint32_t *key0, uint32_t n, const uint64_t *goff, uint32_t ng, hipStream_t st, SortEmuBufs &b)
 {
-  static DevBuf cnt, bad;
-  uint32_t *c = cnt.as<uint32_t>(n), *bd = bad.as<uint32_t>(8);
+  uint32_t *c = b.chk_cnt.as<uint32_t>(n), *bd = b.chk_bad.as<uint32_t>(8);
   const uint32_t init[8] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0, 0};
   HIP_CHECK(hipDeviceSynchronize());
   HIP_CHECK(hipMemset(c, 0, (size_t) n * 4));
@@ -2117,18 +2480,26 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
 {
   if (n64 == 0 || ng == 0) return;
   if (n64 > 0x7FFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: more than 2^31 pairs");
-  static bool pipe_flag_set = false;
-  if (!pipe_flag_set)
   {
-    const int nq = getenv("BK_HEAP_NO_Q") != nullptr;
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_q), &nq, sizeof nq));
-    const int nhy = getenv("BK_HEAP_NO_HYBRID") != nullptr || nq;
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_hybrid), &nhy, sizeof nhy));
-    pipe_flag_set = true;
+    // the two debugging switches live in __device__ variables, i.e. once per DEVICE: every device this process sorts on gets them
+    // (one sample over several GPUs runs one host thread per device; the lanes of one device share the entry under the lock)
+    static std::mutex flag_m;
+    static bool flag_set[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> l(flag_m);
+    if (dev >= 0 && dev < 64 && !flag_set[dev])
+    {
+      const int nq = getenv("BK_HEAP_NO_Q") != nullptr;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_q), &nq, sizeof nq));
+      const int nhy = getenv("BK_HEAP_NO_HYBRID") != nullptr || nq;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_hybrid), &nhy, sizeof nhy));
+      flag_set[dev] = true;
+    }
   }
   const uint32_t n = (uint32_t) n64;
   static const bool chk = getenv("BK_SORT_CHECK") != nullptr;
-  static DevBuf chk_key0, chk_idx0;
+  DevBuf &chk_key0 = b.chk_key0;  // (BK_SORT_CHECK: per buffer set, i.e. per lane and device)
   uint32_t *key0 = nullptr;
   if (chk)
   {
@@ -2141,7 +2512,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     for (uint32_t i = 0; i < n; ++i)
       if (hx[i] < n) k0[hx[i]] = hk[i];
     HIP_CHECK(hipMemcpy(key0, k0.data(), (size_t) n * 4, hipMemcpyHostToDevice));
-    sort_check("at entry", key, idx, key0, n, goff, ng, st);
+    sort_check("at entry", key, idx, key0, n, goff, ng, st, b);
   }
   unsigned long long *cnt = b.cnt.as<unsigned long long>((uint64_t) (n / 8 + ng) + 32);
   if (const char *dump = getenv("BK_DEBUG_SORT_DUMP"))
@@ -2179,10 +2550,14 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   uint32_t *fin = b.fin_cnt.as<uint32_t>(4);  // small count, large count, capacity
   const uint32_t fin_init[4] = {0, 0, fin_cap, 0};
   HIP_CHECK(hipMemcpyAsync(fin, fin_init, 16, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, fin_list, fin);
+  uint32_t *lvl = b.lvl.as<uint32_t>(4);
+  HIP_CHECK(hipMemsetAsync(lvl, 0, 16, st));
+  hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, fin_list, fin, lvl + 2);
   prims::exclusive_scan<unsigned long long>(cnt, cnt, ng, b.scan_tmp, st);
   unsigned long long tot = 0;
+  uint32_t max_live = 0xFFFFFFFFu;  // largest live segment (known at level 0 and after a batch of levels)
   HIP_CHECK(hipMemcpyAsync(&tot, cnt + ng, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&max_live, lvl + 2, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   uint32_t ns = (uint32_t) tot, na = (uint32_t) (tot >> 32);  // live segments, elements in them
   size_t max_segs = (size_t) n / 8 + ng + 16;
@@ -2207,14 +2582,85 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       HIP_CHECK(hipStreamSynchronize(st));
       t_loop0 = now_ms();
     }
-    uint32_t *lvl = b.lvl.as<uint32_t>(4);
-    uint32_t max_live = 0xFFFFFFFFu;  // largest live segment (known after a batch of levels)
     bool pivoted = false;  // the live segments already carry their pivots (the fused child kernel picked them)
     while (ns)
     {
       if (ns > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
       // how many levels may be queued before the host has to look: the segment count at most doubles per level and
       // the fused child kernel takes CHILD_FUSED segments
+      // every live segment to a workgroup of its own for the rest of its introsort tree (k_se_tail) as soon as the largest one is
+      // small enough for a single CU to stream (BK_SORT_TAIL_MAX elements, default 2^19; BK_SORT_NO_TAIL=1: the level loop to the
+      // end) and the wide top of the trees is done (BK_SORT_TAIL_LEVEL, default 4: the first levels hold thousands of segments and
+      // are one pass over everything for the device-wide kernels, while a single workgroup per ROOT would walk ~10^2 nodes; measured
+      // with four lanes: level 2 41.3 ms, level 4 39.6, level 6 42.2 for the stage, 42.0-42.7 without the tail kernel)
+      static const bool no_tail = getenv("BK_SORT_NO_TAIL") != nullptr || getenv("BK_SORT_OLD_LEVELS") != nullptr;
+      static const uint32_t tail_max = getenv("BK_SORT_TAIL_MAX") ? (uint32_t) strtoul(getenv("BK_SORT_TAIL_MAX"), nullptr, 10) : (1u << 19);
+      static const int tail_level = getenv("BK_SORT_TAIL_LEVEL") ? atoi(getenv("BK_SORT_TAIL_LEVEL")) : 4;
+      if (!no_tail && level >= tail_level && max_live <= tail_max)
+      {
+        if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
+        // rounds: a segment that is handed on is at most half of its parent and larger than FIN_MAX
+        int rounds = 1;
+        for (uint64_t sz = max_live; sz / 2 > FIN_MAX; sz /= 2) ++rounds;
+        uint32_t *rc = b.lv_bar.as<uint32_t>((uint64_t) rounds + 2);
+        HIP_CHECK(hipMemsetAsync(rc, 0, ((size_t) rounds + 2) * 4, st));
+        HIP_CHECK(hipMemcpyAsync(rc, &ns, 4, hipMemcpyHostToDevice, st));
+        const uint32_t cap = (uint32_t) std::min<uint64_t>(max_segs, (uint64_t) na / FIN_MAX + 1);
+        for (int r = 0; r < rounds; ++r)
+        {
+          const uint32_t grid = r == 0 ? ns : cap;
+          hipLaunchKernelGGL(k_se_tail_round, dim3(grid), dim3(TL_THREADS), 0, st, (const Seg *) segs, (const uint32_t *) (rc + r), segs2, rc + r + 1, cap, key, idx, posL, posR, fin_list, fin,
+                             err, heap_list);
+          std::swap(segs, segs2);
+        }
+        if (dbg_levels)
+        {
+          HIP_CHECK(hipStreamSynchronize(st));
+          fprintf(stderr, "[sortemu]   levels %d.. by one workgroup per live segment in %d rounds: %u segments, %u live elements, largest %u, %.3f ms so far\n", level, rounds, ns, na, max_live, now_ms() - t_loop0);
+        }
+        break;
+      }
+      // the rest of the loop in one launch (k_lv_persist) once a level is down to BK_SORT_PERSIST_TILES tiles.  OFF unless that
+      // variable is set: measured on the 30x WGS shape (two lanes) it changes nothing - 42.7 ms for the stage without it, 43.1-43.4
+      // with thresholds of 4 / 16 / 64 tiles, 46.8 with 256 - because a level's kernels are busy for most of their 6-12 us
+      // (dependent loads inside them), not waiting for each other, and a grid barrier that crosses the XCDs' L2s costs as much as
+      // a launch boundary (tools/ubench/gridbar.hip); it does take load off the command processor (seven lanes: 64.8 -> 59.0 ms)
+      static const bool no_persist = getenv("BK_SORT_NO_PERSIST") != nullptr || getenv("BK_SORT_OLD_LEVELS") != nullptr;
+      static const uint32_t persist_tiles = getenv("BK_SORT_PERSIST_TILES") ? (uint32_t) atoi(getenv("BK_SORT_PERSIST_TILES")) : 0u;
+      if (!no_persist && persist_tiles && ns <= CHILD_FUSED && na / FIN_MAX <= CHILD_FUSED && cdiv(na, LV_TILE) <= persist_tiles)
+      {
+        if ((uint64_t) na / FIN_MAX + 1 > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
+        const uint32_t cur[4] = {ns, na, 0u, 0u};
+        HIP_CHECK(hipMemcpyAsync(lvl, cur, 16, hipMemcpyHostToDevice, st));
+        if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
+        uint32_t *bar = b.lv_bar.as<uint32_t>(4);
+        HIP_CHECK(hipMemsetAsync(bar, 0, 16, st));
+        LvPersist pa;
+        pa.segs = segs;
+        pa.segs2 = segs2;
+        pa.lvl = lvl;
+        pa.key = key;
+        pa.idx = idx;
+        pa.tile_cnt = tile_cnt;
+        pa.segbase = segbase;
+        pa.posL = posL;
+        pa.posR = posR;
+        pa.tile_seg = tile_seg;
+        pa.fl = fin_list;
+        pa.fin = fin;
+        pa.err = err;
+        pa.heap_list = heap_list;
+        pa.bar = bar;
+        pa.max_levels = (uint32_t) (200 - level);
+        const uint32_t wg = std::min<uint32_t>(LVP_MAX_WG, std::max<uint32_t>(1u, cdiv(cdiv(na, LV_TILE), LVP_TILES_PER_WG)));
+        hipLaunchKernelGGL(k_lv_persist, dim3(wg), dim3(256), 0, st, pa);
+        uint32_t now[4] = {0, 0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(now, lvl, 16, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (now[3] || now[0]) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
+        if (dbg_levels) fprintf(stderr, "[sortemu]   levels %d.. in one launch (%u workgroups): %u segments, %u live elements, %.3f ms so far\n", level, wg, ns, na, now_ms() - t_loop0);
+        break;
+      }
       int batch = 0;
       static const bool no_batch = getenv("BK_SORT_NO_BATCH") != nullptr;
       static const int max_batch = getenv("BK_SORT_BATCH") ? atoi(getenv("BK_SORT_BATCH")) : 6;
@@ -2305,7 +2751,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (level > 200) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
     }
   }
-  if (chk) sort_check("after the partition levels", key, idx, key0, n, goff, ng, st);
+  if (chk) sort_check("after the partition levels", key, idx, key0, n, goff, ng, st, b);
   // What is left: (1) segments of at most FIN_MAX elements - the rest of their introsort loop runs in LDS, one workgroup
   // each (the finisher; it may add small segments to the heap list) - and (2) the segments that exhausted introsort's
   // depth limit in the level loop, which are heapsorted (they are final: no children).  The longest heap segment is the
@@ -2315,6 +2761,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   HIP_CHECK(hipMemcpyAsync(nfin2, fin, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  if (e[0] & 8u) throw bk_error(BK_ERR_HIP, "std_sort_groups: k_se_tail_round lost a segment (list overflow or a cut outside its segment)");
   const uint32_t nfin = nfin2[0] + nfin2[1];
   const uint32_t nh1 = e[3], max1 = e[1];  // heap segments of the level loop
   const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
@@ -2527,7 +2974,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   }
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
-  if (chk) sort_check("after the heaps and the finisher", key, idx, key0, n, goff, ng, st);
+  if (chk) sort_check("after the heaps and the finisher", key, idx, key0, n, goff, ng, st, b);
   // __final_insertion_sort == stable sort by key of what the introsort loop left: two tilings of 32-element windows
   static const bool radix_final = getenv("BK_FINAL_RADIX") != nullptr;  // the general stable radix sort (debugging)
   if (!radix_final)

@@ -251,7 +251,8 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
   else
     tmp = own;
   if (!is_complementary(tmp, sac, c2, c2len, 10)) return false;  // is_complementary_cigar(sa[3], 10), BreakID.cc:915
-  t.rec = (uint32_t) (a.rec_base + i);
+  t.rec = a.rec_base + i;
+  t.reserved = 0;
   t.tid = tid;
   t.pos = pos;
   t.endpos = endpos;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
           const uint64_t i = i0 + k;
           Cand cd;
           cd.qhash = a.qhash[i];
-          cd.rec = (uint32_t) (a.rec_base + i);
+          cd.rec = a.rec_base + i;
           cd.tid = tidv[k];
           cd.pos = posv[k];
           cd.mtid = a.mtid[i];
@@ -496,7 +497,6 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
           cd.mapq = mqv[k];
           cd.pad = 0;
           cd.qcheck = a.qcheck ? a.qcheck[i] : 0u;
-          cd.pad2 = 0;
           if (slot < ST_CAND_CAP)
             s_cand[slot] = cd;
           else
@@ -603,8 +603,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     if (cand)
     {
       Cand cd;
-      cd.qhash = a.qhash[i]; cd.rec = (uint32_t) (a.rec_base + i); cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
-      cd.flag = flag; cd.mapq = mapq; cd.pad = 0; cd.qcheck = a.qcheck ? a.qcheck[i] : 0u; cd.pad2 = 0;
+      cd.qhash = a.qhash[i]; cd.rec = a.rec_base + i; cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
+      cd.flag = flag; cd.mapq = mapq; cd.pad = 0; cd.qcheck = a.qcheck ? a.qcheck[i] : 0u;
       unsigned long long g = atomicAdd(&a.counters->n_cand, 1ull);
       if (g < a.cand_cap) a.cand[g] = cd;
     }

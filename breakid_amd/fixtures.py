@@ -57,4 +57,13 @@ def deepw():
     return _from_table("deepw", contigs, synth_gpu.to_numpy_cols(cols))
 
 
-ALL = {"g3": g3, "panel": panel, "deep": deep, "deepw": deepw}
+def panelfull():
+    """BASELINE.json configs[3] at its full size: 500 fusion loci x 2000x (6 799 500 records, 20 % split reads, heavy coordinate
+    ties) - the table tools/time_reference.py times the reference on ("config 4")."""
+    import torch
+    from . import synth_gpu
+    contigs, cols = synth_gpu.make_panel(12349, torch.device("cpu"), n_loci=500, depth=2000, window=600, contigs=PANEL_CONTIGS)
+    return _from_table("panelfull", contigs, synth_gpu.to_numpy_cols(cols), synth.random_refgene(PANEL_CONTIGS, 80, 5), nib=True)
+
+
+ALL = {"g3": g3, "panel": panel, "deep": deep, "deepw": deepw, "panelfull": panelfull}

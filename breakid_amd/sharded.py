@@ -206,11 +206,11 @@ class ShardedRun:
         dest = np.asarray([owner[int(keys[g])] for g in range(ng.value)], dtype=np.uint32)
         ctx._check(L.bk_shard_route_pairs(h, dest.ctypes.data if len(dest) else None, ng.value, W, C.byref(ptr), C.byref(cnt)))
         counts = [int(cnt[d]) for d in range(W)]
-        send = tensor_from_ptr(ptr.value, sum(counts) * 48, dev)
-        pairs = comm.all_to_all_var(send, [c * 48 for c in counts])
+        send = tensor_from_ptr(ptr.value, sum(counts) * abi.PAIR.itemsize, dev)
+        pairs = comm.all_to_all_var(send, [c * abi.PAIR.itemsize for c in counts])
         self._keep.append(pairs)
         ak = np.asarray(gkeys, dtype=np.uint32)
-        ctx._check(L.bk_shard_group_pairs(h, C.c_void_p(pairs.data_ptr() if pairs.numel() else 0), pairs.numel() // 48,
+        ctx._check(L.bk_shard_group_pairs(h, C.c_void_p(pairs.data_ptr() if pairs.numel() else 0), pairs.numel() // abi.PAIR.itemsize,
                                           ak.ctypes.data if len(ak) else None, len(ak)))
 
     def run(self, rec_base, qual=20, fast=True):

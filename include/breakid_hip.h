@@ -74,11 +74,14 @@ typedef struct bk_pair {
   int32_t p1_tid, p2_tid;    /* chromosome of each side (-1 = "*") */
   uint16_t p1_flag, p2_flag;
   uint8_t p1_mapq, p2_mapq, p1_rev, p2_rev;
-  uint32_t rec;              /* index of the record that completed the pair (discovery order) */
+  uint64_t rec;              /* index, in the whole sample, of the record that completed the pair (discovery order); 64 bits like the
+                                reference's own counters (long / size_t, BreakID.cc:1379,1911-1913): a shard's records are numbered
+                                rec_base + i, and a sample may hold more than 2^32 records even though one context does not */
   uint32_t id;               /* "pair_No_<id>": index inside its group at add_enspan_point_id time */
   int32_t cluster;           /* cluster number inside the group, -1 before clustering */
   uint32_t group;            /* group ordinal, groups ordered like std::map<string> on "chrA_chrB" */
-} bk_pair;
+  uint32_t reserved;         /* 0 */
+} bk_pair;                   /* 56 bytes */
 
 /* One split-read evidence tuple = numeric content of `split_align_pair` (src/BreakID.h:116-133).
  * Chromosome names are interned (ids < n_targets are header names).  CIGAR strings are only compared for equality by the
@@ -86,15 +89,16 @@ typedef struct bk_pair {
  * sides pass the ([0-9]+[MS]){2} gate, CigarRoller.cc:326) is encoded EXACTLY (bit 63 set; counts < 2^28, up to 3 leading
  * zeros per count), anything else as a 63-bit hash of the text (bit 63 clear). */
 typedef struct bk_split {
-  uint32_t rec;
+  uint64_t rec;              /* index of the record in the whole sample (rec_base + i) */
   int32_t tid, pos, endpos;  /* of the record itself: 0-based pos, bam_endpos (sam.c:344-350) */
+  uint32_t reserved;         /* 0 */
   uint64_t qhash;
   int32_t prim_chr, sec_chr;
   uint32_t prim_start, prim_end, prim_bp, sec_start, sec_end, sec_bp;
   uint64_t prim_cigar, sec_cigar;
   uint32_t flags;            /* bit0 = secondary (flag & 0x100); bit1 = "error cigar" record */
   uint32_t qcheck;           /* bk_qname_check of the read name (0 when the table has no qcheck column) */
-} bk_split;
+} bk_split;                  /* 88 bytes */
 
 #define BK_TYPE_DIFF_CHR 1u
 #define BK_TYPE_SAME_ORIENT 2u

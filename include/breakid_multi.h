@@ -31,17 +31,25 @@ extern "C" {
 
 /* Splits the coordinate-sorted host table into n_gpus contiguous record ranges, runs the whole hot path (the body of the
  * reference's main() between BreakID.cc:98 and :167) with rank r on device r % device_count, and returns rank 0's context,
- * which holds the complete cluster table (bk_fetch(BK_STAGE_CLUSTERS)); the caller frees it with bk_free.
+ * which holds the complete cluster table (bk_fetch(BK_STAGE_CLUSTERS)); the caller releases it with bk_multi_free.
  * n_clustered_total = pairs that survived clustering over all groups (what decides whether the index / refGene are opened). */
 int bk_multi_run(const bk_soa *host_table, const uint32_t *target_len, const char *const *target_name, int n_targets, int n_gpus, int transport, int mapq_min,
                  int fast, double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, char *err, size_t errlen);
 
 /* The same from the file: rank r decodes part r of n_gpus of the BAM on its own GPU (bk_bam_decode_device_part: BGZF inflate and
  * record decode on the device, no host table) and takes the records in place; the ranks' record counts give their rec_base.
- * n_targets / names / lens receive the file's reference list (owned by the library, valid for the life of the process).
+ * n_targets / names / lens receive the file's reference list (owned by the library, valid until bk_multi_free of the context).
  * BK_ERR_IO for files whose records run across BGZF blocks (no cut points): decode on the host and call bk_multi_run then. */
 int bk_multi_run_bam(const char *path, int n_gpus, int transport, int mapq_min, int fast, double *w_out, uint64_t *n_clustered_total, bk_ctx **ctx0_out, int *n_targets,
                      const char *const **names, const uint32_t **lens, char *err, size_t errlen);
+
+/* Frees a context returned by bk_multi_run / bk_multi_run_bam AND the device tables it points at (the gathered tuple / cluster
+ * tables; for bk_multi_run_bam also rank 0's decoded records and the reference names).  bk_free alone would leave those allocated. */
+void bk_multi_free(bk_ctx *ctx);
+
+/* Insert-size statistics (what bk_isize_stats gives on one GPU) and the per-group counters of the whole sample (bk_group_stats:
+ * every group once, summed over the ranks) of the run that returned `ctx`; valid until bk_multi_free. */
+int bk_multi_stats(bk_ctx *ctx, double *mean, double *sd, const bk_group_stat **groups, uint32_t *n_groups);
 
 #ifdef __cplusplus
 }

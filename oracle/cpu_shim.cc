@@ -176,5 +176,7 @@ int bk_multi_run_bam(const char *, int, int, int, int, double *, uint64_t *, bk_
   if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");
   return BK_ERR_NO_DEVICE;
 }
+void bk_multi_free(bk_ctx *c) { bk_free(c); }
+int bk_multi_stats(bk_ctx *, double *, double *, const bk_group_stat **, uint32_t *) { return BK_ERR_NO_DEVICE; }
 
 }  // extern "C"

@@ -641,7 +641,7 @@ bool record_split(Oracle &o, uint64_t i, bk_split &t)
     tmp = own;  // Set(align.getCigarString()) re-parses the rolled text: identical ops
   if (!is_complementary(tmp, f[3].data(), f[3].size(), 10)) return false;
   memset(&t, 0, sizeof t);
-  t.rec = (uint32_t) i;
+  t.rec = i;
   t.tid = s.tid[i];
   t.pos = s.pos[i];
   t.endpos = o.endpos(i);
@@ -887,7 +887,7 @@ int ora_discordant_pairs(ora *o, int qual_i, double w)
         }
         p.p1_rev = (p.p1_flag & 0x10) ? 1 : 0;
         p.p2_rev = (p.p2_flag & 0x10) ? 1 : 0;
-        p.rec = (uint32_t) i;
+        p.rec = i;
         p.cluster = -1;
         all.push_back(p);
       }

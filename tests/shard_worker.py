@@ -46,6 +46,11 @@ def main():
     comm = sharded.Comm(dev)
     counts = comm.all_gather_scalars([cols["n"]])[:, 0].tolist()
     rec_base = int(sum(counts[:rank]))
+    # SHARD_WORKER_REC_GAP: the ranks behind rank 0 number their records from beyond 2^32 (a sample of more than 4 G records whose
+    # first shard is short): discovery order only depends on the ORDER of the indices, so every call must stay the oracle's
+    gap = int(os.environ.get("SHARD_WORKER_REC_GAP", "0"))
+    if rank > 0:
+        rec_base += gap
     ctx = capi.Context(contigs, device=dev.index)
     ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
     run = sharded.ShardedRun(ctx, comm, routed=routed)
@@ -59,6 +64,15 @@ def main():
         ow, rc = o.run(20, fast=(mode == "fast"))
         exp, _ = o.fetch(abi.STAGE_CLUSTERS)
         ok = rc == 0 and w == ow and np.array_equal(got, exp)
+        if gap:
+            # the gathered evidence tuples carry the sample-wide record index: rank 0's as they are, the others' beyond the gap
+            gs, _ = ctx.fetch(abi.STAGE_SPLITS)
+            es, _ = o.fetch(abi.STAGE_SPLITS)
+            back = gs.copy()
+            far = back["rec"] >= counts[0]
+            back["rec"][far] -= gap
+            ok = ok and len(gs) == len(es) and np.array_equal(back, es) and bool(far.any()) and int(gs["rec"].max()) >= (1 << 32)
+            print("SHARD_REC64", "OK" if ok else "MISMATCH", "largest record index", int(gs["rec"].max()), flush=True)
         print("SHARD_CHECK", "OK" if ok else "MISMATCH", "w", w, ow, "clusters", len(got), len(exp), "valid", int(((got["flags"] & 2) != 0).sum()), flush=True)
         if not ok and len(got) == len(exp):
             bad = [i for i in range(len(got)) if got[i] != exp[i]][:5]

@@ -85,7 +85,7 @@ def test_qname_hash_matches_python():
 
 
 def test_abi_struct_sizes():
-    assert abi.PAIR.itemsize == 48 and abi.SPLIT.itemsize == 80 and abi.CLUSTER.itemsize == 72
+    assert abi.PAIR.itemsize == 56 and abi.SPLIT.itemsize == 88 and abi.CLUSTER.itemsize == 72
 
 
 def test_bench_gpus_flag_is_honoured_or_refused():

@@ -29,7 +29,7 @@ def _gpu(fx, fast):
     return ctx, mean, sd, w
 
 
-@pytest.mark.parametrize("name,mode", [("deep", "fast"), ("deepw", "fast"), ("panel", "fast"), ("panel", "ahc"), ("g3", "fast"), ("g3", "ahc")])
+@pytest.mark.parametrize("name,mode", [("deep", "fast"), ("deepw", "fast"), ("panel", "fast"), ("panel", "ahc"), ("g3", "fast"), ("g3", "ahc"), ("panelfull", "fast")])
 def test_stages_match_reference_on_large_inputs(name, mode):
     fx, meta = bigcases.load(name)
     if fx is None or not any(os.path.exists(os.path.join(bigcases.GOLD, "%s.%s.%s" % (name, mode, s))) for s in ("stages.txt.gz", "digest.json")):
@@ -57,3 +57,30 @@ def test_cli_on_large_inputs_matches_reference_txt(name, mode):
             got = open(prefix + suffix).read()
             exp = open(os.path.join(bigcases.GOLD, "%s.%s%s" % (name, mode, suffix))).read()
             assert got == exp, (suffix, got[:600], exp[:600])
+        # _performance.txt (BreakID.cc:175-191): header + the five deterministic columns against the reference's file
+        perf = open(prefix + "_performance.txt").read().split("\n")
+        exp = open(os.path.join(bigcases.GOLD, "%s.%s_perf5.txt" % (name, mode))).read().split("\n")
+        assert perf[0] == exp[0] and perf[1].split("\t")[:5] == exp[1].split("\t") and len(perf[1].split("\t")) == 9, (perf, exp)
+
+
+def test_cli_on_the_full_size_panel_matches_the_reference_files():
+    """BASELINE.json configs[3] at its full size (500 loci x 2000x, 6 799 500 records, -fast: the reference takes 72 s): the txt
+    files of bin/BreakID against the sha256 of the reference's, and the five deterministic columns of _performance.txt"""
+    import hashlib
+    if not os.path.exists(os.path.join(bigcases.GOLD, "panelfull.fast.digest.json")):
+        pytest.skip("golden panelfull not generated")
+    sha, rows, perf5 = bigcases.expected_txt("panelfull", "fast")
+    fx, meta = bigcases.load("panelfull")
+    with tempfile.TemporaryDirectory() as tmp:
+        bam = os.path.join(tmp, "panelfull.bam")
+        fx.write_bam(bam)
+        bamio.write_bai(bam)
+        side = synth.write_side_files(fx.contigs, tmp, refgene_lines=fx.refgene, max_nib_len=60_000_000)
+        prefix = os.path.join(tmp, "out")
+        r = subprocess.run([BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all", "-fast"], env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for suffix in ("_fusion.txt", "_fusion_all.txt"):
+            got = open(prefix + suffix, "rb").read()
+            assert got.count(b"\n") == rows[suffix] and hashlib.sha256(got).hexdigest() == sha[suffix], (suffix, got[:600])
+        perf = open(prefix + "_performance.txt").read().split("\n")
+        assert perf[0] == perf5[0] and "\t".join(perf[1].split("\t")[:5]) == perf5[1], (perf, perf5)

@@ -184,6 +184,53 @@ def test_wgs_shape_100M_oracle_determinism_and_invariants():
     o.close()
 
 
+def test_wgs_shape_full_size_620M_records():
+    """BASELINE.json configs[1] at its full size (620 M records, the table bench.py times): the same bytes from two runs and from
+    the sharded driver at world size 1, the size-independent invariants of the cluster table and - where the host has the memory
+    for the 27 GB table (the single-thread oracle then takes ~40 s) - bit-identity of every final call with the CPU oracle."""
+    import zlib
+    import psutil
+    import torch
+    from breakid_amd import sharded, synth_gpu
+    dev = torch.device("cuda", 0)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 150 * (1 << 30):
+        pytest.skip("needs ~150 GB of free HBM (table, generator temporaries, two contexts)")
+    contigs, cols = synth_gpu.make_wgs(620_000_000, 12346, dev)
+    torch.cuda.empty_cache()
+    ptrs = abi.device_ptrs(cols)
+    ctx = capi.Context(contigs)
+    crcs = []
+    for rep in range(2):
+        ctx.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+        w, n_valid = ctx.run(qual=20, fast=True)
+        cl, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+        crcs.append(zlib.crc32(cl.tobytes()))
+    assert crcs[0] == crcs[1] and n_valid > 100_000
+    clustered, goff = ctx.fetch(abi.STAGE_CLUSTERED)
+    assert int(cl["n_drp"].sum()) == len(clustered)
+    assert np.all(cl["p1_min"] <= cl["p1_mean"]) and np.all(cl["p1_mean"] <= cl["p1_max"])
+    assert np.all(cl["p2_min"] <= cl["p2_mean"]) and np.all(cl["p2_mean"] <= cl["p2_max"])
+    assert np.all(np.diff(cl["group"].astype(np.int64)) >= 0)
+    assert len(goff) - 1 == 300  # 24 contigs: every unordered chromosome pair holds discordant pairs at this depth
+    del clustered
+    b = capi.Context(contigs)
+    b.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w2 = sharded.ShardedRun(b, sharded.Comm(dev)).run(0, qual=20, fast=True)
+    cl2, _ = b.fetch(abi.STAGE_CLUSTERS)
+    assert w2 == w and zlib.crc32(cl2.tobytes()) == crcs[0]
+    b.close()
+    if psutil.virtual_memory().available > 90 * (1 << 30):
+        host = synth_gpu.to_numpy_cols(cols)
+        o = pyoracle.Oracle(contigs, host)
+        ow, rc = o.run(20, fast=True)
+        exp, _ = o.fetch(abi.STAGE_CLUSTERS)
+        assert rc == 0 and ow == w and np.array_equal(cl, exp)
+        assert n_valid == int(((exp["flags"] & 2) != 0).sum())
+        o.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("fast", [True, False])
 def test_panel_shape_vs_oracle(fast):
     """BASELINE.json configs[3] at test size: reads piled over fusion loci, ~20 % split reads whose clip points

@@ -45,6 +45,19 @@ def test_two_rank_sharded_sample_matches_oracle(mode, exchange):
     assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("exchange", ["routed", "replicated"])
+def test_record_indices_beyond_2_32_across_ranks(exchange):
+    """rank 1 numbers its records from 2^32 - 1000 + n_0 on: candidates, pairs and tuples carry 64-bit sample-wide indices (the
+    reference counts in long / size_t, BreakID.cc:1379,1911-1913); join order, pair order inside the groups and tuple order must
+    come out as the oracle's on the concatenated sample"""
+    port = "29641" if exchange == "routed" else "29642"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_WORKER_REC_GAP=str((1 << 32) - 1000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "tests", "shard_worker.py"), "400000", "83", "fast", exchange]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARD_CHECK OK" in r.stdout and "SHARD_REC64 OK" in r.stdout and "SHARD_REPLICAS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
 def test_two_rank_sharded_sample_with_lanes_of_groups_inside_every_rank():
     """BREAKID_GROUP_LANES=2 on a sharded sample: every rank deals the groups it OWNS to two lanes (the others belong to no lane)"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", BREAKID_GROUP_LANES="2", BREAKID_LANES_MIN_PAIRS="1000", GPU_MAX_HW_QUEUES="16")

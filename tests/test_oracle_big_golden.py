@@ -1,5 +1,5 @@
 """CPU: the oracle port against the reference's outputs on the LARGE inputs (tools/make_golden_big.py): configs[0] shape
-(G3, 1 M records), panel shape (G5) and the two inputs on which the reference binary's own std::sort takes its heapsort
+(G3, 1 M records), panel shape (G5; `panelfull` = BASELINE.json configs[3] at its full size, 6.8 M records, through the calls) and the two inputs on which the reference binary's own std::sort takes its heapsort
 branch (`deep`: segments up to 3*10^5 elements; `deepw`: the WGS same/other-chromosome mixture)."""
 import json
 import os
@@ -9,7 +9,7 @@ import pytest
 from oracle import pyoracle
 from tests import bigcases
 
-CASES = [("deep", "fast"), ("deepw", "fast"), ("panel", "fast"), ("panel", "ahc"), ("g3", "fast")]
+CASES = [("deep", "fast"), ("deepw", "fast"), ("panel", "fast"), ("panel", "ahc"), ("g3", "fast"), ("panelfull", "fast")]
 
 
 @pytest.mark.parametrize("name,mode", CASES)
