@@ -32,7 +32,7 @@ class Soa(C.Structure):
                 ("mpos", C.c_void_p), ("isize", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
                 ("qhash", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
                 ("aux_off", C.c_void_p), ("aux", C.c_void_p), ("n_cigar_words", C.c_uint64),
-                ("n_aux_bytes", C.c_uint64), ("qcheck", C.c_void_p)]
+                ("n_aux_bytes", C.c_uint64), ("qcheck", C.c_void_p), ("side", C.c_void_p)]
 
 
 SOA_COLS = [("tid", np.int32), ("pos", np.int32), ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32),
@@ -96,4 +96,6 @@ def device_ptrs(cols):
     p = {k: cols[k].data_ptr() for k, _ in SOA_COLS}
     if "qcheck" in cols:
         p["qcheck"] = cols["qcheck"].data_ptr()
+    if "side" in cols:  # bk_side rows (include/breakid_hip.h): qhash, mtid, mpos, qcheck of a record in one 32-byte row
+        p["side"] = cols["side"].data_ptr()
     return p

@@ -196,6 +196,8 @@ class Context:
             setattr(s, name, ptrs[name])
         if ptrs.get("qcheck"):
             s.qcheck = ptrs["qcheck"]
+        if ptrs.get("side"):
+            s.side = ptrs["side"]
         s.n_cigar_words = n_cigar_words
         s.n_aux_bytes = n_aux_bytes
         self._keep = (ptrs, s)

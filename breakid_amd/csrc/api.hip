@@ -68,6 +68,7 @@ struct bk_ctx
   // records
   bk_soa rec{};
   DevBuf col[13];
+  DevBuf d_side;  // bk_side rows of an uploaded host table
   bool have_records = false;
 
   // stream pass
@@ -275,6 +276,8 @@ StreamArgs stream_args(bk_ctx *c, uint64_t n)
   a.rec_base = c->rec_base;
   a.tid = c->rec.tid; a.pos = c->rec.pos; a.mtid = c->rec.mtid; a.mpos = c->rec.mpos; a.isize = c->rec.isize;
   a.flag = c->rec.flag; a.mapq = c->rec.mapq; a.qhash = c->rec.qhash; a.qcheck = c->rec.qcheck;
+  static const bool no_side = getenv("BREAKID_NO_SIDE") != nullptr;  // (comparison: the four columns even when the table has the rows)
+  a.side = no_side && c->rec.qhash ? nullptr : c->rec.side;
   a.cigar_off = c->rec.cigar_off; a.cigar = c->rec.cigar; a.aux_off = c->rec.aux_off; a.aux = c->rec.aux;
   a.mapq_min = c->mapq_min;
   a.names = c->names;
@@ -507,6 +510,7 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
       for (const void *p : {(const void *) s->tid, (const void *) s->pos, (const void *) s->isize, (const void *) s->flag, (const void *) s->mapq, (const void *) s->cigar_off,
                             (const void *) s->aux_off})
         if (s->n && ((uintptr_t) p & 15u)) throw bk_error(BK_ERR_ARG, "bk_upload_records: BK_MEM_DEVICE columns must be 16-byte aligned");
+      if (s->n && s->side && ((uintptr_t) s->side & 15u)) throw bk_error(BK_ERR_ARG, "bk_upload_records: BK_MEM_DEVICE side rows must be 16-byte aligned");
       ctx->rec = *s;
     }
     else
@@ -527,6 +531,10 @@ int bk_upload_records(bk_ctx *ctx, const bk_soa *s, int mem_space)
       d.isize = (const int32_t *) dst[4]; d.flag = (const uint16_t *) dst[5]; d.mapq = (const uint8_t *) dst[6]; d.qhash = (const uint64_t *) dst[7];
       d.cigar_off = (const uint32_t *) dst[8]; d.cigar = (const uint32_t *) dst[9]; d.aux_off = (const uint32_t *) dst[10]; d.aux = (const uint8_t *) dst[11];
       d.qcheck = s->qcheck ? (const uint32_t *) dst[12] : nullptr;
+      // the side layout for the streaming pass (one 32-byte row per record, include/breakid_hip.h: bk_side), made on the device
+      bk_side *side = ctx->d_side.as<bk_side>(n + 1);
+      launch_make_side(d.qhash, d.mtid, d.mpos, d.qcheck, n, side, ctx->st);
+      d.side = side;
       ctx->rec = d;
     }
     ctx->have_records = true;

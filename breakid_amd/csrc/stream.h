@@ -42,6 +42,7 @@ struct StreamArgs
   const uint8_t *mapq;
   const uint64_t *qhash;
   const uint32_t *qcheck;  // may be null
+  const bk_side *side;     // may be null; when set, qhash / mtid / mpos / qcheck come from it
   const uint32_t *cigar_off, *cigar, *aux_off;
   const uint8_t *aux;
   int mapq_min;
@@ -57,6 +58,8 @@ struct StreamArgs
 };
 
 void launch_stream(const StreamArgs &a, hipStream_t st);
+// side[i] = {qhash[i], mtid[i], mpos[i], qcheck ? qcheck[i] : 0} (include/breakid_hip.h: bk_side)
+void launch_make_side(const uint64_t *qhash, const int32_t *mtid, const int32_t *mpos, const uint32_t *qcheck, uint64_t n, bk_side *side, hipStream_t st);
 void launch_split_records(const StreamArgs &a, unsigned long long n_sa, hipStream_t st);
 // mean: host-computed (double) sum / (double) n; thr: exception threshold 2^(kmax-53) (or huge = replay all)
 void launch_sd_local(const uint16_t *flag, const int32_t *isize, uint64_t n, double mean, double thr, SdBufs &b, hipStream_t st, unsigned long long *l_total,

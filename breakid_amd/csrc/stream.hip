@@ -11,6 +11,40 @@
 
 namespace
 {
+// qhash, mtid, mpos, qcheck of record i: one 32-byte row when the table has the side layout (a 16-byte and a 4-byte load out of
+// one sector), else four columns
+__global__ __launch_bounds__(256) void k_make_side(const uint64_t *__restrict__ qhash, const int32_t *__restrict__ mtid, const int32_t *__restrict__ mpos,
+                                                   const uint32_t *__restrict__ qcheck, uint64_t n, bk_side *__restrict__ side)
+{
+  const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bk_side r;
+  r.qhash = qhash[i];
+  r.mtid = mtid[i];
+  r.mpos = mpos[i];
+  r.qcheck = qcheck ? qcheck[i] : 0u;
+  r.reserved[0] = r.reserved[1] = r.reserved[2] = 0;
+  side[i] = r;
+}
+__device__ __forceinline__ void cand_fields(const StreamArgs &a, uint64_t i, uint64_t &qhash, int32_t &mtid, int32_t &mpos, uint32_t &qcheck)
+{
+  if (a.side)
+  {
+    const uint4 v = *reinterpret_cast<const uint4 *>(a.side + i);
+    qhash = (uint64_t) v.x | ((uint64_t) v.y << 32);
+    mtid = (int32_t) v.z;
+    mpos = (int32_t) v.w;
+    qcheck = a.side[i].qcheck;
+  }
+  else
+  {
+    qhash = a.qhash[i];
+    mtid = a.mtid[i];
+    mpos = a.mpos[i];
+    qcheck = a.qcheck ? a.qcheck[i] : 0u;
+  }
+}
+
 // ---- CIGAR roll-up (CigarRoller.cc:26-46 operator+=, :67-116 Add, Cigar.cc:80-144) ------------------
 // classes: 1 match, 3 insert, 4 del, 5 skip, 6 softClip, 7 hardClip, 8 pad (Cigar.h:65-76)
 struct Roll
@@ -256,7 +290,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
   t.tid = tid;
   t.pos = pos;
   t.endpos = endpos;
-  t.qhash = a.qhash[i];
+  t.qhash = a.side ? a.side[i].qhash : a.qhash[i];
   bool secondary = (flag & 0x100) != 0;
   uint32_t flags = secondary ? 1u : 0u;
   // stoi(sa[1])
@@ -339,7 +373,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
   }
   if (poison) flags |= 2u;
   t.flags = flags;
-  t.qcheck = a.qcheck ? a.qcheck[i] : 0u;
+  t.qcheck = a.side ? a.side[i].qcheck : (a.qcheck ? a.qcheck[i] : 0u);
   return true;
 }
 
@@ -487,16 +521,13 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
           if (!cand[k]) continue;
           const uint64_t i = i0 + k;
           Cand cd;
-          cd.qhash = a.qhash[i];
+          cand_fields(a, i, cd.qhash, cd.mtid, cd.mpos, cd.qcheck);
           cd.rec = a.rec_base + i;
           cd.tid = tidv[k];
           cd.pos = posv[k];
-          cd.mtid = a.mtid[i];
-          cd.mpos = a.mpos[i];
           cd.flag = flv[k];
           cd.mapq = mqv[k];
           cd.pad = 0;
-          cd.qcheck = a.qcheck ? a.qcheck[i] : 0u;
           if (slot < ST_CAND_CAP)
             s_cand[slot] = cd;
           else
@@ -603,8 +634,9 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     if (cand)
     {
       Cand cd;
-      cd.qhash = a.qhash[i]; cd.rec = a.rec_base + i; cd.tid = tid; cd.pos = pos; cd.mtid = a.mtid[i]; cd.mpos = a.mpos[i];
-      cd.flag = flag; cd.mapq = mapq; cd.pad = 0; cd.qcheck = a.qcheck ? a.qcheck[i] : 0u;
+      cand_fields(a, i, cd.qhash, cd.mtid, cd.mpos, cd.qcheck);
+      cd.rec = a.rec_base + i; cd.tid = tid; cd.pos = pos;
+      cd.flag = flag; cd.mapq = mapq; cd.pad = 0;
       unsigned long long g = atomicAdd(&a.counters->n_cand, 1ull);
       if (g < a.cand_cap) a.cand[g] = cd;
     }
@@ -914,4 +946,9 @@ void debug_cigar(const uint8_t *kind, const uint32_t *c1_off, const uint8_t *c1,
                  hipStream_t st)
 {
   if (n) hipLaunchKernelGGL(k_debug_cigar, dim3(cdiv(n, 64)), dim3(64), 0, st, kind, c1_off, c1, c2_off, c2, e, n, out);
+}
+
+void launch_make_side(const uint64_t *qhash, const int32_t *mtid, const int32_t *mpos, const uint32_t *qcheck, uint64_t n, bk_side *side, hipStream_t st)
+{
+  if (n) hipLaunchKernelGGL(k_make_side, dim3(cdiv(n, 256)), dim3(256), 0, st, qhash, mtid, mpos, qcheck, n, side);
 }

@@ -221,7 +221,21 @@ def make_wgs(n_records: int, seed: int, device, contigs=HG19, read_len=150, disc
     out["n_cigar_words"] = nwords
     out["n_aux_bytes"] = nbytes
     del perm, aux_len, aoff
+    out["side"] = side_rows(out)
     return list(contigs), out
+
+
+def side_rows(cols):
+    """The bk_side layout of a table (include/breakid_hip.h): qhash, mtid, mpos, qcheck of every record in one 32-byte row, as a
+    producer of device tables may hand it over next to (or instead of) those four columns.  int64 [n, 4]: the hash, mtid in the
+    low and mpos in the high half of the second word, qcheck in the low half of the third."""
+    n = cols["tid"].numel()
+    side = torch.zeros((n, 4), dtype=torch.int64, device=cols["tid"].device)
+    side[:, 0] = cols["qhash"]
+    side[:, 1] = (cols["mtid"].to(torch.int64) & 0xFFFFFFFF) | (cols["mpos"].to(torch.int64) << 32)
+    if "qcheck" in cols:
+        side[:, 2] = cols["qcheck"].to(torch.int64) & 0xFFFFFFFF
+    return side
 
 
 def to_numpy_cols(cols):
@@ -442,6 +456,7 @@ def _assemble(contigs, device, seed, P, tid, pos, mpos, ins, pid, sp, read_len):
     out["n"] = n
     out["n_cigar_words"] = nwords
     out["n_aux_bytes"] = nbytes
+    out["side"] = side_rows(out)
     return list(contigs), out
 
 

@@ -65,7 +65,20 @@ typedef struct bk_soa {
   uint64_t n_cigar_words;    /* = cigar_off[n] (given so that device-resident tables need no read-back) */
   uint64_t n_aux_bytes;      /* = aux_off[n] */
   const uint32_t *qcheck;    /* n entries or NULL */
+  const struct bk_side *side; /* n entries or NULL: see bk_side */
 } bk_soa;
+
+/* Optional device layout of the four columns only discordant candidates and SA-bearing records need (about 5 % of the records
+ * of a WGS sample): qhash, mtid, mpos and qcheck of a record in ONE 32-byte row, so that the streaming pass fetches one sector
+ * per candidate instead of one per column (four scattered 4-8-byte reads cost four 64-byte fetches).  A producer that writes a
+ * table in device memory may fill it (the synthetic generator does); a host table gets it when it is uploaded; when `side` is
+ * given the library reads those four values from it and never touches the qhash / mtid / mpos / qcheck columns. */
+typedef struct bk_side {
+  uint64_t qhash;
+  int32_t mtid, mpos;
+  uint32_t qcheck;           /* 0 = the table has no second read-name hash */
+  uint32_t reserved[3];      /* 0 */
+} bk_side;                   /* 32 bytes */
 
 /* One discordant pair = the numeric content of `discordant_pair` (src/BreakID.h:39-58). */
 typedef struct bk_pair {

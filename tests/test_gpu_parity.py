@@ -146,6 +146,41 @@ def test_wgs_shape_device_resident_vs_oracle():
     o.close()
 
 
+def test_side_rows_replace_the_four_candidate_columns():
+    """bk_side (include/breakid_hip.h): qhash, mtid, mpos, qcheck of a record in one 32-byte row.  A device table that carries the
+    rows gives the same stages as the one with the four columns - also when those columns hold garbage (they are never read
+    then) - and a host table gets its rows when it is uploaded."""
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs(2_000_000, 4321, dev)
+    n, ncw, nab = cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"]
+    with_side = abi.device_ptrs(cols)
+    assert with_side.get("side")
+    columns_only = {k: v for k, v in with_side.items() if k != "side"}
+    junk = torch.full((n + 8,), -7, dtype=torch.int64, device=dev)
+    side_only = dict(with_side, qhash=junk.data_ptr(), mtid=junk.data_ptr(), mpos=junk.data_ptr(), qcheck=junk.data_ptr())
+    ref = None
+    for ptrs in (columns_only, with_side, side_only):
+        ctx = capi.Context(contigs)
+        ctx.attach_device(ptrs, n, ncw, nab)
+        w, nv = ctx.run(qual=20, fast=True)
+        got = [w, nv] + [ctx.fetch(st)[0] for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_SPLITS, abi.STAGE_CLUSTERS)]
+        if ref is None:
+            ref = got
+        else:
+            assert got[0] == ref[0] and got[1] == ref[1]
+            for a, b in zip(got[2:], ref[2:]):
+                assert np.array_equal(a, b)
+        ctx.close()
+    host = synth_gpu.to_numpy_cols(cols)
+    ctx = capi.Context(contigs)
+    ctx.upload(host)
+    w, nv = ctx.run(qual=20, fast=True)
+    assert w == ref[0] and nv == ref[1] and np.array_equal(ctx.fetch(abi.STAGE_CLUSTERS)[0], ref[6]) and np.array_equal(ctx.fetch(abi.STAGE_SPLITS)[0], ref[5])
+    ctx.close()
+
+
 def test_wgs_shape_100M_oracle_determinism_and_invariants():
     """The largest table the single-thread oracle finishes in seconds (100 M records, ~6 s): bit-identical final calls,
     the same bytes from a second run and from the sharded driver at world size 1 (routed exchange), and the
