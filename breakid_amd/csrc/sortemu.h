@@ -6,7 +6,7 @@
 
 struct SortEmuBufs
 {
-  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, scratch32b, fin_list, fin_cnt, lvl, lv_tile, lv_segbase, lv_tileseg, lv_bar, chk_key0, chk_cnt, chk_bad;
+  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, scratch32b, fin_list, fin_cnt, lvl, lv_tile, lv_segbase, lv_tileseg, lv_bar, chk_key0, chk_cnt, chk_bad, rk_a, rk_b;
   prims::RadixBufs radix;
   // optional observer (host): heavy[g] = largest heapsort segment (elements) any sort through these buffers left to group g's
   // lone-wave heap kernels - what the lanes of api.hip balance on.  Set by the caller around the sorts it wants recorded.

@@ -1068,11 +1068,148 @@ constexpr uint32_t HEAP_RANKED_MAX = 65534;  // rank + 1 must fit 16 bits and st
 // CLS 2 runs with HEAP_BIG_THREADS threads: the loads, the ranking and the final gather of a 40 000-element segment are
 // 700 dependent round trips for a lone wave (0.9 ms) and a fraction of that for four; the heap itself belongs to wave 0,
 // the other waves sleep at the barriers meanwhile.
-constexpr uint32_t HEAP_BIG_THREADS = 256;
-template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
+constexpr uint32_t HEAP_BIG_THREADS = 1024;
+constexpr uint32_t RK_UNROLL = 4;
+// Dense ranks of the m <= 65534 keys of ONE heap segment by the workgroup that is about to heapsort it: entries (key << 16 | position)
+// go through four stable 8-bit counting passes between two scratch arrays in global memory (wave w owns a contiguous run of rows
+// of 64 entries; a row's lanes find the lanes of the same digit with eight ballots, the first of them moves the wave's running
+// base of that digit), then out[position] = (number of smaller DISTINCT keys + 1) << 16 | position: the ranked entries of
+// sort_heap_lds_q.  lds: (NW + 1) * 256 words of scratch, wcnt: NW + 1 words behind them (all inside the dynamic LDS the heap is
+// loaded into afterwards: `out` may be that LDS - the scratch is dead when the entries are written).
+// Replaces the device-wide ranking (count / gather / five radix passes / flags / scan / scatter: ~30 launches and two host looks in
+// front of every sort's longest heap) by ~60 us inside the heap's own workgroup.
+__device__ void wg_ranked_entries(const uint32_t *gk, const uint32_t m, unsigned long long *A, unsigned long long *B, uint32_t *out, uint32_t *lds, uint32_t *wcnt, const uint32_t NT)
+{
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, NW = NT >> 6;
+  for (uint32_t i = tid; i < m; i += NT) A[i] = ((unsigned long long) gk[i] << 16) | i;
+  const uint32_t rows = (m + 63) / 64, rpw = (rows + NW - 1) / NW;
+  const uint32_t r0 = min(rows, w * rpw), r1 = min(rows, r0 + rpw);
+  unsigned long long *src = A, *dst = B;
+  __syncthreads();
+  for (int pass = 0; pass < 4; ++pass)
+  {
+    const int sh = 16 + 8 * pass;
+    uint32_t *hist = lds + w * 256;
+    for (uint32_t d = lane; d < 256; d += 64) hist[d] = 0;
+    for (uint32_t r = r0; r < r1; r += RK_UNROLL)
+    {
+      unsigned long long e[RK_UNROLL];
+#pragma unroll
+      for (uint32_t u = 0; u < RK_UNROLL; ++u)
+      {
+        const uint32_t i = (r + u) * 64 + lane;
+        e[u] = (r + u < r1 && i < m) ? src[i] : ~0ull;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < RK_UNROLL; ++u)
+        if (e[u] != ~0ull) atomicAdd(&hist[(uint32_t) (e[u] >> sh) & 255u], 1u);
+    }
+    __syncthreads();
+    // bases: digit-major, wave-minor
+    if (tid < 256)
+    {
+      uint32_t tot = 0;
+      for (uint32_t k = 0; k < NW; ++k) tot += lds[k * 256 + tid];
+      uint32_t inc = tot;
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((int) lane >= d) inc += o;
+      }
+      if (lane == 63) wcnt[w] = inc;
+      // (tid < 256 = the first four waves: they meet at the barrier below with everybody)
+      lds[NW * 256 + tid] = inc - tot;  // exclusive inside the wave
+    }
+    __syncthreads();
+    if (tid < 256)
+    {
+      uint32_t base = lds[NW * 256 + tid];
+      for (uint32_t k = 0; k < w; ++k) base += wcnt[k];
+      for (uint32_t k = 0; k < NW; ++k)
+      {
+        const uint32_t c = lds[k * 256 + tid];
+        lds[k * 256 + tid] = base;
+        base += c;
+      }
+    }
+    __syncthreads();
+    for (uint32_t r = r0; r < r1; r += RK_UNROLL)
+    {
+      unsigned long long e[RK_UNROLL];
+#pragma unroll
+      for (uint32_t u = 0; u < RK_UNROLL; ++u)
+      {
+        const uint32_t i = (r + u) * 64 + lane;
+        e[u] = (r + u < r1 && i < m) ? src[i] : ~0ull;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < RK_UNROLL; ++u)
+      {
+        const bool valid = e[u] != ~0ull;
+        const uint32_t d = (uint32_t) (e[u] >> sh) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit)
+        {
+          const bool mine = (d >> bit) & 1u;
+          const unsigned long long bal = __ballot(mine);
+          peers &= mine ? bal : ~bal;
+        }
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t) (peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) peers, 0u));
+        const uint32_t base = valid ? hist[d] : 0u;
+        if (valid) dst[base + before] = e[u];
+        if (valid && before == 0) hist[d] = base + (uint32_t) __popcll(peers);  // (one lane per digit of the row; the wave's LDS operations stay in order)
+      }
+    }
+    __syncthreads();
+    unsigned long long *t = src;
+    src = dst;
+    dst = t;
+  }
+  // src: sorted by key, equal keys in position order.  rank = number of key changes in front of the entry
+  uint32_t changes = 0;
+  for (uint32_t r = r0; r < r1; ++r)
+  {
+    const uint32_t i = r * 64 + lane;
+    const bool ch = i < m && i > 0 && (src[i] >> 16) != (src[i - 1] >> 16);
+    changes += (uint32_t) __popcll(__ballot(ch));
+  }
+  if (lane == 0) wcnt[w] = changes;
+  __syncthreads();
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < w; ++k) run += wcnt[k];
+  __syncthreads();  // (wcnt is read; the caller's LDS may be overwritten from here on)
+  for (uint32_t r = r0; r < r1; r += RK_UNROLL)
+  {
+    unsigned long long e[RK_UNROLL], ep[RK_UNROLL];
+#pragma unroll
+    for (uint32_t u = 0; u < RK_UNROLL; ++u)
+    {
+      const uint32_t i = (r + u) * 64 + lane;
+      const bool in = r + u < r1 && i < m;
+      e[u] = in ? src[i] : ~0ull;
+      ep[u] = in && i > 0 ? src[i - 1] : ~0ull;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < RK_UNROLL; ++u)
+    {
+      const bool valid = e[u] != ~0ull;
+      const bool ch = valid && ep[u] != ~0ull && (e[u] >> 16) != (ep[u] >> 16);
+      const unsigned long long mk = __ballot(ch);
+      const uint32_t upto = __builtin_amdgcn_mbcnt_hi((uint32_t) (mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mk, 0u)) + (ch ? 1u : 0u);
+      if (valid)
+      {
+        const uint32_t pos = (uint32_t) e[u] & 0xFFFFu;
+        out[pos] = ((run + upto + 1u) << 16) | pos;
+      }
+      run += (uint32_t) __popcll(mk);
+    }
+  }
+}
+template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_THREADS : 64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
                                                                        hent *__restrict__ scratch, uint32_t lo, uint32_t hi,
                                                                        const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32,
-                                                                       uint32_t *__restrict__ scratch32b)
+                                                                       uint32_t *__restrict__ scratch32b, unsigned long long *rka, unsigned long long *rkb)
 {
   extern __shared__ __attribute__((aligned(16))) hent dyn[];
   __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
@@ -1087,7 +1224,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
   const bool w0 = threadIdx.x < 64;                       // the wave that owns the heap
   for (uint32_t i = threadIdx.x; i < m; i += NT) buf[i] = ((hent) gk[i] << 32) | gx[i];
   __syncthreads();
-  if (CLS == 2 && ASM && rank32 != nullptr && m <= HEAP_RANKED_MAX)
+  if (CLS == 2 && ASM && (rank32 != nullptr || rka != nullptr) && m <= HEAP_RANKED_MAX)
   {
     // ranked 4-byte entries ((rank + 1) << 16 | local index, never 0): up to HEAP_LARGE32 of them fit LDS (slots 1..m of l32,
     // slot 0 scratch, two zero slots behind).  buf keeps the packed originals; the sorted entries end up in g32.
@@ -1098,7 +1235,13 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
     unsigned long long tp1, tp2, tp3;
     if (fits)
     {
-      for (uint32_t i = threadIdx.x; i < m; i += NT) l32[1 + i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      if (CLS == 2 && rank32 == nullptr)
+      {
+        wg_ranked_entries(gk, m, rka + sg.first, rkb + sg.first, l32 + 1, l32, l32 + (NT / 64 + 1) * 256, NT);
+        __syncthreads();
+      }
+      else
+        for (uint32_t i = threadIdx.x; i < m; i += NT) l32[1 + i] = ((rank32[sg.first + i] + 1u) << 16) | i;
       if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : m + threadIdx.x] = 0;
       __syncthreads();
       tp1 = wall_clock64();
@@ -1111,7 +1254,10 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? 256 : 64) v
     }
     else
     {
-      for (uint32_t i = threadIdx.x; i < m; i += NT) g32[i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      if (CLS == 2 && rank32 == nullptr)
+        wg_ranked_entries(gk, m, rka + sg.first, rkb + sg.first, g32, l32, l32 + (NT / 64 + 1) * 256, NT);
+      else
+        for (uint32_t i = threadIdx.x; i < m; i += NT) g32[i] = ((rank32[sg.first + i] + 1u) << 16) | i;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       tp1 = wall_clock64();
@@ -2771,6 +2917,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   hent *hscratch = nullptr;
   const uint32_t *rank32 = nullptr;
   uint32_t *scratch32 = nullptr, *scratch32b = nullptr;
+  unsigned long long *rka = nullptr, *rkb = nullptr;  // scratch of the ranking inside the big heaps' own workgroups (wg_ranked_entries)
   int used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg)
@@ -2793,7 +2940,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       HIP_CHECK(hipEventCreateWithFlags(&b.join[used], hipEventDisableTiming));
     }
     HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-    hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32, scratch32b);
+    hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32, scratch32b, rka, rkb);
     HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
     ++used;
   };
@@ -2870,7 +3017,16 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
     const bool ranked_on = use_asm && !no_ranked;
     const uint32_t big_lo = ranked_on ? HEAP_RANKED_MIN : HEAP_LARGE;  // heaps above this size go to the one-per-CU kernel
-    if (max1 > HEAP_RANKED_MIN && ranked_on)
+    // BK_HEAP_RANK_PRE=1: the device-wide ranking in front of the heap kernels (the earlier form; comparison / debugging)
+    static const bool rank_pre = getenv("BK_HEAP_RANK_PRE") != nullptr;
+    if (max1 > HEAP_RANKED_MIN && ranked_on && !rank_pre)
+    {
+      rka = b.rk_a.as<unsigned long long>((uint64_t) n + HEAP_PAD);
+      rkb = b.rk_b.as<unsigned long long>((uint64_t) n + HEAP_PAD);
+      scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
+      if (max1 > HEAP_LARGE32) scratch32b = b.scratch32b.as<uint32_t>((uint64_t) n + HEAP_PAD);  // overflow slots of the heaps beyond the LDS
+    }
+    if (max1 > HEAP_RANKED_MIN && ranked_on && rank_pre)
     {
       unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
       hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
@@ -2915,7 +3071,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       // stream: only the big heaps need a side stream, and every stream of every lane of groups costs a hardware queue
       static const bool mid_side = getenv("BK_HEAP_MID_SIDE") != nullptr;
       if ((!split || ranked_on) && !mid_side)
-        hipLaunchKernelGGL(k1, dim3(nh1), dim3(64), ((size_t) big_lo + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, big_lo, rank32, scratch32, scratch32b);
+        hipLaunchKernelGGL(k1, dim3(nh1), dim3(64), ((size_t) big_lo + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, big_lo, rank32, scratch32, scratch32b, rka, rkb);
       else if (!split || ranked_on)
         side(k1, ((size_t) big_lo + HEAP_PAD) * 8, hl, nh1, HEAP_SMALL, big_lo);
       else
@@ -2944,9 +3100,9 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         if (nh2 > nh1 && e[1] > HEAP_SMALL)
         {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, HEAP_SMALL, HEAP_LARGE, rank32, scratch32, scratch32b);
+          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, HEAP_SMALL, HEAP_LARGE, rank32, scratch32, scratch32b, rka, rkb);
         }
-        hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b);
+        hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b, rka, rkb);
       };
       if (use_asm)
         small(k_se_heapsort<0, true>, k_se_heapsort<1, true>);
