@@ -51,6 +51,7 @@ struct Seg
 // Segments of up to FIN_MAX elements leave the device-wide level loop: one workgroup finishes each of them in LDS
 // (k_se_finish).  fin[0] = number of entries of the finisher list.
 constexpr uint32_t FIN_MAX = 2048;
+constexpr uint32_t HEAP_BIG_MIN = 4096;  // = HEAP_RANKED_MIN: segments above it are heapsorted one per CU (k_se_heapsort<2>)
 // The partition passes work on tiles of LV_TILE compact indices (k_lv_*).  Whoever writes a level's segment list also leaves,
 // for every tile, the segment that owns the tile's first index: a tile then starts with one load instead of a binary search
 // over the list (seven dependent round trips that were most of a late level's kernel time).
@@ -119,6 +120,9 @@ __device__ __forceinline__ void pivot_one(Seg &sg, uint32_t *__restrict__ key, u
     sg.depth = -1;
     uint32_t slot = atomicAdd(err + 3, 1u);
     heap_list[slot] = make_uint2(sg.first, sg.last);
+    // the long ones a second time, from the END of the list downwards (err[5] = its last slot): their kernel takes a whole CU's LDS
+    // per workgroup, so it is launched over them only, not over every segment of the list
+    if (sg.last - sg.first > HEAP_BIG_MIN) heap_list[err[5] - atomicAdd(err + 4, 1u)] = make_uint2(sg.first, sg.last);
     atomicAdd(err + 2, sg.last - sg.first);
     atomicMax(err + 1, sg.last - sg.first);
     return;
@@ -2688,8 +2692,8 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     }
     ++call;
   }
-  uint32_t *err = b.err.as<uint32_t>(4);
-  HIP_CHECK(hipMemsetAsync(err, 0, 16, st));
+  uint32_t *err = b.err.as<uint32_t>(8);  // [0] flags [1] longest heap segment [2] elements in heap segments [3] their number [4] the long ones [5] last slot of the list
+  HIP_CHECK(hipMemsetAsync(err, 0, 32, st));
   // level 0 segments = groups larger than 16
   const uint32_t fin_cap = (uint32_t) ((uint64_t) n / 16 + ng + 16);  // every entry holds more than 16 elements
   FinSeg *fin_list = b.fin_list.as<FinSeg>(fin_cap);
@@ -2709,6 +2713,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   size_t max_segs = (size_t) n / 8 + ng + 16;
   Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
   uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
+  {
+    const uint32_t last_slot = (uint32_t) (max_segs - 1);
+    HIP_CHECK(hipMemcpyAsync(err + 5, &last_slot, 4, hipMemcpyHostToDevice, st));
+  }
   if (ns)
   {
     hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs, b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2));
@@ -2903,13 +2911,13 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   // depth limit in the level loop, which are heapsorted (they are final: no children).  The longest heap segment is the
   // critical path of the whole sort, so the big heaps are started first, on side streams, and the finisher runs beside them.
   uint32_t nfin2[2] = {0, 0};
-  uint32_t e[4] = {0, 0, 0, 0};
+  uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_CHECK(hipMemcpyAsync(nfin2, fin, 8, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(e, err, 16, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(e, err, 32, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   if (e[0] & 8u) throw bk_error(BK_ERR_HIP, "std_sort_groups: k_se_tail_round lost a segment (list overflow or a cut outside its segment)");
   const uint32_t nfin = nfin2[0] + nfin2[1];
-  const uint32_t nh1 = e[3], max1 = e[1];  // heap segments of the level loop
+  const uint32_t nh1 = e[3], max1 = e[1], n_big = e[4];  // heap segments of the level loop; those above HEAP_BIG_MIN
   const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
   static const bool use_asm = getenv("BK_HEAP_CXX") == nullptr;  // BK_HEAP_CXX=1: the C++ statement of the pop loop (debugging)
   static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
@@ -3060,7 +3068,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (max1 > big_lo)
       {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_BIG_LDS));
-        side(k2, HEAP_BIG_LDS, hl, nh1, big_lo, 0xFFFFFFFFu, HEAP_BIG_THREADS);
+        side(k2, HEAP_BIG_LDS, hl + (max_segs - n_big), n_big, big_lo, 0xFFFFFFFFu, HEAP_BIG_THREADS);  // (the list of the long ones only)
       }
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
       const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
