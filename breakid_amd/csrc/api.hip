@@ -794,7 +794,7 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
   return p;
 }
 // sizes = pairs per group now; hx / hy = longest heap segment per group seen in a sort by x / by y (0: none)
-static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vector<uint32_t> &hx, const std::vector<uint32_t> &hy, int K)
+static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vector<uint32_t> &hx, const std::vector<uint32_t> &hy, int K, double x_sorts = 1.0)
 {
   const uint32_t ng = (uint32_t) sizes.size();
   // in units of one pop of a lone wave in LDS (~0.15 us): a pair costs a lane ~0.15 ns in the two sorts that are left (most of a
@@ -812,7 +812,7 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
   LanePlan p;
   p.lane_of.assign(ng, 0);
   std::vector<double> mx(K, 0.0), my(K, 0.0), pairs(K, 0.0);
-  auto cost = [&](int l) { return mx[l] + my[l] + per_pair * pairs[l]; };
+  auto cost = [&](int l) { return x_sorts * mx[l] + my[l] + per_pair * pairs[l]; };  // x_sorts: how many sorts by x are left (one by y)
   const bool bulk = lane_bulk() && K >= 3;
   for (uint32_t g : order)
   {
@@ -827,7 +827,7 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
     double best_cost = 0;
     for (int l = l0; l < K; ++l)
     {
-      const double c = std::max(mx[l], heap_cost(hx[g])) + std::max(my[l], heap_cost(hy[g])) + per_pair * (pairs[l] + (double) sizes[g]);
+      const double c = x_sorts * std::max(mx[l], heap_cost(hx[g])) + std::max(my[l], heap_cost(hy[g])) + per_pair * (pairs[l] + (double) sizes[g]);
       // the lane whose own cost ends lowest takes the group (ties: the emptier lane)
       if (l == l0 || c < best_cost || (c == best_cost && cost(l) < cost(best)))
       {
@@ -934,7 +934,10 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   }
   else
   {
-    // part 1: sorts 1-2, observed
+    // part 1: sorts 1-3, observed.  BREAKID_LANE_SPLIT=2 deals again after the second sort already (x from the first sort, y from the
+    // second, three sorts left): measured worse - 42.0 ms against 38.1 - because the heaps of the FIRST sort by x (short, on the
+    // unmasked list) say little about the later ones: the lanes of the second part then end between 12.8 and 26 ms
+    static const bool split_early = getenv("BREAKID_LANE_SPLIT") && atoi(getenv("BREAKID_LANE_SPLIT")) == 2;
     in_lanes([&](int l) {
       ClusterBufs &cb = lane_cb(l);
       cb.heavy_x.assign(ng, 0u);
@@ -942,8 +945,11 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       cb.observe = true;
       cb.se.heavy_all = lane_bulk();
       remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>(), ctx->gstart_host.data(), keep[l].data());
-      cb.heavy_x.assign(ng, 0u);  // the third sort (by x, on the masked list) is the one that tells about the fifth
-      remove_isolated_end(pairs, lane_list(l), cb, lane_st(l));
+      if (!split_early)
+      {
+        cb.heavy_x.assign(ng, 0u);  // the third sort (by x, on the masked list) is the one that tells about the fifth
+        remove_isolated_end(pairs, lane_list(l), cb, lane_st(l));
+      }
       cb.observe = false;
     });
     PairList &mid = ctx->lane_mid;
@@ -962,12 +968,13 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
         hx[g] = std::max(hx[g], lane_cb(l).heavy_x[g]);
         hy[g] = std::max(hy[g], lane_cb(l).heavy_y[g]);
       }
-    upload_plan(plan_observed(sizes, hx, hy, K));
-    // part 2: sorts 3-5
+    upload_plan(plan_observed(sizes, hx, hy, K, split_early ? 2.0 : 1.0));
+    // part 2: sorts (3,) 4, 5
     in_lanes([&](int l) {
       PairList &L = lane_list(l), &iso = lane_iso(l);
       hipStream_t st = lane_st(l);
       list_subset_ranges(mid, goff_h.data(), keep[l].data(), L, st);
+      if (split_early) remove_isolated_end(pairs, L, lane_cb(l), st);
       iso.n = L.n;
       iso.ng = L.ng;
       uint32_t *ii = iso.idx.as<uint32_t>(L.n + 1), *ig = iso.gof.as<uint32_t>(L.n + 1);

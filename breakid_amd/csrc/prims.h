@@ -100,12 +100,37 @@ template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_apply(const T
   }
 }
 
+// the whole scan by ONE workgroup (tiles one after the other, the carry in a register): a short array is bound by the three
+// dependent launches of the general form, not by its elements - and every dispatch of a process shares one command processor
+constexpr uint64_t SCAN_ONE_MAX = 16 * SCAN_TILE;
+template <class T> __global__ __launch_bounds__(BLOCK) void k_scan_one(const T *in, T *out, uint64_t n, const uint32_t *__restrict__ n_dev = nullptr)
+{
+  __shared__ T lds[WAVES];
+  if (n_dev) n = *n_dev;
+  T carry = 0;
+  for (uint64_t base = 0; base < n; base += BLOCK)
+  {
+    const uint64_t i = base + threadIdx.x;
+    const T v = i < n ? in[i] : (T) 0;
+    T tot;
+    const T ex = block_exclusive_scan(v, lds, tot);
+    if (i < n) out[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
 // in/out may alias.  tmp grows as needed.
 template <class T> inline void exclusive_scan(const T *in, T *out, uint64_t n, DevBuf &tmp, hipStream_t st)
 {
   if (n == 0)
   {
     HIP_CHECK(hipMemsetAsync(out, 0, sizeof(T), st));
+    return;
+  }
+  if (n <= SCAN_ONE_MAX)
+  {
+    hipLaunchKernelGGL(k_scan_one<T>, dim3(1), dim3(BLOCK), 0, st, in, out, n, (const uint32_t *) nullptr);
     return;
   }
   uint32_t nb = cdiv(n, SCAN_TILE);
@@ -118,6 +143,11 @@ template <class T> inline void exclusive_scan(const T *in, T *out, uint64_t n, D
 // the same with the element count in device memory (*n_dev <= n_bound); out[*n_dev] = total
 template <class T> inline void exclusive_scan_devn(const T *in, T *out, uint64_t n_bound, const uint32_t *n_dev, DevBuf &tmp, hipStream_t st)
 {
+  if (n_bound <= SCAN_ONE_MAX)
+  {
+    hipLaunchKernelGGL(k_scan_one<T>, dim3(1), dim3(BLOCK), 0, st, in, out, n_bound, n_dev);
+    return;
+  }
   uint32_t nb = cdiv(n_bound ? n_bound : 1, SCAN_TILE);
   T *sums = tmp.as<T>(nb + 1);
   hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb), dim3(BLOCK), 0, st, in, sums, n_bound, n_dev);

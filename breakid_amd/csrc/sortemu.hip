@@ -80,6 +80,15 @@ __device__ __forceinline__ void fin_append(FinSeg *__restrict__ fl, uint32_t *__
     fl[fin[2] - 1 - atomicAdd(fin + 1, 1u)] = f;  // fin[2] = capacity of the list
 }
 
+// the state words of one sort in ONE block of device memory: err[8] (flags, longest heap segment, elements in heap segments, their
+// number, the long ones, last slot of the heap list), fin[4] (finisher list: small count, large count, capacity), lvl[4] (live
+// segments, live elements, largest live segment, spare) - one small kernel resets them, one copy reads them all back
+constexpr uint32_t ST_ERR = 0, ST_FIN = 8, ST_LVL = 12, ST_WORDS = 16;
+__global__ void k_se_reset(uint32_t *state, uint32_t fin_cap, uint32_t last_slot)
+{
+  const uint32_t t = threadIdx.x;
+  if (t < ST_WORDS) state[t] = t == ST_FIN + 2 ? fin_cap : (t == ST_ERR + 5 ? last_slot : 0u);
+}
 // cnt entries: (#segments) | (#elements in them) << 32, scanned together
 __global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsigned long long *__restrict__ cnt, FinSeg *__restrict__ fl, uint32_t *__restrict__ fin,
                           uint32_t *__restrict__ max_size)
@@ -91,10 +100,16 @@ __global__ void k_se_init(const uint64_t *__restrict__ goff, uint32_t ng, unsign
   if (sz > FIN_MAX) atomicMax(max_size, (uint32_t) sz);  // largest live segment of level 0
   if (sz > 16 && sz <= FIN_MAX) fin_append(fl, fin, (uint32_t) goff[g], (uint32_t) goff[g + 1], 2 * (63 - __clzll((long long) sz)));
 }
-__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs, uint32_t *__restrict__ tile_seg)
+__global__ void k_se_init_write(const uint64_t *__restrict__ goff, uint32_t ng, const unsigned long long *__restrict__ off, Seg *__restrict__ segs, uint32_t *__restrict__ tile_seg,
+                                uint32_t *__restrict__ lvl)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
+  if (g == 0)
+  {
+    lvl[0] = (uint32_t) off[ng];  // live segments / elements of level 0 for the level kernels that read their counts on the device
+    lvl[1] = (uint32_t) (off[ng] >> 32);
+  }
   uint64_t sz = goff[g + 1] - goff[g];
   if (sz > FIN_MAX)
   {
@@ -2692,16 +2707,15 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     }
     ++call;
   }
-  uint32_t *err = b.err.as<uint32_t>(8);  // [0] flags [1] longest heap segment [2] elements in heap segments [3] their number [4] the long ones [5] last slot of the list
-  HIP_CHECK(hipMemsetAsync(err, 0, 32, st));
   // level 0 segments = groups larger than 16
   const uint32_t fin_cap = (uint32_t) ((uint64_t) n / 16 + ng + 16);  // every entry holds more than 16 elements
   FinSeg *fin_list = b.fin_list.as<FinSeg>(fin_cap);
-  uint32_t *fin = b.fin_cnt.as<uint32_t>(4);  // small count, large count, capacity
-  const uint32_t fin_init[4] = {0, 0, fin_cap, 0};
-  HIP_CHECK(hipMemcpyAsync(fin, fin_init, 16, hipMemcpyHostToDevice, st));
-  uint32_t *lvl = b.lvl.as<uint32_t>(4);
-  HIP_CHECK(hipMemsetAsync(lvl, 0, 16, st));
+  size_t max_segs = (size_t) n / 8 + ng + 16;
+  Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
+  uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
+  uint32_t *state = b.err.as<uint32_t>(ST_WORDS);
+  uint32_t *err = state + ST_ERR, *fin = state + ST_FIN, *lvl = state + ST_LVL;
+  hipLaunchKernelGGL(k_se_reset, dim3(1), dim3(64), 0, st, state, fin_cap, (uint32_t) (max_segs - 1));
   hipLaunchKernelGGL(k_se_init, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, fin_list, fin, lvl + 2);
   prims::exclusive_scan<unsigned long long>(cnt, cnt, ng, b.scan_tmp, st);
   unsigned long long tot = 0;
@@ -2710,16 +2724,9 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   HIP_CHECK(hipMemcpyAsync(&max_live, lvl + 2, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   uint32_t ns = (uint32_t) tot, na = (uint32_t) (tot >> 32);  // live segments, elements in them
-  size_t max_segs = (size_t) n / 8 + ng + 16;
-  Seg *segs = b.segs_a.as<Seg>(max_segs), *segs2 = b.segs_b.as<Seg>(max_segs);
-  uint2 *heap_list = b.heap_list.as<uint2>(max_segs);
-  {
-    const uint32_t last_slot = (uint32_t) (max_segs - 1);
-    HIP_CHECK(hipMemcpyAsync(err + 5, &last_slot, 4, hipMemcpyHostToDevice, st));
-  }
   if (ns)
   {
-    hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs, b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2));
+    hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs, b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2), lvl);
     // BK_SORT_OLD_LEVELS=1: the seven-launch partition level over materialised flags (debugging / comparison)
     static const bool old_levels = getenv("BK_SORT_OLD_LEVELS") != nullptr;
     unsigned long long *lr = old_levels ? b.lr.as<unsigned long long>((uint64_t) n + 1) : nullptr;
@@ -2862,7 +2869,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         // `batch` levels without a host round trip: counts live in lvl, grids are sized for the counts at the start
         if (std::min<uint64_t>((uint64_t) ns << batch, (uint64_t) na / FIN_MAX + 1) > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
         const uint32_t cur[2] = {ns, na};
-        HIP_CHECK(hipMemcpyAsync(lvl, cur, 8, hipMemcpyHostToDevice, st));
+        if (level > 0) HIP_CHECK(hipMemcpyAsync(lvl, cur, 8, hipMemcpyHostToDevice, st));  // (level 0: k_se_init_write left them; later batches: the children kernel did, but an unbatched level may lie between)
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
         const unsigned nbk = cdiv(na, 256), nbt = cdiv(na, LV_TILE);
         uint32_t ns_bound = ns;
@@ -2910,11 +2917,12 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   // each (the finisher; it may add small segments to the heap list) - and (2) the segments that exhausted introsort's
   // depth limit in the level loop, which are heapsorted (they are final: no children).  The longest heap segment is the
   // critical path of the whole sort, so the big heaps are started first, on side streams, and the finisher runs beside them.
-  uint32_t nfin2[2] = {0, 0};
-  uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(nfin2, fin, 8, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(e, err, 32, hipMemcpyDeviceToHost, st));
+  uint32_t hstate[ST_WORDS] = {};
+  HIP_CHECK(hipMemcpyAsync(hstate, state, sizeof hstate, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  uint32_t nfin2[2] = {hstate[ST_FIN], hstate[ST_FIN + 1]};
+  uint32_t e[8];
+  for (int k = 0; k < 8; ++k) e[k] = hstate[ST_ERR + k];
   if (e[0] & 8u) throw bk_error(BK_ERR_HIP, "std_sort_groups: k_se_tail_round lost a segment (list overflow or a cut outside its segment)");
   const uint32_t nfin = nfin2[0] + nfin2[1];
   const uint32_t nh1 = e[3], max1 = e[1], n_big = e[4];  // heap segments of the level loop; those above HEAP_BIG_MIN
