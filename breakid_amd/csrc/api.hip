@@ -1665,6 +1665,7 @@ int bk_group_stats(bk_ctx *ctx, const bk_group_stat **out, uint32_t *n_groups)
       o.n_isolated_removed = iso[g + 1] - iso[g];
       o.n_clustered = clu[g + 1] - clu[g];
       o.cluster_id_end = o.n_clustered ? kmax[g] : 0;
+      o.ordinal = ctx->glex_host[g];
     }
     *out = ctx->f_gstats.data();
     *n_groups = ng;

@@ -412,51 +412,34 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
     sum.mean = mean;
     sum.sd = sd;
     sum.groups.assign(gs, gs + ngs);
+    if (getenv("BK_DEBUG_MULTI"))
+    {
+      uint64_t a = 0, b = 0, c = 0;
+      for (uint32_t g = 0; g < ngs; ++g)
+      {
+        a += gs[g].n_scan;
+        b += gs[g].n_isolated_removed;
+        c += gs[g].n_clustered;
+      }
+      fprintf(stderr, "[multi] rank %d: %u groups, scan %llu, after the masks %llu, clustered %llu\n", T.rank, ngs, (unsigned long long) a, (unsigned long long) b, (unsigned long long) c);
+    }
     if (W > 1)
     {
-      // a rank that received no pairs lists no groups: every rank sends as many rows as the longest list (the others padded), the
-      // longest list gives the order, the counters are summed by chromosome pair
+      // a group lives on the rank that owns it; its row carries the group's ordinal in the reference's order among all groups of
+      // the sample, so the whole list is every rank's rows (padded to the longest list for the exchange) sorted by ordinal
       uint64_t mine = ngs;
       std::vector<uint64_t> cnts(W);
       T.allgather_host(&mine, 8, cnts.data(), st);
       const uint64_t mx = *std::max_element(cnts.begin(), cnts.end());
+      sum.groups.clear();
       if (mx)
       {
-        std::vector<bk_group_stat> send((size_t) mx), all((size_t) W * mx);
-        for (uint64_t g = 0; g < mx; ++g)
-        {
-          if (g < ngs)
-            send[g] = gs[g];
-          else
-          {
-            send[g] = bk_group_stat{};
-            send[g].p1_tid = send[g].p2_tid = INT32_MIN;
-          }
-        }
+        std::vector<bk_group_stat> send((size_t) mx, bk_group_stat{}), all((size_t) W * mx);
+        for (uint64_t g = 0; g < ngs; ++g) send[g] = gs[g];
         T.allgather_host(send.data(), (size_t) mx * sizeof(bk_group_stat), all.data(), st);
-        int lead = 0;
-        while (cnts[lead] != mx) ++lead;
-        sum.groups.assign(all.begin() + (size_t) lead * mx, all.begin() + (size_t) (lead + 1) * mx);
-        std::map<std::pair<int32_t, int32_t>, size_t> at;
-        for (size_t g = 0; g < sum.groups.size(); ++g)
-        {
-          bk_group_stat &o = sum.groups[g];
-          at[{o.p1_tid, o.p2_tid}] = g;
-          o.n_scan = o.n_isolated_removed = o.n_clustered = 0;
-          o.cluster_id_end = 0;
-        }
         for (int r = 0; r < W; ++r)
-          for (uint64_t g = 0; g < cnts[r]; ++g)
-          {
-            const bk_group_stat &x = all[(size_t) r * mx + g];
-            auto it = at.find({x.p1_tid, x.p2_tid});
-            if (it == at.end()) continue;
-            bk_group_stat &o = sum.groups[it->second];
-            o.n_scan += x.n_scan;
-            o.n_isolated_removed += x.n_isolated_removed;
-            o.n_clustered += x.n_clustered;
-            o.cluster_id_end = std::max(o.cluster_id_end, x.cluster_id_end);
-          }
+          for (uint64_t g = 0; g < cnts[r]; ++g) sum.groups.push_back(all[(size_t) r * mx + g]);
+        std::stable_sort(sum.groups.begin(), sum.groups.end(), [](const bk_group_stat &a, const bk_group_stat &b) { return a.ordinal < b.ordinal; });
       }
     }
   }

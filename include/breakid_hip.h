@@ -181,7 +181,9 @@ int bk_fetch(bk_ctx *ctx, int stage, const void **data, uint64_t *count, const u
 typedef struct bk_group_stat {
   int32_t p1_tid, p2_tid;
   uint64_t n_scan, n_isolated_removed, n_clustered;
-  uint32_t cluster_id_end, pad;
+  uint32_t cluster_id_end;
+  uint32_t ordinal;          /* of the group in the reference's std::map<string> order of "chrA_chrB" among ALL groups of the sample
+                                (= bk_pair.group; on one GPU simply the row number) */
 } bk_group_stat;
 int bk_group_stats(bk_ctx *ctx, const bk_group_stat **out, uint32_t *n_groups);
 

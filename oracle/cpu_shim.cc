@@ -144,6 +144,7 @@ int bk_group_stats(bk_ctx *c, const bk_group_stat **out, uint32_t *n_groups)
     int32_t mx = -1;
     for (uint64_t p = co[g]; p < co[g + 1]; ++p) mx = std::max(mx, ((const bk_pair *) cl)[p].cluster);
     o.cluster_id_end = (uint32_t) (mx + 1);
+    o.ordinal = g;
   }
   *out = c->gstats.data();
   *n_groups = ng;

@@ -105,6 +105,42 @@ def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, rank
             got = open(prefix + suffix).read()
             exp = open(os.path.join(golden_dir, "%s.%s%s" % (name, mode, suffix))).read()
             assert got == exp, (suffix, got[:600], exp[:600])
+        # the sharded run writes the same _performance.txt columns (per-group counters summed over the ranks: bk_multi_stats) and
+        # the same stdout lines as the single-GPU path
+        perf = open(prefix + "_performance.txt").read().split("\n")
+        exp = open(os.path.join(golden_dir, "%s.%s_perf5.txt" % (name, mode))).read().split("\n")
+        assert perf[0] == exp[0] and perf[1].split("\t")[:5] == exp[1].split("\t") and len(perf[1].split("\t")) == 9, (perf, exp)
+        assert "the insert size mean: " in r.stdout and "Scanning discordant read pairs done." in r.stdout
+
+
+@pytest.mark.parametrize("comm", ["local"] + (["rccl"] if False else []))
+def test_cli_sharded_run_one_rank_fails_and_every_rank_stops(comm):
+    """a failure of ONE rank (its part of the file ends in a corrupt BGZF block) must end the whole run with that rank's error -
+    never leave the others waiting in an exchange (the rank threads meet on the host in front of every collective)"""
+    ds, refgene = _dataset("small")
+    with tempfile.TemporaryDirectory() as tmp:
+        bam = os.path.join(tmp, "bad.bam")
+        ds.write_bam(bam, aligned=True)
+        raw = bytearray(open(bam, "rb").read())
+        # damage the deflate stream of a block in the last third of the file (its header stays intact: the cut points are found)
+        off, starts = 0, []
+        while off < len(raw):
+            starts.append(off)
+            off += int.from_bytes(raw[off + 16:off + 18], "little") + 1
+        victim = starts[-3]
+        for k in range(40, 80):
+            raw[victim + k] ^= 0x5A
+        open(bam, "wb").write(bytes(raw))
+        bamio_ok = False
+        try:
+            bamio.write_bai(bam)
+            bamio_ok = True
+        except Exception:
+            open(bam + ".bai", "wb").write(b"BAI\1" + (len(ds.contigs)).to_bytes(4, "little") + bytes(8 * len(ds.contigs)))
+        side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
+        cmd = [BIN, "-i", bam, "-o", os.path.join(tmp, "out"), "-n", side["nib"], "-all", "-fast", "-gpus", "3", "-comm", comm]
+        r = subprocess.run(cmd, env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0, (r.stdout[-500:], r.stderr[-500:], bamio_ok)
 
 
 def _device_count():
