@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--seed", type=int, default=12346)
     ap.add_argument("--workload", default="wgs", choices=["wgs", "panel"],
                     help="wgs = configs[1] (the headline line); panel = configs[3] targeted-panel shape (500 loci x 2000x, single GPU, side measurement)")
-    ap.add_argument("--from-bam", type=int, default=1_000_000, metavar="PAIRS",
+    ap.add_argument("--from-bam", type=int, default=4_000_000, metavar="PAIRS",
                     help="side measurement (N=1, 0 = skip): write a synthetic BAM of PAIRS read pairs and time file -> calls end to end: GPU feed alone, feed "
                          "with the stream pass overlapped (bk_bam_decode_device_ctx), rest of the hot path; reported as `from_bam` beside the headline line "
                          "(the metric itself is defined on the resident table)")

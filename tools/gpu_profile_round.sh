@@ -4,13 +4,13 @@ D=gpurun_out/prof_r03
 mkdir -p $D
 python bench.py > $D/bench_final.log 2> $D/bench_final.err
 echo bench done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/ks_raw -o ks -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > $D/ks.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/ks_raw -o ks -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --from-bam 0 > $D/ks.log 2>&1
 cp $(find $D/ks_raw -name "*kernel_stats.csv" | head -n 1) $D/ks_kernel_stats.csv
 echo stats done
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/f_raw -o fetch -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 > $D/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/f_raw -o fetch -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --from-bam 0 > $D/fetch.log 2>&1
 cp $(find $D/f_raw -name "*counter_collection.csv" | head -n 1) $D/fetch_counter_collection.csv
 echo fetch done
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/w_raw -o write -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 > $D/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/w_raw -o write -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --from-bam 0 > $D/write.log 2>&1
 cp $(find $D/w_raw -name "*counter_collection.csv" | head -n 1) $D/write_counter_collection.csv
 rm -rf $D/ks_raw $D/f_raw $D/w_raw
 ls -la $D

@@ -10,7 +10,7 @@ then copy <raw>/*/ks_kernel_stats.csv, fetch_counter_collection.csv, write_count
 import csv, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = os.path.join(root, sys.argv[1]) + "/"
-R = sys.argv[2] if len(sys.argv) > 2 else "r02"
+R = sys.argv[2] if len(sys.argv) > 2 else "r03"
 P = os.path.join(root, "profiles") + "/"
 line = [l for l in open(d + "bench_final.log") if l.startswith("{")][-1]
 open(P + R + "_bench_620M_1gpu.json", "w").write(line)
