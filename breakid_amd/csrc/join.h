@@ -6,7 +6,7 @@
 
 struct JoinBufs
 {
-  DevBuf counter, unsorted, okey, oval, key, val, pairs, gof, gflag, gscan, gstart, gkey, scan_tmp, route_cand, route_cnt, route_pairs, route_off, maxrec;
+  DevBuf counter, unsorted, okey, oval, key, val, pairs, gof, gflag, gscan, gstart, gkey, scan_tmp, route_cand, route_cnt, route_pairs, route_off, maxrec, key2, val2;
   prims::RadixBufs radix;
   // bits a record index needs (the caller's table: records of the whole sample); the pair sort key is (chr-pair key << rec_bits) |
   // discovery index, so that the sort runs over rec_bits + key bits instead of 32 + key bits

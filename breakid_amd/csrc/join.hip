@@ -19,6 +19,25 @@ __global__ __launch_bounds__(256) void k_join_keys(const Cand *__restrict__ c, u
   }
 }
 
+__global__ __launch_bounds__(256) void k_join_rec_keys(const Cand *__restrict__ c, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+  {
+    key[i] = c[i].rec;
+    val[i] = (uint32_t) i;
+  }
+}
+__global__ __launch_bounds__(256) void k_join_hash_of(const Cand *__restrict__ c, const uint32_t *__restrict__ order, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+  uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+  {
+    key[i] = c[order[i]].qhash;
+    val[i] = order[i];
+  }
+}
+
 __device__ __forceinline__ uint32_t gpos(const uint32_t *__restrict__ tprefix, int32_t nt, int32_t tid, int32_t pos)
 {
   // combine_genome_chr_pos, util_bam.cc:57-68 (uint32 wrap; loop does not run for tid <= 0)
@@ -28,8 +47,10 @@ __device__ __forceinline__ uint32_t gpos(const uint32_t *__restrict__ tprefix, i
 
 // the mate join of the run of equal read-name hashes that starts at sorted position i (nothing when i is not a run
 // start); append(pair) takes every discordant pair, in the reference's arrival order
+// ordered: the candidates of a run already stand in record order (the fallback for runs of any length: sorted by record index
+// first, then stably by the name hash), so the run is walked as it lies
 template <class F> __device__ __forceinline__ void join_run(const Cand *__restrict__ cand, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, double w,
-                                                            const uint32_t *__restrict__ tprefix, int32_t nt, uint32_t *__restrict__ err, uint64_t i, F &&append)
+                                                            const uint32_t *__restrict__ tprefix, int32_t nt, uint32_t *__restrict__ err, uint64_t i, F &&append, bool ordered = false)
 {
   if (i >= n) return;
   const uint64_t h = key[i];
@@ -38,9 +59,9 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
   while (e < n && key[e] == h) ++e;
   const uint32_t len = (uint32_t) (e - i);
   if (len < 2) return;
-  if (len > 4096)
+  if (len > 4096 && !ordered)
   {
-    atomicOr(err, 1u);
+    atomicOr(err, 1u);  // the selection below is quadratic in the run: the caller sorts the runs and comes back
     return;
   }
   // visit the run in record order: repeatedly take the smallest record index above the last one
@@ -67,6 +88,11 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
     uint32_t best = 0xFFFFFFFFu;
     if (len == 2)
       best = step;  // marker only: r0 / r1 carry the data
+    else if (ordered)
+    {
+      best = val[i + step];
+      if (cand[best].qcheck != cand[val[i]].qcheck) atomicOr(err, 2u);
+    }
     else
     {
       long long best_rec = 0x7fffffffffffffffLL;
@@ -126,7 +152,7 @@ template <class F> __device__ __forceinline__ void join_run(const Cand *__restri
 __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ cand, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, double w,
                                                     const uint32_t *__restrict__ tprefix, int32_t nt, bk_pair *__restrict__ out, uint64_t *__restrict__ okey,
                                                     uint32_t *__restrict__ oval, unsigned long long cap, unsigned long long *__restrict__ counter,
-                                                    uint32_t *__restrict__ err, int rbits)
+                                                    uint32_t *__restrict__ err, int rbits, int ordered)
 {
   // Pairs are appended through ONE counter: a returning atomic per wave tops out near 90 per microsecond on this part
   // (15 M pairs from 480 K waves: 5.3 ms, the whole kernel).  The first pair of every lane is therefore counted in LDS
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(256) void k_join_pairs(const Cand *__restrict__ can
     }
   };
   const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  join_run(cand, key, val, n, w, tprefix, nt, err, i, append);
+  join_run(cand, key, val, n, w, tprefix, nt, err, i, append, ordered != 0);
   unsigned int my = 0;
   if (have) my = atomicAdd(&s_cnt, 1u);
   __syncthreads();
@@ -351,19 +377,35 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
   uint32_t *oval = b.oval.as<uint32_t>(cap);
   unsigned long long host[2] = {0, 0};
   static const bool full_sort = getenv("BK_JOIN_FULL_SORT") != nullptr;  // all 64 bits from the start (debugging / comparison)
-  for (int attempt = full_sort ? 1 : 0; attempt < 2; ++attempt)
+  // attempt 0: candidates sorted by the upper half of the name hash, mixed runs put right; 1: by the whole hash; 2: by record index
+  // and then stably by the whole hash, so that a run of ANY length is walked in record order as it lies (a read name that more than
+  // 4096 candidates share: the selection of the next record inside a run is quadratic and gives up there)
+  static const bool ordered_only = getenv("BK_JOIN_ORDERED") != nullptr;  // (comparison / tests)
+  for (int attempt = ordered_only ? 2 : (full_sort ? 1 : 0); attempt < 3; ++attempt)
   {
     if (n_cand)
     {
       uint64_t *key = b.key.as<uint64_t>(n_cand);
       uint32_t *val = b.val.as<uint32_t>(n_cand);
-      hipLaunchKernelGGL(k_join_keys, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, n_cand, key, val);
       uint64_t *ks;
       uint32_t *vs;
-      prims::radix_sort_pairs(key, val, n_cand, attempt == 0 ? 32 : 0, 64, b.radix, st, &ks, &vs);
-      if (attempt == 0) hipLaunchKernelGGL(k_join_fix_runs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, ks, vs, n_cand, err);
+      if (attempt < 2)
+      {
+        hipLaunchKernelGGL(k_join_keys, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, n_cand, key, val);
+        prims::radix_sort_pairs(key, val, n_cand, attempt == 0 ? 32 : 0, 64, b.radix, st, &ks, &vs);
+        if (attempt == 0) hipLaunchKernelGGL(k_join_fix_runs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, ks, vs, n_cand, err);
+      }
+      else
+      {
+        hipLaunchKernelGGL(k_join_rec_keys, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, n_cand, key, val);
+        prims::radix_sort_pairs(key, val, n_cand, 0, rec_bits, b.radix, st, &ks, &vs);
+        uint64_t *key2 = b.key2.as<uint64_t>(n_cand);
+        uint32_t *val2 = b.val2.as<uint32_t>(n_cand);
+        hipLaunchKernelGGL(k_join_hash_of, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, (const uint32_t *) vs, n_cand, key2, val2);
+        prims::radix_sort_pairs(key2, val2, n_cand, 0, 64, b.radix, st, &ks, &vs);
+      }
       hipLaunchKernelGGL(k_join_pairs, dim3(cdiv(n_cand, 256)), dim3(256), 0, st, cand, ks, vs, n_cand, w, tprefix, nt, unsorted, okey, oval,
-                         (unsigned long long) cap, counter, err, rec_bits);
+                         (unsigned long long) cap, counter, err, rec_bits, attempt == 2 ? 1 : 0);
     }
     HIP_CHECK(hipMemcpyAsync(host, counter, 16, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -372,11 +414,17 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
       HIP_CHECK(hipMemsetAsync(counter, 0, 16, st));  // a long run of equal upper halves with several names in it: once more, on all 64 bits
       continue;
     }
+    if (attempt < 2 && ((uint32_t) host[1] & 1u) && !((uint32_t) host[1] & 2u))
+    {
+      HIP_CHECK(hipMemsetAsync(counter, 0, 16, st));  // a run of more than 4096 candidates: once more, every run in record order
+      attempt = 1;
+      continue;
+    }
     break;
   }
   if ((uint32_t) host[1] & 2u)
     throw bk_error(BK_ERR_COLLISION, "two different read names share one 64-bit name hash (their second hashes differ): the mate join would not be the reference's");
-  if ((uint32_t) host[1] & 1u) throw bk_error(BK_ERR_LIMIT, "more than 4096 candidate records share one read-name hash");
+  if ((uint32_t) host[1] & 1u) throw bk_error(BK_ERR_HIP, "mate join: a run was refused although its candidates were sorted (internal error)");
   if (host[0] > cap) throw bk_error(BK_ERR_LIMIT, "pair capacity exceeded");  // cannot happen: one pair per two candidates
   return host[0];
 }

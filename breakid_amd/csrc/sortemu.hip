@@ -2050,9 +2050,11 @@ __device__ __forceinline__ int tl_child(uint32_t first, uint32_t last, int32_t d
   if (sz > 16) fin_append(fl, fin, first, last, depth);
   return 0;
 }
+// spine = 0: one partition per workgroup, BOTH sides handed on (the wide top of the trees: a round per level, every node of a level
+// at once); spine = 1: the workgroup carries on with the larger side as described above
 __global__ __launch_bounds__(TL_THREADS) void k_se_tail_round(const Seg *__restrict__ in, const uint32_t *__restrict__ n_in, Seg *__restrict__ out, uint32_t *__restrict__ n_out,
                                                               uint32_t out_cap, uint32_t *key, uint32_t *idx, uint32_t *posL, uint32_t *posR, FinSeg *fl, uint32_t *fin, uint32_t *err,
-                                                              uint2 *heap_list)
+                                                              uint2 *heap_list, int spine)
 {
   __shared__ Seg s_cur;
   __shared__ Seg s_kid[2];
@@ -2228,9 +2230,17 @@ __global__ __launch_bounds__(TL_THREADS) void k_se_tail_round(const Seg *__restr
     }
     __syncthreads();
     const int big = (cut - first) >= (last - cut) ? 0 : 1;  // carry on with the larger side, hand the smaller one on
-    const bool go_on = s_live[big] != 0;
+    const bool go_on = spine && s_live[big] != 0;
     if (tid == 0)
     {
+      if (!spine && s_live[big])
+      {
+        const uint32_t slot = atomicAdd(n_out, 1u);
+        if (slot < out_cap)
+          out[slot] = s_kid[big];
+        else
+          atomicOr(err, 8u);
+      }
       if (s_live[1 - big])
       {
         const uint32_t slot = atomicAdd(n_out, 1u);
@@ -2760,18 +2770,22 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (!no_tail && level >= tail_level && max_live <= tail_max)
       {
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-        // rounds: a segment that is handed on is at most half of its parent and larger than FIN_MAX
+        // spine rounds: a segment that is handed on is at most half of its parent and larger than FIN_MAX; in front of them
+        // BK_SORT_TAIL_WIDE rounds that play one level each (every node of the level at once, both sides handed on)
+        static const int wide_rounds = getenv("BK_SORT_TAIL_WIDE") ? atoi(getenv("BK_SORT_TAIL_WIDE")) : 0;
+        const int wide = level == 0 ? std::max(0, std::min(wide_rounds, 24)) : 0;
         int rounds = 1;
         for (uint64_t sz = max_live; sz / 2 > FIN_MAX; sz /= 2) ++rounds;
+        rounds += wide;
         uint32_t *rc = b.lv_bar.as<uint32_t>((uint64_t) rounds + 2);
         HIP_CHECK(hipMemsetAsync(rc, 0, ((size_t) rounds + 2) * 4, st));
         HIP_CHECK(hipMemcpyAsync(rc, &ns, 4, hipMemcpyHostToDevice, st));
         const uint32_t cap = (uint32_t) std::min<uint64_t>(max_segs, (uint64_t) na / FIN_MAX + 1);
         for (int r = 0; r < rounds; ++r)
         {
-          const uint32_t grid = r == 0 ? ns : cap;
-          hipLaunchKernelGGL(k_se_tail_round, dim3(grid), dim3(TL_THREADS), 0, st, (const Seg *) segs, (const uint32_t *) (rc + r), segs2, rc + r + 1, cap, key, idx, posL, posR, fin_list, fin,
-                             err, heap_list);
+          const uint64_t bound = r < wide + 1 ? std::min<uint64_t>(cap, (uint64_t) ns << std::min(r, 20)) : cap;  // (a level at most doubles the segments)
+          hipLaunchKernelGGL(k_se_tail_round, dim3((unsigned) std::max<uint64_t>(1, bound)), dim3(TL_THREADS), 0, st, (const Seg *) segs, (const uint32_t *) (rc + r), segs2, rc + r + 1, cap, key,
+                             idx, posL, posR, fin_list, fin, err, heap_list, r < wide ? 0 : 1);
           std::swap(segs, segs2);
         }
         if (dbg_levels)

@@ -92,21 +92,35 @@ def test_device_table_with_a_misaligned_column_is_refused():
     ctx.close()
 
 
-def test_read_name_run_longer_than_4096_candidates_is_refused():
+def test_read_name_run_longer_than_4096_candidates_matches_the_oracle():
+    """4200 discordant records under ONE read name (the reference pairs them up in arrival order, BreakID.cc:1419-1436): the
+    in-run selection of the mate join is quadratic and gives up at 4096, the join then sorts every run by record index and walks
+    it as it lies - no limit on the length of a run"""
+    from oracle import pyoracle
     contigs = [("chr1", 10_000_000), ("chr2", 10_000_000)]
     ds = synth.Dataset(contigs)
     rng = np.random.default_rng(3)
     for i in range(400):
         ds.recs += synth._proper_pair(rng, i, 0, 1000, 9_000_000, 100, 350, 40)
-    for i in range(2100):  # 4200 discordant records under ONE read name (the reference pairs them up in arrival order)
+    for i in range(2100):
         ds.recs += synth._discordant_pair("same", 0, 100_000 + 7 * i, 1, 200_000 + 5 * i, 100)
+    for i in range(30):  # and ordinary names beside it
+        ds.recs += synth._discordant_pair("other%d" % i, 0, 3_000_000 + 11 * i, 1, 4_000_000 + 13 * i, 100)
     ds.sort()
+    cols = ds.to_soa()
     ctx = capi.Context(contigs)
-    ctx.upload(ds.to_soa())
-    with pytest.raises(capi.BreakIDError) as e:
-        ctx.run(qual=20, fast=True)
-    assert e.value.code == abi.BK_ERR_LIMIT and "4096" in str(e.value)
+    ctx.upload(cols)
+    w, _ = ctx.run(qual=20, fast=True)
+    o = pyoracle.Oracle(contigs, cols)
+    ow, rc = o.run(20, fast=True)
+    assert rc == 0 and w == ow
+    for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_CLUSTERS):
+        a, ao = ctx.fetch(st)
+        b, bo = o.fetch(st)
+        assert np.array_equal(a, b), st
+    assert len(ctx.fetch(abi.STAGE_SCAN)[0]) >= 30  # (the 4200 same-name records pair up in arrival order, mostly within one chromosome and closer than w)
     ctx.close()
+    o.close()
 
 
 def test_read_name_run_of_4096_candidates_matches_the_oracle():

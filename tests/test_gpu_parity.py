@@ -469,7 +469,7 @@ print("LANES_OK", nv)
     assert r.returncode == 0 and "LANES_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("switch", ["BK_SORT_OLD_LEVELS", "BK_SORT_NO_BATCH", "BK_HEAP_NO_Q", "BK_HEAP_CXX", "BK_HEAP_NO_RANKED", "BK_FAST_JUMP_GLOBAL", "BK_JOIN_FULL_SORT"])
+@pytest.mark.parametrize("switch", ["BK_SORT_OLD_LEVELS", "BK_SORT_NO_BATCH", "BK_SORT_NO_TAIL", "BK_SORT_NO_TAIL=1,BK_SORT_PERSIST_TILES=64", "BK_SORT_TAIL_LEVEL=0,BK_SORT_TAIL_WIDE=5", "BK_SORT_TAIL_LEVEL=0", "BK_HEAP_RANK_PRE", "BK_HEAP_NO_Q", "BK_HEAP_CXX", "BK_HEAP_NO_RANKED", "BK_FAST_JUMP_GLOBAL", "BK_JOIN_FULL_SORT", "BK_JOIN_ORDERED", "BREAKID_NO_SIDE"])
 def test_earlier_statements_of_the_same_computation_still_agree(switch):
     """the library keeps the earlier forms of the partition level, the pop loop, the anchored windows and the candidate sort
     behind environment switches (comparison / debugging): each must give the reference's order and the oracle's stages.
@@ -508,6 +508,8 @@ for st in (abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTERED, abi.STAGE_CLUSTER
 print("SWITCH_OK", nv)
 """ % ROOT_DIR
     env = dict(os.environ)
-    env[switch] = "1"
+    for kv in switch.split(","):
+        k, _, v = kv.partition("=")
+        env[k] = v or "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SWITCH_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
