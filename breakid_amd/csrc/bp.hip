@@ -347,13 +347,13 @@ __device__ __forceinline__ bool tuples_match_at(const bk_split *__restrict__ pa,
     if (err) atomicOr(err, 2u);
     return false;
   }
-  return ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.prim_start == b.prim_start && a.sec_start == b.sec_start &&
+  return ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.reserved == b.reserved && a.prim_start == b.prim_start && a.sec_start == b.sec_start &&
          a.prim_end == b.prim_end && a.sec_end == b.sec_end && a.prim_cigar == b.prim_cigar && a.sec_cigar == b.sec_cigar && a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;
 }
 
 __device__ __forceinline__ bool tuples_match(const bk_split &a, const bk_split &b)
 {
-  return a.qhash == b.qhash && ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.prim_start == b.prim_start &&
+  return a.qhash == b.qhash && ((a.flags ^ b.flags) & 1u) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.reserved == b.reserved && a.prim_start == b.prim_start &&
          a.sec_start == b.sec_start && a.prim_end == b.prim_end && a.sec_end == b.sec_end && a.prim_cigar == b.prim_cigar && a.sec_cigar == b.sec_cigar &&
          a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;  // new_condition, :627-637
 }

@@ -319,6 +319,9 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
   long long a_end = (own.reflen == 0 ? (long long) pos : (long long) pos + own.reflen - 1) + 1;
   int32_t own_chr = (tid >= 0 && tid < a.names.n_targets) ? a.names.own_id[tid] : a.names.empty_id;
   int32_t sa_chr = intern_name(a.names, sa + tb[0], te[0] - tb[0]);
+  // a contig name that is neither in the header nor chr1..22,X,Y travels as a 30-bit hash id; its second hash rides in `reserved`
+  // so that two such names are only equal when 62 bits agree (the reference compares the strings, BreakID.cc:627-637)
+  if (sa_chr & 0x40000000) t.reserved = qname_check32(sa + tb[0], te[0] - tb[0]);
   uint32_t own_end_val, own_bp = 0, sa_bp = 0;
   uint64_t own_cig;
   bool poison = false;

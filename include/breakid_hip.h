@@ -104,7 +104,8 @@ typedef struct bk_pair {
 typedef struct bk_split {
   uint64_t rec;              /* index of the record in the whole sample (rec_base + i) */
   int32_t tid, pos, endpos;  /* of the record itself: 0-based pos, bam_endpos (sam.c:344-350) */
-  uint32_t reserved;         /* 0 */
+  uint32_t reserved;         /* second hash (bk_qname_check of the text) of an SA contig name that is neither in the header nor chr1..22,X,Y
+                                (such a name is a 30-bit hash id in prim_chr / sec_chr); 0 otherwise */
   uint64_t qhash;
   int32_t prim_chr, sec_chr;
   uint32_t prim_start, prim_end, prim_bp, sec_start, sec_end, sec_bp;

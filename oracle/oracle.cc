@@ -195,6 +195,24 @@ uint64_t cigar_code(const char *t, size_t len)
   return h & ~(1ull << 63);
 }
 
+// the ABI's second 32-bit name hash (include/breakid_hip.h: bk_qname_check), restated: bk_split.reserved carries it for SA contig
+// names that are not known names
+uint32_t name_check32(const char *s, size_t len)
+{
+  uint32_t h = 0x811C9DC5u ^ ((uint32_t) len * 0x9E3779B1u);
+  for (size_t i = 0; i < len; ++i)
+  {
+    h = (h ^ (uint8_t) s[i]) * 0x01000193u;
+    h = (h << 13) | (h >> 19);
+    h = h * 5u + 0xE6546B64u;
+  }
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h ? h : 1u;
+}
 uint64_t text_hash(const char *s, size_t len)  // FNV-1a 64: ids of contig names that are not in the header
 {
   uint64_t h = 0xCBF29CE484222325ull;
@@ -657,6 +675,9 @@ bool record_split(Oracle &o, uint64_t i, bk_split &t)
   std::string own_str = own.str();
   int own_chr = o.intern(chrom_id_to_name(s.tid[i]));
   int sa_chr = o.intern(f[0]);
+  // a contig name that is neither in the header nor chr1..22,X,Y travels as a 30-bit hash id; its second hash rides in `reserved`
+  // so that two such names are only equal when 62 bits agree (the reference compares the strings, BreakID.cc:627-637)
+  if (sa_chr & 0x40000000) t.reserved = name_check32(f[0].data(), f[0].size());
   uint32_t own_end_val, own_bp = 0, sa_bp = 0;
   uint64_t own_cig;
   bool poison = false;
@@ -720,6 +741,7 @@ struct VoteIn
   int32_t prim_chr, sec_chr;
   uint32_t prim_start, prim_end, prim_bp, sec_start, sec_end, sec_bp;
   uint64_t prim_cigar, sec_cigar;
+  uint32_t chr_check = 0;  // second hash of an SA contig name that is not a known name (bk_split.reserved)
 };
 
 // BreakID.cc:577-857 find_bp_pair ("update version"), bp_pos_error = 2
@@ -732,7 +754,7 @@ void find_bp_pair(const std::vector<VoteIn> &s1, const std::vector<VoteIn> &s2, 
     for (auto &b : s2)
     {
       if (a.qhash != b.qhash) continue;
-      bool c = (a.secondary != b.secondary) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr &&
+      bool c = (a.secondary != b.secondary) && a.prim_chr == b.prim_chr && a.sec_chr == b.sec_chr && a.chr_check == b.chr_check &&
                a.prim_start == b.prim_start && a.sec_start == b.sec_start && a.prim_end == b.prim_end &&
                a.sec_end == b.sec_end && a.prim_cigar == b.prim_cigar && a.sec_cigar == b.sec_cigar &&
                a.prim_bp == b.prim_bp && a.sec_bp == b.sec_bp;
@@ -1075,7 +1097,7 @@ bool sa_region(Oracle &o, int tid, uint32_t rstart, uint32_t rend, std::vector<V
       ++ev;
       if (t.flags & 2) poison = true;
       VoteIn v{t.qhash, t.flags & 1u, t.prim_chr, t.sec_chr, t.prim_start, t.prim_end, t.prim_bp,
-               t.sec_start, t.sec_end, t.sec_bp, t.prim_cigar, t.sec_cigar};
+               t.sec_start, t.sec_end, t.sec_bp, t.prim_cigar, t.sec_cigar, t.reserved};
       out.push_back(v);
     }
   }
@@ -1224,10 +1246,10 @@ int ora_unit_vote(const bk_split *s1, uint32_t n1, const bk_split *s2, uint32_t 
   std::vector<VoteIn> a, b;
   for (uint32_t i = 0; i < n1; ++i)
     a.push_back(VoteIn{s1[i].qhash, s1[i].flags & 1u, s1[i].prim_chr, s1[i].sec_chr, s1[i].prim_start, s1[i].prim_end,
-                       s1[i].prim_bp, s1[i].sec_start, s1[i].sec_end, s1[i].sec_bp, s1[i].prim_cigar, s1[i].sec_cigar});
+                       s1[i].prim_bp, s1[i].sec_start, s1[i].sec_end, s1[i].sec_bp, s1[i].prim_cigar, s1[i].sec_cigar, s1[i].reserved});
   for (uint32_t i = 0; i < n2; ++i)
     b.push_back(VoteIn{s2[i].qhash, s2[i].flags & 1u, s2[i].prim_chr, s2[i].sec_chr, s2[i].prim_start, s2[i].prim_end,
-                       s2[i].prim_bp, s2[i].sec_start, s2[i].sec_end, s2[i].sec_bp, s2[i].prim_cigar, s2[i].sec_cigar});
+                       s2[i].prim_bp, s2[i].sec_start, s2[i].sec_end, s2[i].sec_bp, s2[i].prim_cigar, s2[i].sec_cigar, s2[i].reserved});
   int32_t b1 = -1, b2 = -1;
   int num = 0;
   find_bp_pair(a, b, p1_chr, b1, b2, num);

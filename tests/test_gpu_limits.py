@@ -216,3 +216,39 @@ def test_read_names_sharing_the_upper_half_of_their_hash_are_still_joined_by_nam
         assert np.array_equal(a, b), st
     ctx.close()
     o.close()
+
+
+def test_sa_contig_names_outside_the_header_carry_a_second_hash():
+    """an SA:Z text may name a contig that is neither in the header nor chr1..22,X,Y: it travels as a 30-bit hash id in
+    prim_chr / sec_chr, and its second hash (bk_qname_check of the text) rides in bk_split.reserved, so that two such names are only
+    taken for one when 62 bits agree (the reference compares the strings, BreakID.cc:627-637); known names leave the field 0"""
+    from oracle import pyoracle
+    ds = synth.make_g1()
+    weird = 0
+    for r in ds.recs:
+        if r.sa and r.qname in ("s0", "s1", "s2"):
+            f = r.sa.split(",")
+            f[0] = {"s0": "GL000207.1", "s1": "HLA-A*01:01", "s2": "decoy_" + "x" * 40}[r.qname]
+            r.sa = ",".join(f)
+            weird += 1
+    assert weird >= 6
+    cols = ds.to_soa()
+    ctx = capi.Context(ds.contigs)
+    ctx.upload(cols)
+    w, _ = ctx.run(qual=20, fast=True)
+    o = pyoracle.Oracle(ds.contigs, cols)
+    ow, rc = o.run(20, fast=True)
+    assert rc == 0 and w == ow
+    got, _ = ctx.fetch(abi.STAGE_SPLITS)
+    exp, _ = o.fetch(abi.STAGE_SPLITS)
+    assert np.array_equal(got, exp)
+    unknown = ((got["prim_chr"] & 0x40000000) != 0) | ((got["sec_chr"] & 0x40000000) != 0)
+    assert unknown.sum() >= 6 and np.all(got["reserved"][unknown] != 0) and np.all(got["reserved"][~unknown] == 0)
+    L = capi.lib()
+    for name in (b"GL000207.1", b"HLA-A*01:01"):
+        assert int(L.bk_qname_check(name, len(name))) in set(int(v) for v in got["reserved"][unknown])
+    a, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+    b, _ = o.fetch(abi.STAGE_CLUSTERS)
+    assert np.array_equal(a, b)
+    ctx.close()
+    o.close()
