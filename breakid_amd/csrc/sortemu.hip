@@ -3127,12 +3127,19 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     if (nh2)
     {
       auto small = [&](auto k0, auto k1) {
-        if (nh2 > nh1 && e[1] > HEAP_SMALL)
+        // the finisher's segments (at most FIN_MAX elements) in ONE launch whatever their size - the short ones used to wait in a
+        // second launch behind the long ones - then the few short segments the level loop itself left
+        static const bool two = getenv("BK_HEAP_SMALL_APART") != nullptr;  // (the earlier form: comparison)
+        if (nh2 > nh1 && (e[1] > HEAP_SMALL || !two))
         {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, HEAP_SMALL, HEAP_LARGE, rank32, scratch32, scratch32b, rka, rkb);
+          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, two ? HEAP_SMALL : 0u, HEAP_LARGE, rank32, scratch32, scratch32b, rka,
+                             rkb);
         }
-        hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b, rka, rkb);
+        if (two)
+          hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b, rka, rkb);
+        else if (nh1)
+          hipLaunchKernelGGL(k0, dim3(nh1), dim3(64), 0, st, hl, nh1, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b, rka, rkb);
       };
       if (use_asm)
         small(k_se_heapsort<0, true>, k_se_heapsort<1, true>);
