@@ -62,6 +62,7 @@ struct HuffLds
   uint16_t dfast[1 << DIST_FAST];
   uint16_t lent[288], dent[32];    // table entries of all symbols ordered by (length, symbol): codes longer than the direct tables
   uint32_t llim[16], lbas[16];     // literal/length code: codes of length L have 15-bit left-justified values < llim[L], slot = lbas[L] + (value >> (15 - L))
+  uint32_t dlim[16], dbas[16];     // the same for the distance code
   uint32_t lcount[16], dcount[16];
   uint32_t offs[16], nextc[16];    // table build scratch
   uint8_t lens[344];               // code lengths: literal/length [0,288), distance [288,320), code-length code [320,339)
@@ -134,6 +135,11 @@ __device__ __noinline__ bool build_tables(HuffLds &h, const uint8_t *lens, uint3
       {
         h.llim[len] = (code + c) << (15 - len);
         h.lbas[len] = off - code;
+      }
+      if (T == T_DIST)
+      {
+        h.dlim[len] = (code + c) << (15 - len);
+        h.dbas[len] = off - code;
       }
     }
     off += c;
@@ -247,8 +253,220 @@ __device__ __forceinline__ uint32_t walk_code(uint32_t w, const uint16_t *ent, c
   return 0;
 }
 
+// ---- one Huffman block, every lane walking its own part of the bit stream ---------------------------------------------
+// The rounds below spend 64 lanes on 64 bit positions of which ~7 start a symbol.  Here the rest of the stream is cut into 64
+// parts of S bits and lane i walks part i symbol by symbol, one Huffman code per step (a literal/length code with the length's
+// extra bits, or - after a length - the distance code with its extra bits: one table lookup per step, never more than 28
+// bits), from a 64-bit buffer in registers that takes a dword when it holds 32 bits or fewer (the following dword is on its
+// way while the buffer is used).  Lane i does not know where a code starts inside its part: it starts at the part's first
+// bit, and Huffman streams synchronise - after some symbols a walk from a wrong bit is on the true chain.  The walk of lane i
+// ends at the first literal/length code at or beyond the end of its part; that exit is where lane i+1 must really enter.  The
+// walks are repeated from the neighbour's exit until no entry changes: lane 0's entry is the true one, so after pass k lanes
+// 0..k-1 are final whatever the data (a fixed point in at most 64 passes); when every speculative walk synchronised inside
+// its own part - the usual case with parts of ~400 symbols - the second pass confirms every exit and the loop ends.  The
+// passes count output bytes and matches, a wave prefix sum turns the counts into positions, and a last pass writes.
+constexpr uint32_t X_EOB = 1u << 30, X_BAD = 1u << 31, X_NONE = 0xFFFFFFFFu, X_POS = (1u << 30) - 1u;
+constexpr uint32_t LANE_PART_MIN = 512;  // bits
+// A stretch whose codes all have the same length (random bytes) never synchronises: a walk from a wrong bit stays wrong, the true
+// entries then move on by one lane per pass.  After LANE_PASSES walks with entries still changing the block is left to the rounds,
+// which do not depend on the data (X_RETRY).
+constexpr int LANE_PASSES = 4;
+constexpr uint32_t X_RETRY = 0xFFFFFFFEu;
+
+// The dword that follows a lane's bit buffer is loaded one refill ahead.  It must stay pending while the lane decodes, and the
+// compiler would wait for it at once (a load under a lane condition ends in a register copy that needs the value), so it lives in a
+// register the compiler does not own: the kernels are limited to LANE_VGPRS registers (amdgpu_num_vgpr) and v[LANE_VGPRS] is touched
+// by these two statements only.  vmcnt(0) also waits for the stores of the writing pass (other waves of the CU run meanwhile).
+#define LANE_VGPRS 64
+#define LANE_PRE_REG "v64"
+__device__ __forceinline__ void prefetch_issue(const uint32_t *p) { asm volatile("global_load_dword " LANE_PRE_REG ", %0, off" ::"v"(p) : LANE_PRE_REG, "memory"); }
+__device__ __forceinline__ uint32_t prefetch_take()
+{
+  uint32_t x;
+  asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " LANE_PRE_REG : "=v"(x)::"memory");
+  return x;
+}
+
+// walks [entry, limit) of lanes with `run`; returns the exit: bit position of the first literal/length code at or beyond
+// limit, | X_EOB behind an end-of-block code, | X_BAD at an undecodable code or beyond the end of the stream
+template <int WRITE>
+__device__ __forceinline__ uint32_t lane_walk(const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t entry, uint32_t limit, bool run,
+                                              uint32_t &nout, uint32_t &nmatch, uint8_t *__restrict__ gout, unsigned long long *__restrict__ tok, uint32_t opos, uint32_t tpos,
+                                              uint32_t &bad)
+{
+  const uint16_t *tab = h.lfast;  // dfast follows it
+  uint32_t pos = run ? entry : 0u, want = 0, len = 0, result = X_NONE;
+  uint32_t dw = pos >> 5, nb = 0;
+  uint64_t bb = 0;
+  const uint32_t last_dw = end_dw - 1u;  // dwords behind the stream are never asked for: a walk that would need them is beyond end_bit (X_BAD)
+  if (run)
+  {
+    const uint32_t a = dw < end_dw ? in32[dw] : 0u, b = dw + 1 < end_dw ? in32[dw + 1] : 0u;
+    bb = (((uint64_t) b << 32) | a) >> (pos & 31u);
+    nb = 64u - (pos & 31u);
+    dw += 2;
+    prefetch_issue(in32 + (dw < last_dw ? dw : last_dw));
+  }
+  const uint32_t o0 = opos;
+  uint32_t nm = 0;
+  bool act = run;
+  ST(uint32_t st_steps = 0;)
+  while (__builtin_amdgcn_ballot_w64(act))
+  {
+    ST(++st_steps;)
+    if (act)
+    {
+      if (nb <= 32u)
+      {
+        bb |= (uint64_t) prefetch_take() << nb;
+        nb += 32u;
+        ++dw;
+        prefetch_issue(in32 + (dw < last_dw ? dw : last_dw));
+      }
+      const uint32_t w = (uint32_t) bb;
+      uint32_t e = tab[want ? (1u << LIT_FAST) + (w & ((1u << DIST_FAST) - 1u)) : (w & ((1u << LIT_FAST) - 1u))];
+      if ((e & 15u) == 0u)
+      {
+        // a code longer than the direct table: its length from the canonical limits, then the symbol's entry
+        const uint32_t v = __brev(w) >> 17;
+        if (want)
+        {
+          uint32_t L = DIST_FAST + 1;
+#pragma unroll
+          for (uint32_t q = DIST_FAST + 1; q < 15; ++q) L += (uint32_t) (v >= h.dlim[q]);
+          const uint32_t slot = h.dbas[L] + (v >> (15u - L));
+          e = (v < h.dlim[15] && slot < 32u) ? h.dent[slot] : 0u;
+        }
+        else
+        {
+          uint32_t L = LIT_FAST + 1;
+#pragma unroll
+          for (uint32_t q = LIT_FAST + 1; q < 15; ++q) L += (uint32_t) (v >= h.llim[q]);
+          const uint32_t slot = h.lbas[L] + (v >> (15u - L));
+          e = (v < h.llim[15] && slot < 288u) ? h.lent[slot] : 0u;
+        }
+      }
+      const uint32_t cl = e & 15u;
+      uint32_t n = cl, stop = cl ? 0u : X_BAD;
+      if (want)
+      {
+        const uint32_t dx = (e >> 4) & 15u;
+        const uint32_t dist = 1u + (((e >> 8) & 3u) << dx) + __builtin_amdgcn_ubfe(w, cl, dx);
+        n = cl + dx;
+        if (e & (1u << 10)) stop = X_BAD;
+        if (WRITE && !stop)
+        {
+          if (dist > opos) bad = 1;
+          tok[tpos] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) dist << 32);
+          ++tpos;
+        }
+        if (!stop)
+        {
+          opos += len;
+          ++nm;
+          want = 0;
+        }
+      }
+      else if ((e & 16u) == 0u)
+      {
+        if (cl)
+        {
+          if (WRITE) gout[opos] = (uint8_t) (e >> 8);
+          ++opos;
+        }
+      }
+      else
+      {
+        const uint32_t x = (e >> 5) & 7u;
+        if (x == 7u)
+          stop = (e & 0xFFF0u) == E_EOB ? X_EOB : X_BAD;
+        else
+        {
+          len = 3u + ((e >> 8) << x) + __builtin_amdgcn_ubfe(w, cl, x);
+          n = cl + x;
+          want = 1;
+        }
+      }
+      pos += n;
+      bb >>= n;
+      nb -= n;
+      if (pos > end_bit) stop = X_BAD;
+      if (stop)
+      {
+        result = pos | stop;
+        act = false;
+      }
+      else if (!want && pos >= limit)
+      {
+        result = pos;
+        act = false;
+      }
+    }
+  }
+  ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[1], (unsigned long long) st_steps);)
+  nout = opos - o0;
+  nmatch = nm;
+  return result;
+}
+
+// the Huffman block whose first code is at `bitpos` (tables built): literals and match tokens written, o / ntok advanced;
+// returns the bit behind the end-of-block code, or ~0u (malformed, or more output than out_cap)
+__device__ __forceinline__ uint32_t lanes_block(const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t bitpos, uint8_t *__restrict__ gout,
+                                                unsigned long long *__restrict__ tok, uint32_t out_cap, uint32_t &o, uint32_t &ntok)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  if (bitpos >= end_bit) return ~0u;
+  uint32_t S = (end_bit - bitpos + 63u) >> 6;
+  S = S < LANE_PART_MIN ? LANE_PART_MIN : S;
+  const uint32_t s = bitpos + lane * S;
+  const uint32_t limit = s + S < end_bit ? s + S : end_bit;
+  uint32_t entry = s < end_bit ? s : X_NONE, exitv = X_NONE, nout = 0, nm = 0, bad = 0;
+  bool need = true;
+  for (int pass = 0; pass < 66; ++pass)
+  {
+    const bool run = need && entry != X_NONE && entry < limit;
+    ST(const unsigned long long st_run = __builtin_amdgcn_ballot_w64(run); if (threadIdx.x == 0) { atomicAdd(&g_bgzf_stats[5], 1ull); if (st_run) atomicMax(&g_bgzf_stats[4], (unsigned long long) pass + 1ull); })
+    uint32_t no = 0, nmm = 0;
+    ST(const uint64_t st_w0 = wall_clock64();)
+    const uint32_t ex = lane_walk<0>(h, in32, end_dw, end_bit, entry, limit, run, no, nmm, nullptr, nullptr, 0u, 0u, bad);
+    ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[0], (unsigned long long) (wall_clock64() - st_w0));)
+    if (need)
+    {
+      exitv = run ? ex : entry;  // no entry: no exit; an entry beyond the part: nothing to walk, the neighbour enters there
+      nout = run ? no : 0u;
+      nm = run ? nmm : 0u;
+    }
+    const uint32_t prev = (uint32_t) __shfl_up((int) exitv, 1);
+    uint32_t ne = lane == 0 ? bitpos : ((prev & (X_EOB | X_BAD)) ? X_NONE : prev);
+    if (ne != X_NONE && ne >= end_bit) ne = X_NONE;
+    need = ne != entry;
+    entry = ne;
+    if (!__builtin_amdgcn_ballot_w64(need)) break;
+    if (pass + 1 >= LANE_PASSES && __builtin_amdgcn_ballot_w64(need && entry != X_NONE && entry < limit)) return X_RETRY;
+  }
+  const bool real = entry != X_NONE;
+  const unsigned long long stops = __builtin_amdgcn_ballot_w64(real && (exitv & (X_EOB | X_BAD)) != 0u);
+  if (!stops) return ~0u;  // no end of block before the end of the stream
+  const uint32_t fs = (uint32_t) __ffsll((long long) stops) - 1u;
+  const uint32_t fx = (uint32_t) __builtin_amdgcn_readlane((int) exitv, (int) fs);
+  if (fx & X_BAD) return ~0u;
+  const uint32_t my_out = real ? nout : 0u, my_m = real ? nm : 0u;
+  const uint32_t incl = wave_incl_scan(my_out), mincl = wave_incl_scan(my_m);
+  const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63), mtotal = (uint32_t) __builtin_amdgcn_readlane((int) mincl, 63);
+  if (o + total > out_cap || ntok + mtotal > BGZF_TOKENS_PER_BLOCK) return ~0u;
+  uint32_t no = 0, nmm = 0;
+  ST(const uint64_t st_w1 = wall_clock64();)
+  (void) lane_walk<1>(h, in32, end_dw, end_bit, entry, limit, real && entry < limit, no, nmm, gout, tok, o + incl - my_out, ntok + mincl - my_m, bad);
+  ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[2], (unsigned long long) (wall_clock64() - st_w1));)
+  if (__builtin_amdgcn_ballot_w64(bad != 0u)) return ~0u;
+  o += total;
+  ntok += mtotal;
+  return fx & X_POS;
+}
+
 // Walks one deflate stream: literals -> gout, matches -> tok[] (position | length << 16 | distance << 32).  Returns the
 // number of output positions (ntok = number of tokens), or ~0u on a malformed stream.
+template <int LANES>
 __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in_off, uint32_t in_len, uint8_t *gout, unsigned long long *tok, uint32_t out_cap, HuffLds &h, uint32_t &ntok)
 {
   const uint32_t lane = threadIdx.x & 63;
@@ -350,7 +568,22 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
       if (!uni(build_tables<T_LITLEN>(h, h.lens, nlen, h.lfast, LIT_FAST, h.lent, h.lcount))) return ~0u;
       if (!uni(build_tables<T_DIST>(h, h.lens + 288, ndist, h.dfast, DIST_FAST, h.dent, h.dcount))) return ~0u;
       ST(st_tb += wall_clock64() - tb0;)
-      while (true)
+      bool walked = false;
+      if (LANES)
+      {
+        const uint32_t r = uni(lanes_block(h, dc.in32, dc.end_dw, dc.end_bit, uni(dc.bitpos), gout, tok, out_cap, o, ntok));
+        if (r == ~0u) return ~0u;
+        if (r != X_RETRY)
+        {
+          dc.bitpos = r;
+          o = uni(o);
+          ntok = uni(ntok);
+          walked = true;
+        }
+        ST(else ++st_slow;)
+      }
+      // (the walks of the lanes did not agree within LANE_PASSES passes: nothing was written, the rounds decode the block)
+      while (!walked)
       {
         dc.ensure();
         dc.bitpos = uni(dc.bitpos);
@@ -508,9 +741,9 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
       if (lane == 0)
       {
         atomicAdd(&g_bgzf_stats[1], (unsigned long long) st_rounds);
-        atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
-        atomicAdd(&g_bgzf_stats[5], (unsigned long long) st_slow);
-        atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
+        if (!LANES) atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
+        atomicAdd(&g_bgzf_stats[5], LANES ? (unsigned long long) st_slow << 32 : (unsigned long long) st_slow);
+        if (LANES) atomicMax(&g_bgzf_stats[6], (unsigned long long) (wall_clock64() - st_t0)); else atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
         atomicAdd(&g_bgzf_stats[0], (unsigned long long) st_ll | ((unsigned long long) st_fix << 32));
         atomicAdd(&g_bgzf_stats[4], (unsigned long long) st_dlong);
         atomicAdd(&g_bgzf_stats[3], (unsigned long long) st_tb);
@@ -524,6 +757,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
 }
 
 // blk[first + blockIdx.x]: literals into out, match tokens into slab block blockIdx.x, their number into ntok[blockIdx.x]
+template <int LANES>
 __device__ __forceinline__ void decode_block(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
                                              unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err, HuffLds &s_h)
 {
@@ -533,7 +767,7 @@ __device__ __forceinline__ void decode_block(const uint8_t *__restrict__ file, c
   if (b.isize == 0)
     got = 0;
   else if (b.isize <= 65536u)
-    got = decode_wave(file, b.in_off, b.clen, out + b.out_off, slab + (size_t) blockIdx.x * BGZF_TOKENS_PER_BLOCK, b.isize, s_h, nt);
+    got = decode_wave<LANES>(file, b.in_off, b.clen, out + b.out_off, slab + (size_t) blockIdx.x * BGZF_TOKENS_PER_BLOCK, b.isize, s_h, nt);
   const bool bad = got != b.isize;
   if (threadIdx.x == 0)
   {
@@ -542,22 +776,24 @@ __device__ __forceinline__ void decode_block(const uint8_t *__restrict__ file, c
   }
 }
 // one launch has the GPU to itself (a whole file at once): as many waves per CU as the LDS holds (22)
-__global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+template <int LANES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(LANE_VGPRS))) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
                                                     unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
   __shared__ HuffLds s_h;
-  decode_block(file, blk, first, nblk, out, slab, ntok, err, s_h);
+  decode_block<LANES>(file, blk, first, nblk, out, slab, ntok, err, s_h);
 }
 // the chunks of the streaming feed: decoders of several chunks and the resolve blocks of others share the CUs.  Four waves per
 // SIMD (the register allocation is rounded up to enforce it) leave 45 KiB of LDS and a wave slot per SIMD with 96 registers
 // on every CU - room for a resolve block; without the cap the decoders fill the LDS (22 x 7 KiB) and the resolve blocks of
 // a chunk wait until the other chunks' decoders have drained.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
+template <int LANES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4), amdgpu_num_vgpr(LANE_VGPRS))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
                                                                                                       uint32_t nblk, uint8_t *__restrict__ out, unsigned long long *__restrict__ slab,
                                                                                                       uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
   __shared__ HuffLds s_h;
-  decode_block(file, blk, first, nblk, out, slab, ntok, err, s_h);
+  decode_block<LANES>(file, blk, first, nblk, out, slab, ntok, err, s_h);
 }
 
 // LZ77 resolution of one block by pointer jumping in LDS (file comment), a window of RES_WIN output positions at a time.
@@ -677,6 +913,7 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, RES_WIN * 2));
     attr_set = true;
   }
+  static const bool rounds = getenv("BK_BGZF_ROUNDS") != nullptr;  // the decoder that walks 64 bit positions per round (comparison)
   const uint32_t cap = bgzf_scratch_blocks(nblk);
   unsigned long long *slab = static_cast<unsigned long long *>(scratch_dev);
   uint32_t *ntok = reinterpret_cast<uint32_t *>(slab + (size_t) cap * BGZF_TOKENS_PER_BLOCK);
@@ -684,9 +921,9 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
   {
     const uint32_t nb = nblk - first < BGZF_BATCH_BLOCKS ? nblk - first : BGZF_BATCH_BLOCKS;
     if (shared_gpu)
-      hipLaunchKernelGGL(k_bgzf_decode_shared, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
+      hipLaunchKernelGGL(rounds ? k_bgzf_decode_shared<0> : k_bgzf_decode_shared<1>, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
     else
-      hipLaunchKernelGGL(k_bgzf_decode, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
+      hipLaunchKernelGGL(rounds ? k_bgzf_decode<0> : k_bgzf_decode<1>, dim3(nb), dim3(64), 0, st, file_dev, blk_dev, first, nb, out_dev, slab, ntok, err_dev);
     hipLaunchKernelGGL(k_bgzf_resolve, dim3(nb), dim3(RESOLVE_THREADS), RES_WIN * 2, st, blk_dev, first, nb, out_dev, slab, ntok);
   }
 #ifdef BGZF_STATS
@@ -696,6 +933,8 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bgzf_stats), 64));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bgzf_stats), z, 64));
+    fprintf(stderr, "[bgzf raw] lanes decoder: walk passes %.1f us, write pass %.1f us, tables %.1f us, whole %.1f us per block; %.1f steps, %.1f passes per block; slowest block %.1f us, most walking passes of a Huffman block %.0f, %llu Huffman blocks left to the rounds\n", h[0] * 0.01 / nblk, h[2] * 0.01 / nblk,
+            h[3] * 0.01 / nblk, h[7] * 0.01 / nblk, (double) h[1] / nblk, (double) (h[5] & 0xFFFFFFFFull) / nblk, h[6] * 0.01, (double) h[4], h[5] >> 32);
     fprintf(stderr, "[bgzf] %u blocks: %llu long-code fix-ups, %llu rounds, %llu symbols on the scalar path (%llu long literal/length codes, %llu long distance codes), %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[0] >> 32, h[1],
             h[5], h[0] & 0xFFFFFFFFull, h[4], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
   }
