@@ -257,160 +257,181 @@ __device__ __forceinline__ uint32_t walk_code(uint32_t w, const uint16_t *ent, c
 // The rounds below spend 64 lanes on 64 bit positions of which ~7 start a symbol.  Here the rest of the stream is cut into 64
 // parts of S bits and lane i walks part i symbol by symbol, one Huffman code per step (a literal/length code with the length's
 // extra bits, or - after a length - the distance code with its extra bits: one table lookup per step, never more than 28
-// bits), from a 64-bit buffer in registers that takes a dword when it holds 32 bits or fewer (the following dword is on its
-// way while the buffer is used).  Lane i does not know where a code starts inside its part: it starts at the part's first
+// bits), from a 64-bit buffer in registers that takes a dword when it holds 32 bits or fewer (the two following dwords are on
+// their way while the buffer is used).  Lane i does not know where a code starts inside its part: it starts at the part's first
 // bit, and Huffman streams synchronise - after some symbols a walk from a wrong bit is on the true chain.  The walk of lane i
-// ends at the first literal/length code at or beyond the end of its part; that exit is where lane i+1 must really enter.  The
-// walks are repeated from the neighbour's exit until no entry changes: lane 0's entry is the true one, so after pass k lanes
-// 0..k-1 are final whatever the data (a fixed point in at most 64 passes); when every speculative walk synchronised inside
-// its own part - the usual case with parts of ~400 symbols - the second pass confirms every exit and the loop ends.  The
-// passes count output bytes and matches, a wave prefix sum turns the counts into positions, and a last pass writes.
-constexpr uint32_t X_EOB = 1u << 30, X_BAD = 1u << 31, X_NONE = 0xFFFFFFFFu, X_POS = (1u << 30) - 1u;
+// ends at the first literal/length code at or beyond the end of its part; that exit is where lane i+1 must really enter.
+// Every walk remembers where it stood, and what it had counted, at its first code at or beyond bit W of its part (checkpoint).
+// A lane whose entry changes walks from the new entry to the checkpoint bit only: at the same code there, the rest of the
+// old walk - its exit, its counts from the checkpoint on - holds for the new entry too; elsewhere the lane walks on to the end
+// of its part and that walk is its reference from then on.  Entries are handed on until none changes: lane 0's entry is the
+// true one, so after pass k lanes 0..k-1 are final whatever the data (a fixed point in at most 64 passes); when every
+// speculative walk synchronised before its checkpoint - the usual case - the second pass is 64 short walks and the last.
+// The walks count output bytes and matches, a wave prefix sum turns the counts into positions, and one more walk writes.
+//
+// A stretch whose codes all have the same length (random bytes) never synchronises: a walk from a wrong bit stays wrong and the
+// true entries move on by one lane per pass.  After LANE_FULL_WALKS passes that needed walks beyond the checkpoint the block is
+// left to the rounds, which do not depend on the data (X_RETRY; nothing has been written by then).
+constexpr uint32_t X_EOB = 1u << 30, X_BAD = 1u << 31, X_NONE = 0xFFFFFFFFu, X_POS = (1u << 30) - 1u, X_RETRY = 0xFFFFFFFEu;
 constexpr uint32_t LANE_PART_MIN = 512;  // bits
-// A stretch whose codes all have the same length (random bytes) never synchronises: a walk from a wrong bit stays wrong, the true
-// entries then move on by one lane per pass.  After LANE_PASSES walks with entries still changing the block is left to the rounds,
-// which do not depend on the data (X_RETRY).
-constexpr int LANE_PASSES = 4;
-constexpr uint32_t X_RETRY = 0xFFFFFFFEu;
+constexpr uint32_t LANE_CHECK = 512;     // W: bits from the start of a part to its checkpoint
+constexpr int LANE_FULL_WALKS = 3;
 
-// The dword that follows a lane's bit buffer is loaded one refill ahead.  It must stay pending while the lane decodes, and the
-// compiler would wait for it at once (a load under a lane condition ends in a register copy that needs the value), so it lives in a
-// register the compiler does not own: the kernels are limited to LANE_VGPRS registers (amdgpu_num_vgpr) and v[LANE_VGPRS] is touched
-// by these two statements only.  vmcnt(0) also waits for the stores of the writing pass (other waves of the CU run meanwhile).
-#define LANE_VGPRS 64
-#define LANE_PRE_REG "v64"
-__device__ __forceinline__ void prefetch_issue(const uint32_t *p) { asm volatile("global_load_dword " LANE_PRE_REG ", %0, off" ::"v"(p) : LANE_PRE_REG, "memory"); }
-__device__ __forceinline__ uint32_t prefetch_take()
+// The dwords that follow a lane's bit buffer are loaded two refills ahead.  They must stay pending while the lane decodes, and
+// the compiler would wait for such a load at once (a load under a lane condition ends in a register copy that needs the value),
+// so they are loaded into registers the compiler does not allocate in these kernels: the accumulation registers a0 and a1
+// (nothing here uses MFMA and nothing spills; tests/test_cpu_host.py looks at the kernels' ISA for any other use of them).  A
+// lane uses the two in turn.  vmcnt(1) is enough at a refill: the dword a lane takes was asked for before the lane's other
+// pending dword, so it is never the newest request of the wave, whatever the other lanes and the stores of the writing walk have
+// issued since.  (The register that is not selected may still be pending: reading it is harmless, its value is dropped.)
+__device__ __forceinline__ void prefetch_issue(const uint32_t *p, uint32_t slot)
 {
-  uint32_t x;
-  asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " LANE_PRE_REG : "=v"(x)::"memory");
+  if (slot)
+    asm volatile("global_load_dword a1, %0, off" ::"v"(p) : "a1", "memory");
+  else
+    asm volatile("global_load_dword a0, %0, off" ::"v"(p) : "a0", "memory");
+}
+__device__ __forceinline__ uint32_t prefetch_take(uint32_t slot)
+{
+  uint32_t x, y;
+  asm volatile("s_waitcnt vmcnt(1)\n\t"
+               "v_accvgpr_read_b32 %0, a0\n\t"
+               "v_accvgpr_read_b32 %1, a1\n\t"
+               "v_cmp_ne_u32 vcc, 0, %2\n\t"
+               "s_nop 0\n\t"
+               "v_cndmask_b32 %0, %0, %1, vcc"
+               : "=&v"(x), "=&v"(y)
+               : "v"(slot)
+               : "vcc", "memory");
   return x;
 }
 
-// walks [entry, limit) of lanes with `run`; returns the exit: bit position of the first literal/length code at or beyond
-// limit, | X_EOB behind an end-of-block code, | X_BAD at an undecodable code or beyond the end of the stream
-template <int WRITE>
-__device__ __forceinline__ uint32_t lane_walk(const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t entry, uint32_t limit, bool run,
-                                              uint32_t &nout, uint32_t &nmatch, uint8_t *__restrict__ gout, unsigned long long *__restrict__ tok, uint32_t opos, uint32_t tpos,
-                                              uint32_t &bad)
+struct LaneWalk
 {
-  const uint16_t *tab = h.lfast;  // dfast follows it
-  uint32_t pos = run ? entry : 0u, want = 0, len = 0, result = X_NONE;
-  uint32_t dw = pos >> 5, nb = 0;
-  uint64_t bb = 0;
+  uint64_t bb;    // unread bits, the next one in bit 0
+  uint32_t nb;    // how many of them are valid (> 32 at every lookup)
+  uint32_t dw;    // dword index of the older pending dword
+  uint32_t slot;  // which register holds it
+  uint32_t pos;   // bit position of the next code
+  uint32_t opos;  // output position (counting walks: bytes so far)
+  uint32_t nm;    // matches so far (writing walk: index of the next token)
+  uint32_t stop;  // X_EOB / X_BAD once the walk has ended for good
+};
+
+__device__ __forceinline__ void lane_begin(LaneWalk &k, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t entry, bool run, uint32_t opos, uint32_t tpos)
+{
   const uint32_t last_dw = end_dw - 1u;  // dwords behind the stream are never asked for: a walk that would need them is beyond end_bit (X_BAD)
+  k.pos = run ? entry : 0u;
+  k.dw = k.pos >> 5;
+  k.bb = 0;
+  k.nb = 0;
+  k.slot = 0;
+  k.opos = opos;
+  k.nm = tpos;
+  k.stop = 0;
   if (run)
   {
-    const uint32_t a = dw < end_dw ? in32[dw] : 0u, b = dw + 1 < end_dw ? in32[dw + 1] : 0u;
-    bb = (((uint64_t) b << 32) | a) >> (pos & 31u);
-    nb = 64u - (pos & 31u);
-    dw += 2;
-    prefetch_issue(in32 + (dw < last_dw ? dw : last_dw));
+    const uint32_t a = in32[k.dw < last_dw ? k.dw : last_dw], b = in32[k.dw + 1 < last_dw ? k.dw + 1 : last_dw];
+    k.bb = (((uint64_t) b << 32) | a) >> (k.pos & 31u);
+    k.nb = 64u - (k.pos & 31u);
+    k.dw += 2;
+    prefetch_issue(in32 + (k.dw < last_dw ? k.dw : last_dw), 0u);
+    prefetch_issue(in32 + (k.dw + 1 < last_dw ? k.dw + 1 : last_dw), 1u);
   }
-  const uint32_t o0 = opos;
-  uint32_t nm = 0;
-  bool act = run;
+}
+
+// lanes with `run` walk on until their next literal/length code is at or beyond `until`, or the walk ends (k.stop).
+// One step = one code of every walking lane; straight-line apart from the refill, the long codes and the stores: a lane that
+// has finished keeps executing with an advance of 0 bits.
+template <int WRITE>
+__device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t until, bool run,
+                                             uint8_t *__restrict__ gout, unsigned long long *__restrict__ tok, uint32_t &bad)
+{
+  const uint16_t *tab = h.lfast;  // dfast follows it
+  const uint32_t last_dw = end_dw - 1u;
+  uint64_t bb = k.bb;
+  uint32_t nb = k.nb, dw = k.dw, slot = k.slot, pos = k.pos, opos = k.opos, nm = k.nm, kstop = k.stop;
+  uint32_t want = 0, len = 0;
+  uint32_t act = (uint32_t) (run && !kstop && pos < until);
   ST(uint32_t st_steps = 0;)
-  while (__builtin_amdgcn_ballot_w64(act))
+  if (__builtin_amdgcn_ballot_w64(act != 0u))
   {
-    ST(++st_steps;)
-    if (act)
+    do
     {
+      ST(++st_steps;)
       if (nb <= 32u)
       {
-        bb |= (uint64_t) prefetch_take() << nb;
+        bb |= (uint64_t) prefetch_take(slot) << nb;
         nb += 32u;
+        prefetch_issue(in32 + (dw + 2 < last_dw ? dw + 2 : last_dw), slot);
         ++dw;
-        prefetch_issue(in32 + (dw < last_dw ? dw : last_dw));
+        slot ^= 1u;
       }
       const uint32_t w = (uint32_t) bb;
-      uint32_t e = tab[want ? (1u << LIT_FAST) + (w & ((1u << DIST_FAST) - 1u)) : (w & ((1u << LIT_FAST) - 1u))];
-      if ((e & 15u) == 0u)
+      uint32_t e = tab[want ? (1u << LIT_FAST) | (w & ((1u << DIST_FAST) - 1u)) : (w & ((1u << LIT_FAST) - 1u))];
+      if (__builtin_amdgcn_ballot_w64((e & 15u) == 0u && act))
       {
-        // a code longer than the direct table: its length from the canonical limits, then the symbol's entry
-        const uint32_t v = __brev(w) >> 17;
-        if (want)
+        // codes longer than the direct table: the length from the canonical limits, then the symbol's entry
+        if ((e & 15u) == 0u)
         {
-          uint32_t L = DIST_FAST + 1;
+          const uint32_t v = __brev(w) >> 17;
+          uint32_t Ll = LIT_FAST + 1, Ld = DIST_FAST + 1;
 #pragma unroll
-          for (uint32_t q = DIST_FAST + 1; q < 15; ++q) L += (uint32_t) (v >= h.dlim[q]);
-          const uint32_t slot = h.dbas[L] + (v >> (15u - L));
-          e = (v < h.dlim[15] && slot < 32u) ? h.dent[slot] : 0u;
-        }
-        else
-        {
-          uint32_t L = LIT_FAST + 1;
+          for (uint32_t q = LIT_FAST + 1; q < 15; ++q) Ll += (uint32_t) (v >= h.llim[q]);
 #pragma unroll
-          for (uint32_t q = LIT_FAST + 1; q < 15; ++q) L += (uint32_t) (v >= h.llim[q]);
-          const uint32_t slot = h.lbas[L] + (v >> (15u - L));
-          e = (v < h.llim[15] && slot < 288u) ? h.lent[slot] : 0u;
+          for (uint32_t q = DIST_FAST + 1; q < 15; ++q) Ld += (uint32_t) (v >= h.dlim[q]);
+          const uint32_t L = want ? Ld : Ll;
+          const uint32_t sl = (want ? h.dbas[L] : h.lbas[L]) + (v >> (15u - L));
+          const bool ok = want ? (v < h.dlim[15] && sl < 32u) : (v < h.llim[15] && sl < 288u);
+          e = ok ? (want ? h.dent[sl] : h.lent[sl]) : 0u;
         }
       }
+      // the fields of either entry kind: x extra bits, value = (m << x) + extra (the literal itself, length - 3, distance - 1)
       const uint32_t cl = e & 15u;
-      uint32_t n = cl, stop = cl ? 0u : X_BAD;
-      if (want)
-      {
-        const uint32_t dx = (e >> 4) & 15u;
-        const uint32_t dist = 1u + (((e >> 8) & 3u) << dx) + __builtin_amdgcn_ubfe(w, cl, dx);
-        n = cl + dx;
-        if (e & (1u << 10)) stop = X_BAD;
-        if (WRITE && !stop)
-        {
-          if (dist > opos) bad = 1;
-          tok[tpos] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) dist << 32);
-          ++tpos;
-        }
-        if (!stop)
-        {
-          opos += len;
-          ++nm;
-          want = 0;
-        }
-      }
-      else if ((e & 16u) == 0u)
-      {
-        if (cl)
-        {
-          if (WRITE) gout[opos] = (uint8_t) (e >> 8);
-          ++opos;
-        }
-      }
-      else
-      {
-        const uint32_t x = (e >> 5) & 7u;
-        if (x == 7u)
-          stop = (e & 0xFFF0u) == E_EOB ? X_EOB : X_BAD;
-        else
-        {
-          len = 3u + ((e >> 8) << x) + __builtin_amdgcn_ubfe(w, cl, x);
-          n = cl + x;
-          want = 1;
-        }
-      }
+      const uint32_t is_lit = ((want | (e >> 4)) & 1u) ^ 1u;  // literal/length state and bit 4 clear
+      const uint32_t xr = want ? (e >> 4) & 15u : (e >> 5) & 7u;
+      const uint32_t special = (want ^ 1u) & (is_lit ^ 1u) & (uint32_t) (xr == 7u);  // end of block / invalid symbol
+      const uint32_t x = (is_lit | special) ? 0u : xr;
+      const uint32_t m = want ? (e >> 8) & 3u : e >> 8;
+      const uint32_t val = (m << x) + __builtin_amdgcn_ubfe(w, cl, x);
+      const uint32_t n = act ? cl + x : 0u;
       pos += n;
       bb >>= n;
       nb -= n;
-      if (pos > end_bit) stop = X_BAD;
-      if (stop)
+      const uint32_t isbad = (uint32_t) (cl == 0u) | (want & (e >> 10)) | (special & (uint32_t) (m != 0u)) | (uint32_t) (pos > end_bit);
+      const uint32_t stop = (isbad & 1u) ? X_BAD : special ? X_EOB : 0u;
+      const uint32_t ok = act & ((isbad & 1u) ^ 1u);
+      const uint32_t done_match = ok & want, put_lit = ok & (want ^ 1u) & is_lit, got_len = ok & (want ^ 1u) & (is_lit ^ 1u) & (special ^ 1u);
+      if (WRITE)
       {
-        result = pos | stop;
-        act = false;
+        if (done_match)
+        {
+          if (val >= opos) bad = 1;  // distance = val + 1 beyond the start of the output
+          tok[nm] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) (val + 1u) << 32);
+        }
+        if (put_lit) gout[opos] = (uint8_t) val;
       }
-      else if (!want && pos >= limit)
-      {
-        result = pos;
-        act = false;
-      }
-    }
+      opos += done_match ? len : put_lit;
+      nm += done_match;
+      len = got_len ? val + 3u : len;
+      want = got_len;
+      kstop = act ? stop : kstop;
+      act = act & (uint32_t) (stop == 0u) & (want | (uint32_t) (pos < until));
+    } while (__builtin_amdgcn_ballot_w64(act != 0u));
   }
+  k.bb = bb;
+  k.nb = nb;
+  k.dw = dw;
+  k.slot = slot;
+  k.pos = pos;
+  k.opos = opos;
+  k.nm = nm;
+  k.stop = kstop;
   ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[1], (unsigned long long) st_steps);)
-  nout = opos - o0;
-  nmatch = nm;
-  return result;
 }
 
 // the Huffman block whose first code is at `bitpos` (tables built): literals and match tokens written, o / ntok advanced;
-// returns the bit behind the end-of-block code, or ~0u (malformed, or more output than out_cap)
+// returns the bit behind the end-of-block code, X_RETRY (see above), or ~0u (malformed, or more output than out_cap)
 __device__ __forceinline__ uint32_t lanes_block(const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t bitpos, uint8_t *__restrict__ gout,
                                                 unsigned long long *__restrict__ tok, uint32_t out_cap, uint32_t &o, uint32_t &ntok)
 {
@@ -420,21 +441,61 @@ __device__ __forceinline__ uint32_t lanes_block(const HuffLds &h, const uint32_t
   S = S < LANE_PART_MIN ? LANE_PART_MIN : S;
   const uint32_t s = bitpos + lane * S;
   const uint32_t limit = s + S < end_bit ? s + S : end_bit;
+  const uint32_t check = s + LANE_CHECK < limit ? s + LANE_CHECK : limit;
+  // the reference walk of this lane: its entry, its checkpoint (position, counts there), its exit and counts at the exit
+  uint32_t ref_entry = X_NONE, cp_pos = X_NONE, cp_out = 0, cp_m = 0, ref_exit = X_NONE, ref_out = 0, ref_m = 0;
+  // what holds for the current entry
   uint32_t entry = s < end_bit ? s : X_NONE, exitv = X_NONE, nout = 0, nm = 0, bad = 0;
   bool need = true;
+  int full_walks = 0;
   for (int pass = 0; pass < 66; ++pass)
   {
-    const bool run = need && entry != X_NONE && entry < limit;
-    ST(const unsigned long long st_run = __builtin_amdgcn_ballot_w64(run); if (threadIdx.x == 0) { atomicAdd(&g_bgzf_stats[5], 1ull); if (st_run) atomicMax(&g_bgzf_stats[4], (unsigned long long) pass + 1ull); })
-    uint32_t no = 0, nmm = 0;
+    const bool walk = need && entry != X_NONE && entry < limit && entry != ref_entry;
+    ST(const unsigned long long st_run = __builtin_amdgcn_ballot_w64(walk); if (threadIdx.x == 0) { atomicAdd(&g_bgzf_stats[5], 1ull); if (st_run) atomicMax(&g_bgzf_stats[4], (unsigned long long) pass + 1ull); })
     ST(const uint64_t st_w0 = wall_clock64();)
-    const uint32_t ex = lane_walk<0>(h, in32, end_dw, end_bit, entry, limit, run, no, nmm, nullptr, nullptr, 0u, 0u, bad);
+    LaneWalk k;
+    lane_begin(k, in32, end_dw, entry, walk, 0u, 0u);
+    lane_segment<0>(k, h, in32, end_dw, end_bit, check, walk, nullptr, nullptr, bad);
+    // at the reference walk's checkpoint: the rest of that walk holds
+    const bool joined = walk && !k.stop && cp_pos != X_NONE && k.pos == cp_pos;
+    const bool on = walk && !joined;
+    const uint32_t my_cp_pos = k.stop ? X_NONE : k.pos, my_cp_out = k.opos, my_cp_m = k.nm;
+    const unsigned long long any_on = __builtin_amdgcn_ballot_w64(on && !k.stop && k.pos < limit);
+    if (any_on)
+    {
+      if (++full_walks > LANE_FULL_WALKS) return X_RETRY;
+      lane_segment<0>(k, h, in32, end_dw, end_bit, limit, on, nullptr, nullptr, bad);
+    }
     ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[0], (unsigned long long) (wall_clock64() - st_w0));)
+    if (on)
+    {
+      ref_entry = entry;
+      cp_pos = my_cp_pos;
+      cp_out = my_cp_out;
+      cp_m = my_cp_m;
+      ref_exit = k.pos | k.stop;
+      ref_out = k.opos;
+      ref_m = k.nm;
+    }
     if (need)
     {
-      exitv = run ? ex : entry;  // no entry: no exit; an entry beyond the part: nothing to walk, the neighbour enters there
-      nout = run ? no : 0u;
-      nm = run ? nmm : 0u;
+      if (entry == X_NONE || entry >= limit)
+      {
+        exitv = entry;  // no entry: no exit; an entry beyond the part: nothing to walk, the neighbour enters there
+        nout = nm = 0;
+      }
+      else if (joined)
+      {
+        exitv = ref_exit;
+        nout = k.opos + (ref_out - cp_out);
+        nm = k.nm + (ref_m - cp_m);
+      }
+      else  // the reference walk itself (just made, or met again)
+      {
+        exitv = ref_exit;
+        nout = ref_out;
+        nm = ref_m;
+      }
     }
     const uint32_t prev = (uint32_t) __shfl_up((int) exitv, 1);
     uint32_t ne = lane == 0 ? bitpos : ((prev & (X_EOB | X_BAD)) ? X_NONE : prev);
@@ -442,7 +503,6 @@ __device__ __forceinline__ uint32_t lanes_block(const HuffLds &h, const uint32_t
     need = ne != entry;
     entry = ne;
     if (!__builtin_amdgcn_ballot_w64(need)) break;
-    if (pass + 1 >= LANE_PASSES && __builtin_amdgcn_ballot_w64(need && entry != X_NONE && entry < limit)) return X_RETRY;
   }
   const bool real = entry != X_NONE;
   const unsigned long long stops = __builtin_amdgcn_ballot_w64(real && (exitv & (X_EOB | X_BAD)) != 0u);
@@ -454,9 +514,13 @@ __device__ __forceinline__ uint32_t lanes_block(const HuffLds &h, const uint32_t
   const uint32_t incl = wave_incl_scan(my_out), mincl = wave_incl_scan(my_m);
   const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63), mtotal = (uint32_t) __builtin_amdgcn_readlane((int) mincl, 63);
   if (o + total > out_cap || ntok + mtotal > BGZF_TOKENS_PER_BLOCK) return ~0u;
-  uint32_t no = 0, nmm = 0;
   ST(const uint64_t st_w1 = wall_clock64();)
-  (void) lane_walk<1>(h, in32, end_dw, end_bit, entry, limit, real && entry < limit, no, nmm, gout, tok, o + incl - my_out, ntok + mincl - my_m, bad);
+  {
+    const bool wr = real && entry < limit;
+    LaneWalk k;
+    lane_begin(k, in32, end_dw, entry, wr, o + incl - my_out, ntok + mincl - my_m);
+    lane_segment<1>(k, h, in32, end_dw, end_bit, limit, wr, gout, tok, bad);
+  }
   ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[2], (unsigned long long) (wall_clock64() - st_w1));)
   if (__builtin_amdgcn_ballot_w64(bad != 0u)) return ~0u;
   o += total;
@@ -582,7 +646,7 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
         }
         ST(else ++st_slow;)
       }
-      // (the walks of the lanes did not agree within LANE_PASSES passes: nothing was written, the rounds decode the block)
+      // (the walks of the lanes did not agree within LANE_FULL_WALKS long passes: nothing was written, the rounds decode the block)
       while (!walked)
       {
         dc.ensure();
@@ -777,7 +841,7 @@ __device__ __forceinline__ void decode_block(const uint8_t *__restrict__ file, c
 }
 // one launch has the GPU to itself (a whole file at once): as many waves per CU as the LDS holds (22)
 template <int LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(LANE_VGPRS))) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first, uint32_t nblk, uint8_t *__restrict__ out,
                                                     unsigned long long *__restrict__ slab, uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
   __shared__ HuffLds s_h;
@@ -788,7 +852,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(LANE_VGPRS))) vo
 // on every CU - room for a resolve block; without the cap the decoders fill the LDS (22 x 7 KiB) and the resolve blocks of
 // a chunk wait until the other chunks' decoders have drained.
 template <int LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4), amdgpu_num_vgpr(LANE_VGPRS))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
                                                                                                       uint32_t nblk, uint8_t *__restrict__ out, unsigned long long *__restrict__ slab,
                                                                                                       uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
