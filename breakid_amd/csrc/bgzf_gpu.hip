@@ -39,12 +39,14 @@ constexpr int LIT_FAST = 11, DIST_FAST = 9;
 // symbol statistics (build with -DBGZF_STATS, run with BK_BGZF_STATS=1); off by default
 #ifdef BGZF_STATS
 __device__ unsigned long long g_bgzf_stats[8];
+__device__ unsigned long long g_lane_stats[8];  // walk clocks, steps, write clocks, windows, long passes after a window's first, passes, windows left to the rounds, slowest block
 #define ST(x) x
 #else
 #define ST(x)
 #endif
 constexpr uint32_t CHUNK_DW = 64;            // one dword per lane
 constexpr uint32_t WIN_DW = 3 * CHUNK_DW;    // input window: three chunks in LDS, the fourth on its way in a register
+constexpr uint32_t LANE_STAGE_DW = 2120;
 constexpr uint32_t RESOLVE_THREADS = 256;
 constexpr uint32_t RES_WIN = 16384;            // output positions whose parents are in LDS at a time (k_bgzf_resolve)
 
@@ -67,6 +69,7 @@ struct HuffLds
   uint32_t offs[16], nextc[16];    // table build scratch
   uint8_t lens[344];               // code lengths: literal/length [0,288), distance [288,320), code-length code [320,339)
   uint32_t win[WIN_DW];
+  uint32_t stage[LANE_STAGE_DW];   // the window of the stream the 64 lanes walk (lanes_block), rows of 32 dwords + 1 pad
 };
 
 // every lane holds the same decoder state; saying so keeps it in scalar registers (the compiler cannot prove it
@@ -254,103 +257,50 @@ __device__ __forceinline__ uint32_t walk_code(uint32_t w, const uint16_t *ent, c
 }
 
 // ---- one Huffman block, every lane walking its own part of the bit stream ---------------------------------------------
-// The rounds below spend 64 lanes on 64 bit positions of which ~7 start a symbol.  Here the rest of the stream is cut into 64
-// parts of S bits and lane i walks part i symbol by symbol, one Huffman code per step (a literal/length code with the length's
-// extra bits, or - after a length - the distance code with its extra bits: one table lookup per step, never more than 28
-// bits), from a 64-bit buffer in registers that takes a dword when it holds 32 bits or fewer (the two following dwords are on
-// their way while the buffer is used).  Lane i does not know where a code starts inside its part: it starts at the part's first
-// bit, and Huffman streams synchronise - after some symbols a walk from a wrong bit is on the true chain.  The walk of lane i
-// ends at the first literal/length code at or beyond the end of its part; that exit is where lane i+1 must really enter.
-// Every walk remembers where it stood, and what it had counted, at its first code at or beyond bit W of its part (checkpoint).
-// A lane whose entry changes walks from the new entry to the checkpoint bit only: at the same code there, the rest of the
-// old walk - its exit, its counts from the checkpoint on - holds for the new entry too; elsewhere the lane walks on to the end
-// of its part and that walk is its reference from then on.  Entries are handed on until none changes: lane 0's entry is the
-// true one, so after pass k lanes 0..k-1 are final whatever the data (a fixed point in at most 64 passes); when every
-// speculative walk synchronised before its checkpoint - the usual case - the second pass is 64 short walks and the last.
-// The walks count output bytes and matches, a wave prefix sum turns the counts into positions, and one more walk writes.
+// The rounds below spend 64 lanes on 64 bit positions of which ~7 start a symbol.  Here the block is taken in windows of
+// 64 x LANE_PART bits (8 KiB of the stream, staged in LDS) and lane i walks part i of the window symbol by symbol, one Huffman
+// code per step (a literal/length code with the length's extra bits, or - after a length - the distance code with its extra
+// bits: one table lookup per step, never more than 28 bits, two dwords of the staged stream).  Lane i does not know where a
+// code starts inside its part: it starts at the part's first bit, and Huffman streams synchronise - after some symbols a walk
+// from a wrong bit is on the true chain.  The walk of lane i ends at the first literal/length code at or beyond the end of its
+// part; that exit is where lane i+1 must really enter.
+// Every walk remembers where it stood, and what it had counted, at its first code at or beyond bit LANE_CHECK of its part
+// (checkpoint).  A lane whose entry changes walks from the new entry to the checkpoint bit only: at the same code there, the
+// rest of the old walk - its exit, its counts from the checkpoint on - holds for the new entry too; elsewhere the lane walks on
+// to the end of its part and that walk is its reference from then on.  Entries are handed on until none changes: lane 0's entry
+// is the true one (the block's first code, or the exit of the window before), so after pass k lanes 0..k-1 are final whatever the
+// data (a fixed point in at most 64 passes); when every speculative walk synchronised before its checkpoint - the usual case -
+// the second pass is 64 short walks and the last.  The walks count output bytes and matches, a wave prefix sum turns the counts
+// into positions, one more walk writes, and the exit of lane 63 is the first code of the next window.
 //
 // A stretch whose codes all have the same length (random bytes) never synchronises: a walk from a wrong bit stays wrong and the
-// true entries move on by one lane per pass.  After LANE_FULL_WALKS passes that needed walks beyond the checkpoint the block is
-// left to the rounds, which do not depend on the data (X_RETRY; nothing has been written by then).
+// true entries move on by one lane per pass.  After LANE_FULL_WALKS passes that needed walks beyond the checkpoint the rest of
+// the block is left to the rounds, which do not depend on the data (X_RETRY: nothing of the window has been written by then).
 constexpr uint32_t X_EOB = 1u << 30, X_BAD = 1u << 31, X_NONE = 0xFFFFFFFFu, X_POS = (1u << 30) - 1u, X_RETRY = 0xFFFFFFFEu;
-constexpr uint32_t LANE_PART_MIN = 512;  // bits
-constexpr uint32_t LANE_CHECK = 512;     // W: bits from the start of a part to its checkpoint
-constexpr int LANE_FULL_WALKS = 3;
-
-// The dwords that follow a lane's bit buffer are loaded two refills ahead.  They must stay pending while the lane decodes, and
-// the compiler would wait for such a load at once (a load under a lane condition ends in a register copy that needs the value),
-// so they are loaded into registers the compiler does not allocate in these kernels: the accumulation registers a0 and a1
-// (nothing here uses MFMA and nothing spills; tests/test_cpu_host.py looks at the kernels' ISA for any other use of them).  A
-// lane uses the two in turn.  vmcnt(1) is enough at a refill: the dword a lane takes was asked for before the lane's other
-// pending dword, so it is never the newest request of the wave, whatever the other lanes and the stores of the writing walk have
-// issued since.  (The register that is not selected may still be pending: reading it is harmless, its value is dropped.)
-__device__ __forceinline__ void prefetch_issue(const uint32_t *p, uint32_t slot)
-{
-  if (slot)
-    asm volatile("global_load_dword a1, %0, off" ::"v"(p) : "a1", "memory");
-  else
-    asm volatile("global_load_dword a0, %0, off" ::"v"(p) : "a0", "memory");
-}
-__device__ __forceinline__ uint32_t prefetch_take(uint32_t slot)
-{
-  uint32_t x, y;
-  asm volatile("s_waitcnt vmcnt(1)\n\t"
-               "v_accvgpr_read_b32 %0, a0\n\t"
-               "v_accvgpr_read_b32 %1, a1\n\t"
-               "v_cmp_ne_u32 vcc, 0, %2\n\t"
-               "s_nop 0\n\t"
-               "v_cndmask_b32 %0, %0, %1, vcc"
-               : "=&v"(x), "=&v"(y)
-               : "v"(slot)
-               : "vcc", "memory");
-  return x;
-}
+constexpr uint32_t LANE_PART = 1024;   // bits of a lane's part: 32 dwords, one padded row of the staged window
+constexpr uint32_t LANE_CHECK = 384;   // bits from the start of a part to its checkpoint
+constexpr int LANE_FULL_WALKS = 8;     // per window; a long pass costs ~1/10 of the rounds over a window
+static_assert(LANE_STAGE_DW >= 64 * (LANE_PART / 32) + 4 + (64 * (LANE_PART / 32) + 4) / 32 + 1, "the staged window, the dwords a last code may reach into, one pad dword per row");
+// dword d of the window lives at d + d / 32: the lanes are 32 dwords apart, the pad spreads them over the banks
+__device__ __forceinline__ uint32_t stage_at(uint32_t d) { return d + (d >> 5); }
 
 struct LaneWalk
 {
-  uint64_t bb;    // unread bits, the next one in bit 0
-  uint32_t nb;    // how many of them are valid (> 32 at every lookup)
-  uint32_t dw;    // dword index of the older pending dword
-  uint32_t slot;  // which register holds it
   uint32_t pos;   // bit position of the next code
   uint32_t opos;  // output position (counting walks: bytes so far)
   uint32_t nm;    // matches so far (writing walk: index of the next token)
   uint32_t stop;  // X_EOB / X_BAD once the walk has ended for good
 };
 
-__device__ __forceinline__ void lane_begin(LaneWalk &k, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t entry, bool run, uint32_t opos, uint32_t tpos)
-{
-  const uint32_t last_dw = end_dw - 1u;  // dwords behind the stream are never asked for: a walk that would need them is beyond end_bit (X_BAD)
-  k.pos = run ? entry : 0u;
-  k.dw = k.pos >> 5;
-  k.bb = 0;
-  k.nb = 0;
-  k.slot = 0;
-  k.opos = opos;
-  k.nm = tpos;
-  k.stop = 0;
-  if (run)
-  {
-    const uint32_t a = in32[k.dw < last_dw ? k.dw : last_dw], b = in32[k.dw + 1 < last_dw ? k.dw + 1 : last_dw];
-    k.bb = (((uint64_t) b << 32) | a) >> (k.pos & 31u);
-    k.nb = 64u - (k.pos & 31u);
-    k.dw += 2;
-    prefetch_issue(in32 + (k.dw < last_dw ? k.dw : last_dw), 0u);
-    prefetch_issue(in32 + (k.dw + 1 < last_dw ? k.dw + 1 : last_dw), 1u);
-  }
-}
-
 // lanes with `run` walk on until their next literal/length code is at or beyond `until`, or the walk ends (k.stop).
-// One step = one code of every walking lane; straight-line apart from the refill, the long codes and the stores: a lane that
-// has finished keeps executing with an advance of 0 bits.
+// One step = one code of every walking lane; straight-line apart from the long codes and the stores: a lane that has finished
+// keeps executing with an advance of 0 bits.  wbit0 = bit position of the window's first staged dword.
 template <int WRITE>
-__device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t until, bool run,
-                                             uint8_t *__restrict__ gout, unsigned long long *__restrict__ tok, uint32_t &bad)
+__device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, uint32_t wbit0, uint32_t end_bit, uint32_t until, bool run, uint8_t *__restrict__ gout,
+                                             unsigned long long *__restrict__ tok, uint32_t &bad)
 {
   const uint16_t *tab = h.lfast;  // dfast follows it
-  const uint32_t last_dw = end_dw - 1u;
-  uint64_t bb = k.bb;
-  uint32_t nb = k.nb, dw = k.dw, slot = k.slot, pos = k.pos, opos = k.opos, nm = k.nm, kstop = k.stop;
+  uint32_t pos = k.pos, opos = k.opos, nm = k.nm, kstop = k.stop;
   uint32_t want = 0, len = 0;
   uint32_t act = (uint32_t) (run && !kstop && pos < until);
   ST(uint32_t st_steps = 0;)
@@ -359,15 +309,9 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, cons
     do
     {
       ST(++st_steps;)
-      if (nb <= 32u)
-      {
-        bb |= (uint64_t) prefetch_take(slot) << nb;
-        nb += 32u;
-        prefetch_issue(in32 + (dw + 2 < last_dw ? dw + 2 : last_dw), slot);
-        ++dw;
-        slot ^= 1u;
-      }
-      const uint32_t w = (uint32_t) bb;
+      const uint32_t rel = pos - wbit0, d = rel >> 5;
+      const uint32_t lo = h.stage[stage_at(d)], hi = h.stage[stage_at(d + 1u)];
+      const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, rel & 31u);
       uint32_t e = tab[want ? (1u << LIT_FAST) | (w & ((1u << DIST_FAST) - 1u)) : (w & ((1u << LIT_FAST) - 1u))];
       if (__builtin_amdgcn_ballot_w64((e & 15u) == 0u && act))
       {
@@ -394,10 +338,7 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, cons
       const uint32_t x = (is_lit | special) ? 0u : xr;
       const uint32_t m = want ? (e >> 8) & 3u : e >> 8;
       const uint32_t val = (m << x) + __builtin_amdgcn_ubfe(w, cl, x);
-      const uint32_t n = act ? cl + x : 0u;
-      pos += n;
-      bb >>= n;
-      nb -= n;
+      pos += act ? cl + x : 0u;
       const uint32_t isbad = (uint32_t) (cl == 0u) | (want & (e >> 10)) | (special & (uint32_t) (m != 0u)) | (uint32_t) (pos > end_bit);
       const uint32_t stop = (isbad & 1u) ? X_BAD : special ? X_EOB : 0u;
       const uint32_t ok = act & ((isbad & 1u) ^ 1u);
@@ -419,113 +360,129 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, cons
       act = act & (uint32_t) (stop == 0u) & (want | (uint32_t) (pos < until));
     } while (__builtin_amdgcn_ballot_w64(act != 0u));
   }
-  k.bb = bb;
-  k.nb = nb;
-  k.dw = dw;
-  k.slot = slot;
   k.pos = pos;
   k.opos = opos;
   k.nm = nm;
   k.stop = kstop;
-  ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[1], (unsigned long long) st_steps);)
+  ST(if (threadIdx.x == 0) atomicAdd(&g_lane_stats[1], (unsigned long long) st_steps);)
 }
 
 // the Huffman block whose first code is at `bitpos` (tables built): literals and match tokens written, o / ntok advanced;
-// returns the bit behind the end-of-block code, X_RETRY (see above), or ~0u (malformed, or more output than out_cap)
-__device__ __forceinline__ uint32_t lanes_block(const HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t bitpos, uint8_t *__restrict__ gout,
+// returns the bit behind the end-of-block code, X_RETRY with the first code that has not been decoded in `bitpos` (see above),
+// or ~0u (malformed, or more output than out_cap)
+__device__ __forceinline__ uint32_t lanes_block(HuffLds &h, const uint32_t *__restrict__ in32, uint32_t end_dw, uint32_t end_bit, uint32_t &bitpos, uint8_t *__restrict__ gout,
                                                 unsigned long long *__restrict__ tok, uint32_t out_cap, uint32_t &o, uint32_t &ntok)
 {
   const uint32_t lane = threadIdx.x & 63;
-  if (bitpos >= end_bit) return ~0u;
-  uint32_t S = (end_bit - bitpos + 63u) >> 6;
-  S = S < LANE_PART_MIN ? LANE_PART_MIN : S;
-  const uint32_t s = bitpos + lane * S;
-  const uint32_t limit = s + S < end_bit ? s + S : end_bit;
-  const uint32_t check = s + LANE_CHECK < limit ? s + LANE_CHECK : limit;
-  // the reference walk of this lane: its entry, its checkpoint (position, counts there), its exit and counts at the exit
-  uint32_t ref_entry = X_NONE, cp_pos = X_NONE, cp_out = 0, cp_m = 0, ref_exit = X_NONE, ref_out = 0, ref_m = 0;
-  // what holds for the current entry
-  uint32_t entry = s < end_bit ? s : X_NONE, exitv = X_NONE, nout = 0, nm = 0, bad = 0;
-  bool need = true;
-  int full_walks = 0;
-  for (int pass = 0; pass < 66; ++pass)
+  const uint32_t last_dw = end_dw - 1u;  // dwords behind the stream are not read: a code that would need them ends beyond end_bit (X_BAD)
+  uint32_t cur = bitpos;
+  for (;;)
   {
-    const bool walk = need && entry != X_NONE && entry < limit && entry != ref_entry;
-    ST(const unsigned long long st_run = __builtin_amdgcn_ballot_w64(walk); if (threadIdx.x == 0) { atomicAdd(&g_bgzf_stats[5], 1ull); if (st_run) atomicMax(&g_bgzf_stats[4], (unsigned long long) pass + 1ull); })
-    ST(const uint64_t st_w0 = wall_clock64();)
-    LaneWalk k;
-    lane_begin(k, in32, end_dw, entry, walk, 0u, 0u);
-    lane_segment<0>(k, h, in32, end_dw, end_bit, check, walk, nullptr, nullptr, bad);
-    // at the reference walk's checkpoint: the rest of that walk holds
-    const bool joined = walk && !k.stop && cp_pos != X_NONE && k.pos == cp_pos;
-    const bool on = walk && !joined;
-    const uint32_t my_cp_pos = k.stop ? X_NONE : k.pos, my_cp_out = k.opos, my_cp_m = k.nm;
-    const unsigned long long any_on = __builtin_amdgcn_ballot_w64(on && !k.stop && k.pos < limit);
-    if (any_on)
+    int full_walks = 0;
+    if (cur >= end_bit) return ~0u;
+    const uint32_t d0 = cur >> 5, wbit0 = d0 << 5;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < 64u * (LANE_PART / 32u) + 4u; j += 64) h.stage[stage_at(j)] = in32[d0 + j < last_dw ? d0 + j : last_dw];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t s = cur + lane * LANE_PART;
+    const uint32_t limit = s + LANE_PART < end_bit ? s + LANE_PART : end_bit;
+    const uint32_t check = s + LANE_CHECK < limit ? s + LANE_CHECK : limit;
+    // the reference walk of this lane: its entry, its checkpoint (position, counts there), its exit and counts at the exit
+    uint32_t ref_entry = X_NONE, cp_pos = X_NONE, cp_out = 0, cp_m = 0, ref_exit = X_NONE, ref_out = 0, ref_m = 0;
+    // what holds for the current entry
+    uint32_t entry = s < end_bit ? s : X_NONE, exitv = X_NONE, nout = 0, nm = 0, bad = 0;
+    bool need = true;
+    for (int pass = 0; pass < 66; ++pass)
     {
-      if (++full_walks > LANE_FULL_WALKS) return X_RETRY;
-      lane_segment<0>(k, h, in32, end_dw, end_bit, limit, on, nullptr, nullptr, bad);
+      const bool walk = need && entry != X_NONE && entry < limit && entry != ref_entry;
+      ST(if (threadIdx.x == 0) { atomicAdd(&g_lane_stats[5], 1ull); if (pass == 0) atomicAdd(&g_lane_stats[3], 1ull); })
+      ST(const uint64_t st_w0 = wall_clock64();)
+      LaneWalk k = {walk ? entry : wbit0, 0u, 0u, 0u};
+      lane_segment<0>(k, h, wbit0, end_bit, check, walk, nullptr, nullptr, bad);
+      // at the reference walk's checkpoint: the rest of that walk holds
+      const bool joined = walk && !k.stop && cp_pos != X_NONE && k.pos == cp_pos;
+      const bool on = walk && !joined;
+      const uint32_t my_cp_pos = k.stop ? X_NONE : k.pos, my_cp_out = k.opos, my_cp_m = k.nm;
+      if (__builtin_amdgcn_ballot_w64(on && !k.stop && k.pos < limit))
+      {
+        ST(if (threadIdx.x == 0 && pass) atomicAdd(&g_lane_stats[4], 1ull);)
+        if (++full_walks > LANE_FULL_WALKS)
+        {
+          ST(if (threadIdx.x == 0) atomicAdd(&g_lane_stats[6], 1ull);)
+          bitpos = cur;
+          return X_RETRY;
+        }
+        lane_segment<0>(k, h, wbit0, end_bit, limit, on, nullptr, nullptr, bad);
+      }
+      ST(if (threadIdx.x == 0) atomicAdd(&g_lane_stats[0], (unsigned long long) (wall_clock64() - st_w0));)
+      if (on)
+      {
+        ref_entry = entry;
+        cp_pos = my_cp_pos;
+        cp_out = my_cp_out;
+        cp_m = my_cp_m;
+        ref_exit = k.pos | k.stop;
+        ref_out = k.opos;
+        ref_m = k.nm;
+      }
+      if (need)
+      {
+        if (entry == X_NONE || entry >= limit)
+        {
+          exitv = entry;  // no entry: no exit; an entry beyond the part: nothing to walk, the neighbour enters there
+          nout = nm = 0;
+        }
+        else if (joined)
+        {
+          exitv = ref_exit;
+          nout = k.opos + (ref_out - cp_out);
+          nm = k.nm + (ref_m - cp_m);
+        }
+        else  // the reference walk itself (just made, or met again)
+        {
+          exitv = ref_exit;
+          nout = ref_out;
+          nm = ref_m;
+        }
+      }
+      const uint32_t prev = (uint32_t) __shfl_up((int) exitv, 1);
+      uint32_t ne = lane == 0 ? cur : ((prev & (X_EOB | X_BAD)) ? X_NONE : prev);
+      if (ne != X_NONE && ne >= end_bit) ne = X_NONE;
+      need = ne != entry;
+      entry = ne;
+      if (!__builtin_amdgcn_ballot_w64(need)) break;
     }
-    ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[0], (unsigned long long) (wall_clock64() - st_w0));)
-    if (on)
+    const bool real = entry != X_NONE;
+    const unsigned long long reals = __builtin_amdgcn_ballot_w64(real);
+    const unsigned long long stops = __builtin_amdgcn_ballot_w64(real && (exitv & (X_EOB | X_BAD)) != 0u);
+    uint32_t fx = 0;
+    if (stops)
     {
-      ref_entry = entry;
-      cp_pos = my_cp_pos;
-      cp_out = my_cp_out;
-      cp_m = my_cp_m;
-      ref_exit = k.pos | k.stop;
-      ref_out = k.opos;
-      ref_m = k.nm;
+      const uint32_t fs = (uint32_t) __ffsll((long long) stops) - 1u;
+      fx = (uint32_t) __builtin_amdgcn_readlane((int) exitv, (int) fs);
+      if (fx & X_BAD) return ~0u;
     }
-    if (need)
+    else if (~reals)
+      return ~0u;  // the stream ends inside the window without an end-of-block code
+    const uint32_t my_out = real ? nout : 0u, my_m = real ? nm : 0u;
+    const uint32_t incl = wave_incl_scan(my_out), mincl = wave_incl_scan(my_m);
+    const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63), mtotal = (uint32_t) __builtin_amdgcn_readlane((int) mincl, 63);
+    if (o + total > out_cap || ntok + mtotal > BGZF_TOKENS_PER_BLOCK) return ~0u;
+    ST(const uint64_t st_w1 = wall_clock64();)
     {
-      if (entry == X_NONE || entry >= limit)
-      {
-        exitv = entry;  // no entry: no exit; an entry beyond the part: nothing to walk, the neighbour enters there
-        nout = nm = 0;
-      }
-      else if (joined)
-      {
-        exitv = ref_exit;
-        nout = k.opos + (ref_out - cp_out);
-        nm = k.nm + (ref_m - cp_m);
-      }
-      else  // the reference walk itself (just made, or met again)
-      {
-        exitv = ref_exit;
-        nout = ref_out;
-        nm = ref_m;
-      }
+      const bool wr = real && entry < limit;
+      LaneWalk k = {wr ? entry : wbit0, o + incl - my_out, ntok + mincl - my_m, 0u};
+      lane_segment<1>(k, h, wbit0, end_bit, limit, wr, gout, tok, bad);
     }
-    const uint32_t prev = (uint32_t) __shfl_up((int) exitv, 1);
-    uint32_t ne = lane == 0 ? bitpos : ((prev & (X_EOB | X_BAD)) ? X_NONE : prev);
-    if (ne != X_NONE && ne >= end_bit) ne = X_NONE;
-    need = ne != entry;
-    entry = ne;
-    if (!__builtin_amdgcn_ballot_w64(need)) break;
+    ST(if (threadIdx.x == 0) atomicAdd(&g_lane_stats[2], (unsigned long long) (wall_clock64() - st_w1));)
+    if (__builtin_amdgcn_ballot_w64(bad != 0u)) return ~0u;
+    o += total;
+    ntok += mtotal;
+    if (stops) return fx & X_POS;
+    const uint32_t nxt = (uint32_t) __builtin_amdgcn_readlane((int) exitv, 63);  // lane 63 is real and went on to the end of its part
+    if (nxt <= cur) return ~0u;
+    cur = nxt;
   }
-  const bool real = entry != X_NONE;
-  const unsigned long long stops = __builtin_amdgcn_ballot_w64(real && (exitv & (X_EOB | X_BAD)) != 0u);
-  if (!stops) return ~0u;  // no end of block before the end of the stream
-  const uint32_t fs = (uint32_t) __ffsll((long long) stops) - 1u;
-  const uint32_t fx = (uint32_t) __builtin_amdgcn_readlane((int) exitv, (int) fs);
-  if (fx & X_BAD) return ~0u;
-  const uint32_t my_out = real ? nout : 0u, my_m = real ? nm : 0u;
-  const uint32_t incl = wave_incl_scan(my_out), mincl = wave_incl_scan(my_m);
-  const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63), mtotal = (uint32_t) __builtin_amdgcn_readlane((int) mincl, 63);
-  if (o + total > out_cap || ntok + mtotal > BGZF_TOKENS_PER_BLOCK) return ~0u;
-  ST(const uint64_t st_w1 = wall_clock64();)
-  {
-    const bool wr = real && entry < limit;
-    LaneWalk k;
-    lane_begin(k, in32, end_dw, entry, wr, o + incl - my_out, ntok + mincl - my_m);
-    lane_segment<1>(k, h, in32, end_dw, end_bit, limit, wr, gout, tok, bad);
-  }
-  ST(if (threadIdx.x == 0) atomicAdd(&g_bgzf_stats[2], (unsigned long long) (wall_clock64() - st_w1));)
-  if (__builtin_amdgcn_ballot_w64(bad != 0u)) return ~0u;
-  o += total;
-  ntok += mtotal;
-  return fx & X_POS;
 }
 
 // Walks one deflate stream: literals -> gout, matches -> tok[] (position | length << 16 | distance << 32).  Returns the
@@ -635,16 +592,13 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
       bool walked = false;
       if (LANES)
       {
-        const uint32_t r = uni(lanes_block(h, dc.in32, dc.end_dw, dc.end_bit, uni(dc.bitpos), gout, tok, out_cap, o, ntok));
+        uint32_t at = uni(dc.bitpos);
+        const uint32_t r = uni(lanes_block(h, dc.in32, dc.end_dw, dc.end_bit, at, gout, tok, out_cap, o, ntok));
         if (r == ~0u) return ~0u;
-        if (r != X_RETRY)
-        {
-          dc.bitpos = r;
-          o = uni(o);
-          ntok = uni(ntok);
-          walked = true;
-        }
-        ST(else ++st_slow;)
+        o = uni(o);
+        ntok = uni(ntok);
+        dc.bitpos = r != X_RETRY ? r : uni(at);
+        walked = r != X_RETRY;
       }
       // (the walks of the lanes did not agree within LANE_FULL_WALKS long passes: nothing was written, the rounds decode the block)
       while (!walked)
@@ -805,9 +759,10 @@ __device__ __forceinline__ uint32_t decode_wave(const uint8_t *file, uint64_t in
       if (lane == 0)
       {
         atomicAdd(&g_bgzf_stats[1], (unsigned long long) st_rounds);
-        if (!LANES) atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
-        atomicAdd(&g_bgzf_stats[5], LANES ? (unsigned long long) st_slow << 32 : (unsigned long long) st_slow);
-        if (LANES) atomicMax(&g_bgzf_stats[6], (unsigned long long) (wall_clock64() - st_t0)); else atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
+        atomicAdd(&g_bgzf_stats[2], (unsigned long long) ntok);
+        atomicAdd(&g_bgzf_stats[5], (unsigned long long) st_slow);
+        atomicAdd(&g_bgzf_stats[6], (unsigned long long) st_dyn);
+        atomicMax(&g_lane_stats[7], (unsigned long long) (wall_clock64() - st_t0));
         atomicAdd(&g_bgzf_stats[0], (unsigned long long) st_ll | ((unsigned long long) st_fix << 32));
         atomicAdd(&g_bgzf_stats[4], (unsigned long long) st_dlong);
         atomicAdd(&g_bgzf_stats[3], (unsigned long long) st_tb);
@@ -997,8 +952,11 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bgzf_stats), 64));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bgzf_stats), z, 64));
-    fprintf(stderr, "[bgzf raw] lanes decoder: walk passes %.1f us, write pass %.1f us, tables %.1f us, whole %.1f us per block; %.1f steps, %.1f passes per block; slowest block %.1f us, most walking passes of a Huffman block %.0f, %llu Huffman blocks left to the rounds\n", h[0] * 0.01 / nblk, h[2] * 0.01 / nblk,
-            h[3] * 0.01 / nblk, h[7] * 0.01 / nblk, (double) h[1] / nblk, (double) (h[5] & 0xFFFFFFFFull) / nblk, h[6] * 0.01, (double) h[4], h[5] >> 32);
+    unsigned long long l[8];
+    HIP_CHECK(hipMemcpyFromSymbol(l, HIP_SYMBOL(g_lane_stats), 64));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), z, 64));
+    fprintf(stderr, "[bgzf lanes] per block: %.1f us in counting walks, %.1f us in writing walks, %.1f us in table builds, %.1f us in all (slowest block %.1f us); %.1f steps, %.2f windows, %.2f passes; %llu long passes after a window's first, %llu windows left to the rounds\n",
+            l[0] * 0.01 / nblk, l[2] * 0.01 / nblk, h[3] * 0.01 / nblk, h[7] * 0.01 / nblk, l[7] * 0.01, (double) l[1] / nblk, (double) l[3] / nblk, (double) l[5] / nblk, l[4], l[6]);
     fprintf(stderr, "[bgzf] %u blocks: %llu long-code fix-ups, %llu rounds, %llu symbols on the scalar path (%llu long literal/length codes, %llu long distance codes), %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[0] >> 32, h[1],
             h[5], h[0] & 0xFFFFFFFFull, h[4], h[2], h[6], h[3] * 0.01 / nblk, h[7] * 0.01 / nblk);
   }
