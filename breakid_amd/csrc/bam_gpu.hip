@@ -600,6 +600,13 @@ struct StageCache
     std::lock_guard<std::mutex> g(mu);
     idle.emplace_back(p, bytes);
   }
+  int idle_of(uint64_t bytes)
+  {
+    std::lock_guard<std::mutex> g(mu);
+    int n = 0;
+    for (auto &e : idle) n += e.second == bytes;
+    return n;
+  }
 };
 StageCache &stage_cache()
 {
@@ -610,7 +617,7 @@ StageCache &stage_cache()
 struct StagePool
 {
   static constexpr int NB = 3;
-  static constexpr uint64_t FIRST = 3;  // chunks before this one are copied from the mapping
+  static constexpr uint64_t FIRST = 3;  // a process's first file: chunks before this one are copied from the mapping
   static constexpr uint64_t SLACK = 65536 + 64;
   struct Buf
   {
@@ -618,7 +625,14 @@ struct StagePool
     int state = 0;  // 0 free, 1 filled (chunk), 2 in flight (ev recorded by the consumer)
     uint64_t chunk = 0, lo = 0, n = 0;
     hipEvent_t ev = nullptr;
+    // scan_lo < scan_hi: the producer has hopped over the headers of the blocks that start in the chunk (offsets relative to
+    // the chunk), total = their inflated bytes (aligned), rel_end = where the first block of the next chunk starts
+    bool scanned = false;
+    std::vector<BgzfBlock> blocks;
+    uint64_t total = 0, rel_end = 0;
   };
+  uint64_t first = FIRST;        // chunks before first_k + first come from the mapping (0 once the process has its staging buffers)
+  uint64_t scan_off = 0, scan_hi = 0;  // first == 0: the producer follows the chain of block headers from scan_off to scan_hi
   Buf buf[NB];
   const uint8_t *file;
   int fd;  // >= 0: the staging threads read() the file (page cache -> buffer, no page tables to fill and to tear down again)
@@ -626,15 +640,24 @@ struct StagePool
   int threads, device;
   std::mutex mu;
   std::condition_variable cv;
-  std::thread producer;
+  std::thread producer, scanner;
   bool stop = false;
   std::string error;
 
-  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev, uint64_t k_first, uint64_t k_end)
+  // b_lo .. b_hi: the block starts the caller decodes (b_hi = 0: the caller hops over the headers itself)
+  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev, uint64_t k_first, uint64_t k_end, uint64_t b_lo = 0, uint64_t b_hi = 0)
       : file(f), fd(fd_), size(n), chunk_bytes(cb), first_k(k_first), nchunks(k_end), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
   {
     for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
-    if (nchunks > first_k + FIRST) producer = std::thread([this] { run(); });
+    // the staging buffers of an earlier file are at hand: every chunk goes through them (a plain DMA each, no pageable copy on
+    // the driver thread), and the producer hops over the block headers of a chunk as soon as it has read it
+    if (b_hi && !getenv("BREAKID_FEED_FIRST_FROM_MAPPING") && stage_cache().idle_of(buf_bytes) >= NB)
+    {
+      first = 0;
+      scan_off = b_lo;
+      scan_hi = b_hi;
+    }
+    if (nchunks > first_k + first) producer = std::thread([this] { run(); });
   }
   ~StagePool() { shutdown(); }
   void shutdown()
@@ -657,8 +680,13 @@ struct StagePool
   }
   void run()
   {
+    run_chunks();
+    if (scanner.joinable()) scanner.join();
+  }
+  void run_chunks()
+  {
     (void) hipSetDevice(device);
-    for (uint64_t k = first_k + FIRST; k < nchunks; ++k)
+    for (uint64_t k = first_k + first; k < nchunks; ++k)
     {
       Buf &b = buf[k % NB];
       {
@@ -715,15 +743,42 @@ struct StagePool
         cv.notify_all();
         return;
       }
+      // the header hops of this chunk (a serial chain over its ~1100 blocks, 0.25 ms) run beside the reads of the next one
+      if (scanner.joinable()) scanner.join();
       {
         std::lock_guard<std::mutex> g(mu);
-        b.chunk = k;
-        b.lo = lo;
-        b.n = n;
-        b.state = 1;
+        if (!error.empty()) return;
       }
-      cv.notify_all();
+      scanner = std::thread([this, &b, k, lo, n] {
+        b.scanned = false;
+        if (scan_hi)
+        {
+          b.blocks.clear();
+          b.total = 0;
+          uint64_t rel = scan_off - lo;
+          std::string why;
+          if (rel < chunk_bytes && scan_off < scan_hi && !bgzf_scan_range(b.p, n, rel, std::min(chunk_bytes - rel, scan_hi - scan_off), b.blocks, b.total, why))
+          {
+            std::lock_guard<std::mutex> g(mu);
+            error = "c" + why;  // ('c': an input error, see get())
+            cv.notify_all();
+            return;
+          }
+          scan_off = lo + rel;
+          b.rel_end = rel;
+          b.scanned = true;
+        }
+        {
+          std::lock_guard<std::mutex> g(mu);
+          b.chunk = k;
+          b.lo = lo;
+          b.n = n;
+          b.state = 1;
+        }
+        cv.notify_all();
+      });
     }
+    if (scanner.joinable()) scanner.join();
   }
   // chunk k >= FIRST: blocks until it is staged
   Buf &get(uint64_t k)
@@ -731,7 +786,7 @@ struct StagePool
     Buf &b = buf[k % NB];
     std::unique_lock<std::mutex> g(mu);
     cv.wait(g, [&] { return !error.empty() || (b.state == 1 && b.chunk == k); });
-    if (!error.empty()) throw bk_error(error[0] == 'c' ? BK_ERR_IO : BK_ERR_LIMIT, error);
+    if (!error.empty()) throw bk_error(error[0] == 'c' ? BK_ERR_IO : BK_ERR_LIMIT, error[0] == 'c' && error.compare(0, 6, "cannot") != 0 ? error.substr(1) : error);
     return b;
   }
   // the consumer has queued its copy out of b on st
@@ -836,6 +891,37 @@ struct FeedSlot
     if (tot) (void) hipHostFree(tot);
   }
 };
+// The slots of a finished decode (streams, events, device buffers of the chunk size) stay with the process for the next file
+// of the device: freeing and allocating them costs 7-9 ms per file.  A decode that failed drops its slots.
+struct SlotCache
+{
+  std::mutex mu;
+  std::vector<std::pair<int, std::unique_ptr<FeedSlot>>> idle;
+  std::unique_ptr<FeedSlot> take(int device)
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (size_t i = 0; i < idle.size(); ++i)
+      if (idle[i].first == device)
+      {
+        std::unique_ptr<FeedSlot> r = std::move(idle[i].second);
+        idle.erase(idle.begin() + (long) i);
+        return r;
+      }
+    return std::unique_ptr<FeedSlot>(new FeedSlot());
+  }
+  void give(int device, std::unique_ptr<FeedSlot> s)
+  {
+    s->used = false;
+    s->blocks.clear();
+    std::lock_guard<std::mutex> g(mu);
+    if (idle.size() < 16) idle.emplace_back(device, std::move(s));
+  }
+};
+SlotCache &slot_cache()
+{
+  static SlotCache *c = new SlotCache();  // never destroyed: the buffers go with the process
+  return *c;
+}
 // buffer of at least `need` bytes that keeps its first `used` bytes (device-to-device copy when it moves)
 void grow_keep(DevBuf &b, size_t used, size_t need)
 {
@@ -897,15 +983,21 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     if (const char *e = getenv("BREAKID_FEED_LAG"))
       if (atoi(e) >= 1) LAG = atoi(e);
     LAG = std::min(LAG, NS - 1);
-    FeedSlot slot_store[NS_MAX];
-    FeedSlot *slot = slot_store;
+    std::unique_ptr<FeedSlot> slot_store[NS_MAX];
+    struct SlotRef  // slot[k] as before
+    {
+      std::unique_ptr<FeedSlot> *a;
+      FeedSlot &operator[](int k) const { return *a[k]; }
+    } slot = {slot_store};
+    const bool keep_slots = !getenv("BREAKID_FEED_NO_SLOT_CACHE");
     for (int k = 0; k < NS; ++k)
     {
+      slot_store[k] = keep_slots ? slot_cache().take(device) : std::unique_ptr<FeedSlot>(new FeedSlot());
       FeedSlot &s = slot[k];
-      HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-      HIP_CHECK(hipEventCreateWithFlags(&s.ev_count, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
-      HIP_CHECK(hipHostMalloc((void **) &s.tot, 4 * sizeof(uint64_t), hipHostMallocDefault));
+      if (!s.st) HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+      if (!s.ev_count) HIP_CHECK(hipEventCreateWithFlags(&s.ev_count, hipEventDisableTiming));
+      if (!s.ev_emit) HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
+      if (!s.tot) HIP_CHECK(hipHostMalloc((void **) &s.tot, 4 * sizeof(uint64_t), hipHostMallocDefault));
     }
     uint64_t first_in_off = 0;
     uint32_t hdr_first_off = 0, n_ref = 0;
@@ -922,7 +1014,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       b_hi = part + 1 < parts ? o : file.size();
     }
     const uint64_t k0 = b_lo / chunk_bytes, k1 = b_hi > b_lo ? (b_hi + chunk_bytes - 1) / chunk_bytes : k0;  // chunks k0 .. k1 - 1
-    StagePool pool(file.data(), stage_from_mapping ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, k0, k1);
+    StagePool pool(file.data(), stage_from_mapping ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, k0, k1, b_lo, b_hi);
     uint64_t off = b_lo, n_rec = 0, n_cig = 0, n_aux = 0, cap_rec = 0, cap_cig = 0, cap_aux = 0, nblk_all = 0, first_bytes = 0;
     double t_h2d = 0, t_alloc = 0, t_scan = 0, t_reserve = 0, t_stage_wait = 0, t_launch = 0, t_emit = 0, t_slot_wait = 0;
     const double t_setup_done = now_s2();
@@ -988,14 +1080,21 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       s.first_off = 0;
       const double ts00 = now_s2();
       t_slot_wait += ts00 - tsw;
-      StagePool::Buf *sb = k >= k0 + StagePool::FIRST ? &pool.get(k) : nullptr;
+      StagePool::Buf *sb = k >= k0 + pool.first ? &pool.get(k) : nullptr;
       const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
       const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
       const double ts0 = now_s2();
       t_stage_wait += ts0 - ts00;
       // the blocks that start inside [k C, (k + 1) C); offsets are relative to the start of the range
       uint64_t total = 0, rel = off - src_lo;
-      if (rel < chunk_bytes && off < b_hi && !bgzf_scan_range(fdata, src_n, rel, std::min(chunk_bytes - rel, b_hi - off), s.blocks, total, why)) throw bk_error(BK_ERR_IO, why);
+      if (sb && sb->scanned)
+      {
+        s.blocks.swap(sb->blocks);
+        total = sb->total;
+        rel = sb->rel_end;
+      }
+      else if (rel < chunk_bytes && off < b_hi && !bgzf_scan_range(fdata, src_n, rel, std::min(chunk_bytes - rel, b_hi - off), s.blocks, total, why))
+        throw bk_error(BK_ERR_IO, why);
       off = src_lo + rel;
       // blocks of the header hold no records; the first record's block starts at first_off
       while (s.first_blk < s.blocks.size() && src_lo + s.blocks[s.first_blk].in_off < first_in_off) ++s.first_blk;
@@ -1105,7 +1204,10 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     const double td0 = now_s2();
     pool.shutdown();
     for (int k = 0; k < NS; ++k)
-      for (DevBuf *b : {&slot[k].dfile, &slot[k].dblk, &slot[k].ddata, &slot[k].dslab, &slot[k].dcnt, &slot[k].dnr, &slot[k].dnc, &slot[k].dna, &slot[k].dscan, &slot[k].derr, &slot[k].dindex}) b->release();
+      if (keep_slots)
+        slot_cache().give(device, std::move(slot_store[k]));  // (every stream is idle: sync_all above)
+      else
+        for (DevBuf *b : {&slot[k].dfile, &slot[k].dblk, &slot[k].ddata, &slot[k].dslab, &slot[k].dcnt, &slot[k].dnr, &slot[k].dnc, &slot[k].dna, &slot[k].dscan, &slot[k].derr, &slot[k].dindex}) b->release();
     const double td2 = now_s2();
     if (getenv("BREAKID_FEED_STATS"))
       fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: setup %.3f s, waiting for a free slot %.3f s, waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, kernel launches %.3f s, waiting for chunk totals + column growth %.3f s, emit launches %.3f s, final sync %.3f s, teardown %.3f s)\n",
