@@ -249,6 +249,38 @@ def test_gpu_inflate_block_kinds_and_code_shapes():
         assert rc != 0 or n == len(texty)   # (a flipped bit may still be a valid stream of the same length)
 
 
+def test_gpu_inflate_streams_that_never_synchronise_and_corrupted_ones():
+    """The decoder walks 64 parts of a Huffman block from guessed bits and relies on the streams' self-synchronisation
+    (bgzf_gpu.hip, lanes_block); where every code has the same length a wrong guess stays wrong for ever and the block is
+    handed to the decoder that takes 64 bit positions per round.  Uniform random bytes without matches (8-bit codes only),
+    two-letter alphabets (1-bit codes: 1024 symbols per part), and both glued to ordinary text inside one BGZF block; then 80
+    corrupted copies of a file: an error or the right length, never a hang."""
+    rng = np.random.default_rng(11)
+    def huff(b):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+        return c.compress(b) + c.flush()
+    def dyn(b):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        return c.compress(b) + c.flush()
+    flat = rng.integers(0, 256, 0xFF00, dtype=np.uint8).tobytes()
+    two = rng.integers(0, 2, 0xFF00, dtype=np.uint8).tobytes()
+    text = (b"read_%08d\tchr7\t55249071\t60\t151M\t=\t55249300\t380\n" * 1200)[:30000]
+    for name, blks, fn in (("flat", [flat, flat[:1000], flat[:70]], huff), ("two", [two, two[:4097]], huff), ("glued", [text + flat[:20000] + two[:15000], flat[:5000] + text], dyn),
+                           ("glued-huff", [text[:20000] + flat[:20000] + text[:20000]], huff)):
+        raw = b"".join(blks)
+        rc, n, got, err = _gpu_inflate(_bgzf(blks, fn), len(raw))
+        assert rc == 0 and n == len(raw) and got == raw, (name, rc, err)
+    blks = [text + two[:9000], flat[:3000] + text[:20000], text]
+    raw = b"".join(blks)
+    data = _bgzf(blks, dyn)
+    for it in range(80):
+        bad = bytearray(data)
+        at = int(rng.integers(18, len(data) - 40))
+        bad[at] ^= int(rng.integers(1, 256))
+        rc, n, got, err = _gpu_inflate(bytes(bad), len(raw))
+        assert rc != 0 or n == len(raw), (it, at)
+
+
 def test_device_decode_in_chunks_equals_one_chunk():
     """the streaming feed (bk_bam_decode_device takes the file in chunks; three in flight) with chunks of a few blocks:
     same table, including the growth of the columns when the first chunk under-estimates the rest"""
