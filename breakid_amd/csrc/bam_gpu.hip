@@ -651,7 +651,7 @@ struct StagePool
     for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
     // the staging buffers of an earlier file are at hand: every chunk goes through them (a plain DMA each, no pageable copy on
     // the driver thread), and the producer hops over the block headers of a chunk as soon as it has read it
-    if (b_hi && !getenv("BREAKID_FEED_FIRST_FROM_MAPPING") && stage_cache().idle_of(buf_bytes) >= NB)
+    if (!getenv("BREAKID_FEED_FIRST_FROM_MAPPING") && stage_cache().idle_of(buf_bytes) >= NB)
     {
       first = 0;
       scan_off = b_lo;
@@ -1443,7 +1443,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
     s.total = 0;
     s.first_blk = 0;
     s.first_off = 0;
-    StagePool::Buf *sb = k >= StagePool::FIRST ? &pool.get(k) : nullptr;
+    StagePool::Buf *sb = k >= pool.first ? &pool.get(k) : nullptr;
     const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
     const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
     uint64_t rel = off - src_lo;  // offsets are relative to the start of the range from here on
