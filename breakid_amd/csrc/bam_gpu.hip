@@ -1,5 +1,6 @@
 // GPU feed: BGZF file image -> inflated stream -> columnar record table, all on the device (see bgzf_gpu.hip).
 #include "bk_common.h"
+#include <functional>
 #include "bgzf_gpu.h"
 #include "../../include/breakid_hip.h"
 #include <algorithm>
@@ -614,6 +615,69 @@ StageCache &stage_cache()
   return *c;
 }
 
+// The threads that copy a chunk of the file into its staging buffer: made once per process (a process with many mappings pays
+// ~0.1 ms per thread it starts; a file of 31 chunks used to start 250 of them), handed pieces of 1 MiB.
+struct CopyPool
+{
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> th;
+  std::function<void(uint64_t)> fn;
+  uint64_t n_items = 0, next = 0, done = 0, gen = 0;
+  void loop()
+  {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> g(mu);
+    for (;;)
+    {
+      cv_work.wait(g, [&] { return gen != seen; });
+      seen = gen;
+      while (next < n_items)
+      {
+        const uint64_t i = next++;
+        auto f = fn;
+        g.unlock();
+        f(i);
+        g.lock();
+        if (++done == n_items) cv_done.notify_all();
+      }
+    }
+  }
+  // f(0) .. f(n - 1) on `threads` threads (the caller is one of them); returns when all have run
+  std::mutex one_batch;  // feeds of several devices in one process take turns (the copies are bound by memory bandwidth anyway)
+  void run(uint64_t n, int threads, const std::function<void(uint64_t)> &f)
+  {
+    std::lock_guard<std::mutex> turn(one_batch);
+    std::unique_lock<std::mutex> g(mu);
+    while ((int) th.size() + 1 < threads)
+    {
+      th.emplace_back([this] { loop(); });
+      th.back().detach();  // the pool lives as long as the process
+    }
+    fn = f;
+    n_items = n;
+    next = 0;
+    done = 0;
+    ++gen;
+    cv_work.notify_all();
+    while (next < n_items)
+    {
+      const uint64_t i = next++;
+      g.unlock();
+      f(i);
+      g.lock();
+      ++done;
+    }
+    cv_done.wait(g, [&] { return done == n_items; });
+    n_items = 0;
+  }
+};
+CopyPool &copy_pool()
+{
+  static CopyPool *c = new CopyPool();
+  return *c;
+}
+
 struct StagePool
 {
   static constexpr int NB = 3;
@@ -710,8 +774,7 @@ struct StagePool
         cv.notify_all();
         return;
       }
-      std::vector<std::thread> ts;
-      const uint64_t per = ((n + threads - 1) / threads + 4095) / 4096 * 4096;
+      const uint64_t per = 1u << 20;
       std::atomic<bool> short_read{false};
       auto fetch = [&](uint64_t at, uint64_t len) {
         if (fd < 0)
@@ -732,10 +795,7 @@ struct StagePool
           got += (uint64_t) r;
         }
       };
-      for (int t = 1; t < threads; ++t)
-        if ((uint64_t) t * per < n) ts.emplace_back([&, t] { fetch(t * per, std::min(per, n - t * per)); });
-      fetch(0, std::min(per, n));
-      for (auto &t : ts) t.join();
+      copy_pool().run((n + per - 1) / per, threads, [&](uint64_t i) { fetch(i * per, std::min(per, n - i * per)); });
       if (short_read)
       {
         std::lock_guard<std::mutex> g(mu);

@@ -39,6 +39,7 @@ constexpr int LIT_FAST = 11, DIST_FAST = 9;
 // symbol statistics (build with -DBGZF_STATS, run with BK_BGZF_STATS=1); off by default
 #ifdef BGZF_STATS
 __device__ unsigned long long g_bgzf_stats[8];
+__device__ unsigned long long g_lane_stats2[4];  // steps with a long code, lanes with a long code, walking lanes over all steps
 __device__ unsigned long long g_lane_stats[8];  // walk clocks, steps, write clocks, windows, long passes after a window's first, passes, windows left to the rounds, slowest block
 #define ST(x) x
 #else
@@ -46,7 +47,11 @@ __device__ unsigned long long g_lane_stats[8];  // walk clocks, steps, write clo
 #endif
 constexpr uint32_t CHUNK_DW = 64;            // one dword per lane
 constexpr uint32_t WIN_DW = 3 * CHUNK_DW;    // input window: three chunks in LDS, the fourth on its way in a register
+#ifndef LANE_PART_BITS
 constexpr uint32_t LANE_STAGE_DW = 2120;
+#else
+constexpr uint32_t LANE_STAGE_DW = 64 * (LANE_PART_BITS / 32) + 4 + (64 * (LANE_PART_BITS / 32) + 4) / 32 + 4;
+#endif
 constexpr uint32_t RESOLVE_THREADS = 256;
 constexpr uint32_t RES_WIN = 16384;            // output positions whose parents are in LDS at a time (k_bgzf_resolve)
 
@@ -277,8 +282,12 @@ __device__ __forceinline__ uint32_t walk_code(uint32_t w, const uint16_t *ent, c
 // true entries move on by one lane per pass.  After LANE_FULL_WALKS passes that needed walks beyond the checkpoint the rest of
 // the block is left to the rounds, which do not depend on the data (X_RETRY: nothing of the window has been written by then).
 constexpr uint32_t X_EOB = 1u << 30, X_BAD = 1u << 31, X_NONE = 0xFFFFFFFFu, X_POS = (1u << 30) - 1u, X_RETRY = 0xFFFFFFFEu;
-constexpr uint32_t LANE_PART = 1024;   // bits of a lane's part: 32 dwords, one padded row of the staged window
-constexpr uint32_t LANE_CHECK = 384;   // bits from the start of a part to its checkpoint
+#ifndef LANE_PART_BITS
+#define LANE_PART_BITS 1024
+#define LANE_CHECK_BITS 384
+#endif
+constexpr uint32_t LANE_PART = LANE_PART_BITS;    // bits of a lane's part: a padded row of the staged window
+constexpr uint32_t LANE_CHECK = LANE_CHECK_BITS;  // bits from the start of a part to its checkpoint
 constexpr int LANE_FULL_WALKS = 8;     // per window; a long pass costs ~1/10 of the rounds over a window
 static_assert(LANE_STAGE_DW >= 64 * (LANE_PART / 32) + 4 + (64 * (LANE_PART / 32) + 4) / 32 + 1, "the staged window, the dwords a last code may reach into, one pad dword per row");
 // dword d of the window lives at d + d / 32: the lanes are 32 dwords apart, the pad spreads them over the banks
@@ -303,18 +312,19 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, uint
   uint32_t pos = k.pos, opos = k.opos, nm = k.nm, kstop = k.stop;
   uint32_t want = 0, len = 0;
   uint32_t act = (uint32_t) (run && !kstop && pos < until);
-  ST(uint32_t st_steps = 0;)
+  ST(uint32_t st_steps = 0; uint32_t st_long = 0; uint32_t st_long_lanes = 0; uint32_t st_lanes = 0;)
   if (__builtin_amdgcn_ballot_w64(act != 0u))
   {
     do
     {
-      ST(++st_steps;)
+      ST(++st_steps; st_lanes += (uint32_t) __popcll(__builtin_amdgcn_ballot_w64(act != 0u));)
       const uint32_t rel = pos - wbit0, d = rel >> 5;
       const uint32_t lo = h.stage[stage_at(d)], hi = h.stage[stage_at(d + 1u)];
       const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, rel & 31u);
       uint32_t e = tab[want ? (1u << LIT_FAST) | (w & ((1u << DIST_FAST) - 1u)) : (w & ((1u << LIT_FAST) - 1u))];
       if (__builtin_amdgcn_ballot_w64((e & 15u) == 0u && act))
       {
+        ST(++st_long; st_long_lanes += (uint32_t) __popcll(__builtin_amdgcn_ballot_w64((e & 15u) == 0u && act));)
         // codes longer than the direct table: the length from the canonical limits, then the symbol's entry
         if ((e & 15u) == 0u)
         {
@@ -348,9 +358,13 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, uint
         if (done_match)
         {
           if (val >= opos) bad = 1;  // distance = val + 1 beyond the start of the output
+#ifndef LANE_EXPERIMENT_NO_TOKENS
           tok[nm] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) (val + 1u) << 32);
+#endif
         }
+#ifndef LANE_EXPERIMENT_NO_LITERALS
         if (put_lit) gout[opos] = (uint8_t) val;
+#endif
       }
       opos += done_match ? len : put_lit;
       nm += done_match;
@@ -364,7 +378,7 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, uint
   k.opos = opos;
   k.nm = nm;
   k.stop = kstop;
-  ST(if (threadIdx.x == 0) atomicAdd(&g_lane_stats[1], (unsigned long long) st_steps);)
+  ST(if (threadIdx.x == 0) { atomicAdd(&g_lane_stats[1], (unsigned long long) st_steps); atomicAdd(&g_lane_stats2[0], (unsigned long long) st_long); atomicAdd(&g_lane_stats2[1], (unsigned long long) st_long_lanes); atomicAdd(&g_lane_stats2[2], (unsigned long long) st_lanes); })
 }
 
 // the Huffman block whose first code is at `bitpos` (tables built): literals and match tokens written, o / ntok advanced;
@@ -955,6 +969,11 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     unsigned long long l[8];
     HIP_CHECK(hipMemcpyFromSymbol(l, HIP_SYMBOL(g_lane_stats), 64));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), z, 64));
+    unsigned long long l2[4];
+    HIP_CHECK(hipMemcpyFromSymbol(l2, HIP_SYMBOL(g_lane_stats2), 32));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats2), z, 32));
+    fprintf(stderr, "[bgzf lanes] steps: %.1f %% with a code longer than the direct table (%.2f lanes of those steps), %.1f of 64 lanes walking on average\n", 100.0 * l2[0] / (l[1] ? l[1] : 1), (double) l2[1] / (l2[0] ? l2[0] : 1),
+            (double) l2[2] / (l[1] ? l[1] : 1));
     fprintf(stderr, "[bgzf lanes] per block: %.1f us in counting walks, %.1f us in writing walks, %.1f us in table builds, %.1f us in all (slowest block %.1f us); %.1f steps, %.2f windows, %.2f passes; %llu long passes after a window's first, %llu windows left to the rounds\n",
             l[0] * 0.01 / nblk, l[2] * 0.01 / nblk, h[3] * 0.01 / nblk, h[7] * 0.01 / nblk, l[7] * 0.01, (double) l[1] / nblk, (double) l[3] / nblk, (double) l[5] / nblk, l[4], l[6]);
     fprintf(stderr, "[bgzf] %u blocks: %llu long-code fix-ups, %llu rounds, %llu symbols on the scalar path (%llu long literal/length codes, %llu long distance codes), %llu matches, %llu Huffman blocks; per block %.1f us in table builds of %.1f us\n", nblk, h[0] >> 32, h[1],

@@ -61,3 +61,7 @@ with open(d + "ks_kernel_stats.csv") as fh:
         if "k_stream" in row["Name"]:
             print("k_stream rocprof avg %.3f ms; bench HIP-event avg %.3f ms; value %.1f; frac %.4f; traffic %d" % (
                 float(row["AverageNs"]) / 1e6, b["roofline"]["avg_launch_ms"], b["value"], b["roofline"]["frac"], j["traffic_bytes_per_launch"]))
+
+for src, dst in (("feedbench.log", "_feedbench_8M_records.log"), ("feed_kernel_stats.csv", "_feed_kernel_stats_8M_records.csv"), ("inflatebench.log", "_inflatebench_570MB.log")):
+    if os.path.exists(d + src):
+        shutil.copy(d + src, P + R + dst)
