@@ -704,6 +704,7 @@ struct StagePool
   int threads, device;
   std::mutex mu;
   std::condition_variable cv;
+  double t_wait_buf = 0, t_copy = 0, t_scan_join = 0;  // the producer's time: waiting for a free buffer, copying, waiting for the scan before
   std::thread producer, scanner;
   bool stop = false;
   std::string error;
@@ -753,6 +754,7 @@ struct StagePool
     for (uint64_t k = first_k + first; k < nchunks; ++k)
     {
       Buf &b = buf[k % NB];
+      const double tp0 = now_s2();
       {
         std::unique_lock<std::mutex> g(mu);
         cv.wait(g, [&] { return stop || b.state == 0 || b.state == 2; });
@@ -765,6 +767,8 @@ struct StagePool
           b.state = 0;
         }
       }
+      const double tp1 = now_s2();
+      t_wait_buf += tp1 - tp0;
       const uint64_t lo = k * chunk_bytes, n = std::min(size - lo, chunk_bytes + SLACK);
       if (!b.p) b.p = stage_cache().take(buf_bytes);
       if (!b.p)
@@ -796,6 +800,8 @@ struct StagePool
         }
       };
       copy_pool().run((n + per - 1) / per, threads, [&](uint64_t i) { fetch(i * per, std::min(per, n - i * per)); });
+      const double tp2 = now_s2();
+      t_copy += tp2 - tp1;
       if (short_read)
       {
         std::lock_guard<std::mutex> g(mu);
@@ -805,6 +811,7 @@ struct StagePool
       }
       // the header hops of this chunk (a serial chain over its ~1100 blocks, 0.25 ms) run beside the reads of the next one
       if (scanner.joinable()) scanner.join();
+      t_scan_join += now_s2() - tp2;
       {
         std::lock_guard<std::mutex> g(mu);
         if (!error.empty()) return;
@@ -1269,6 +1276,9 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       else
         for (DevBuf *b : {&slot[k].dfile, &slot[k].dblk, &slot[k].ddata, &slot[k].dslab, &slot[k].dcnt, &slot[k].dnr, &slot[k].dnc, &slot[k].dna, &slot[k].dscan, &slot[k].derr, &slot[k].dindex}) b->release();
     const double td2 = now_s2();
+    if (getenv("BREAKID_FEED_STATS"))
+      fprintf(stderr, "[feed/gpu] producer: %.3f s waiting for a free staging buffer, %.3f s copying (%d threads), %.3f s waiting for the header hops of the chunk before\n", pool.t_wait_buf, pool.t_copy, copy_threads,
+              pool.t_scan_join);
     if (getenv("BREAKID_FEED_STATS"))
       fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: setup %.3f s, waiting for a free slot %.3f s, waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, kernel launches %.3f s, waiting for chunk totals + column growth %.3f s, emit launches %.3f s, final sync %.3f s, teardown %.3f s)\n",
               (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_setup_done - t0, t_slot_wait, t_stage_wait, t_scan, t_alloc, t_h2d, t_launch, t_reserve, t_emit, t3 - t_end_loop, td2 - td0);

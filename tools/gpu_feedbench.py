@@ -53,6 +53,8 @@ def write_bam(path, n_pairs, seed=7, read_len=150, aligned=True):
             comp = c.compress(blk) + c.flush()
             f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(blk), len(blk)))
         f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+        f.flush()
+        os.fsync(f.fileno())  # a file at rest in the page cache: the timed reads do not run beside the write-back of a GB of dirty pages
     return n, len(raw), os.path.getsize(path)
 
 
