@@ -697,6 +697,7 @@ struct StagePool
   };
   uint64_t first = FIRST;        // chunks before first_k + first come from the mapping (0 once the process has its staging buffers)
   uint64_t scan_off = 0, scan_hi = 0;  // first == 0: the producer follows the chain of block headers from scan_off to scan_hi
+  uint64_t scan_align = BGZF_OUT_ALIGN;  // alignment of the blocks' places in the inflated stream (1: one contiguous stream)
   Buf buf[NB];
   const uint8_t *file;
   int fd;  // >= 0: the staging threads read() the file (page cache -> buffer, no page tables to fill and to tear down again)
@@ -710,9 +711,10 @@ struct StagePool
   std::string error;
 
   // b_lo .. b_hi: the block starts the caller decodes (b_hi = 0: the caller hops over the headers itself)
-  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev, uint64_t k_first, uint64_t k_end, uint64_t b_lo = 0, uint64_t b_hi = 0)
+  StagePool(const uint8_t *f, int fd_, uint64_t n, uint64_t cb, int th, int dev, uint64_t k_first, uint64_t k_end, uint64_t b_lo = 0, uint64_t b_hi = 0, uint64_t align = BGZF_OUT_ALIGN)
       : file(f), fd(fd_), size(n), chunk_bytes(cb), first_k(k_first), nchunks(k_end), buf_bytes((cb + SLACK + 4095) / 4096 * 4096), threads(th), device(dev)
   {
+    scan_align = align;
     for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
     // the staging buffers of an earlier file are at hand: every chunk goes through them (a plain DMA each, no pageable copy on
     // the driver thread), and the producer hops over the block headers of a chunk as soon as it has read it
@@ -824,7 +826,7 @@ struct StagePool
           b.total = 0;
           uint64_t rel = scan_off - lo;
           std::string why;
-          if (rel < chunk_bytes && scan_off < scan_hi && !bgzf_scan_range(b.p, n, rel, std::min(chunk_bytes - rel, scan_hi - scan_off), b.blocks, b.total, why))
+          if (rel < chunk_bytes && scan_off < scan_hi && !bgzf_scan_range(b.p, n, rel, std::min(chunk_bytes - rel, scan_hi - scan_off), b.blocks, b.total, why, scan_align))
           {
             std::lock_guard<std::mutex> g(mu);
             error = "c" + why;  // ('c': an input error, see get())
@@ -960,23 +962,23 @@ struct FeedSlot
 };
 // The slots of a finished decode (streams, events, device buffers of the chunk size) stay with the process for the next file
 // of the device: freeing and allocating them costs 7-9 ms per file.  A decode that failed drops its slots.
-struct SlotCache
+template <class Slot> struct SlotCacheOf
 {
   std::mutex mu;
-  std::vector<std::pair<int, std::unique_ptr<FeedSlot>>> idle;
-  std::unique_ptr<FeedSlot> take(int device)
+  std::vector<std::pair<int, std::unique_ptr<Slot>>> idle;
+  std::unique_ptr<Slot> take(int device)
   {
     std::lock_guard<std::mutex> g(mu);
     for (size_t i = 0; i < idle.size(); ++i)
       if (idle[i].first == device)
       {
-        std::unique_ptr<FeedSlot> r = std::move(idle[i].second);
+        std::unique_ptr<Slot> r = std::move(idle[i].second);
         idle.erase(idle.begin() + (long) i);
         return r;
       }
-    return std::unique_ptr<FeedSlot>(new FeedSlot());
+    return std::unique_ptr<Slot>(new Slot());
   }
-  void give(int device, std::unique_ptr<FeedSlot> s)
+  void give(int device, std::unique_ptr<Slot> s)
   {
     s->used = false;
     s->blocks.clear();
@@ -984,6 +986,7 @@ struct SlotCache
     if (idle.size() < 16) idle.emplace_back(device, std::move(s));
   }
 };
+typedef SlotCacheOf<FeedSlot> SlotCache;
 SlotCache &slot_cache()
 {
   static SlotCache *c = new SlotCache();  // never destroyed: the buffers go with the process
@@ -1473,13 +1476,27 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
     if (atof(e) > 0) chunk_bytes = (uint64_t) (atof(e) * 1048576.0);
   chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000) / 4096 * 4096 + 4096;  // a chunk is longer than the longest block
   // the inflates run LAG chunks ahead of the record phases (which follow each other: a chunk starts with the carry of the one before)
-  constexpr int NS = 4, LAG = 2;
-  PackedSlot slot[NS];
-  for (auto &s : slot)
+  constexpr int NS_MAX = 8;
+  int NS = 4, LAG = 2;
+  if (const char *e = getenv("BREAKID_FEED_PACKED_SLOTS"))
+    if (atoi(e) >= 2 && atoi(e) <= NS_MAX) NS = atoi(e);
+  if (const char *e = getenv("BREAKID_FEED_PACKED_LAG"))
+    if (atoi(e) >= 1) LAG = atoi(e);
+  LAG = std::min(LAG, NS - 1);
+  static SlotCacheOf<PackedSlot> *packed_cache = new SlotCacheOf<PackedSlot>();  // as slot_cache(): a finished decode leaves its slots to the next file
+  const bool keep_slots = !getenv("BREAKID_FEED_NO_SLOT_CACHE");
+  struct SlotSet
   {
-    HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
-    HIP_CHECK(hipHostMalloc((void **) &s.tot, 8 * sizeof(uint64_t), hipHostMallocDefault));
+    std::unique_ptr<PackedSlot> p[NS_MAX];
+    PackedSlot &operator[](size_t k) { return *p[k]; }
+  } slot;
+  for (int k = 0; k < NS; ++k)
+  {
+    slot.p[k] = keep_slots ? packed_cache->take(device) : std::unique_ptr<PackedSlot>(new PackedSlot());
+    PackedSlot &s = slot[k];
+    if (!s.st) HIP_CHECK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    if (!s.ev_emit) HIP_CHECK(hipEventCreateWithFlags(&s.ev_emit, hipEventDisableTiming));
+    if (!s.tot) HIP_CHECK(hipHostMalloc((void **) &s.tot, 8 * sizeof(uint64_t), hipHostMallocDefault));
   }
   hipEvent_t ev_carry;
   HIP_CHECK(hipEventCreateWithFlags(&ev_carry, hipEventDisableTiming));
@@ -1495,8 +1512,9 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   parse_bam_header_of_file(file.data(), file.size(), h, n_ref, first_in_off, hdr_first_off);
   ColumnSink sink{h};
   std::string why;
+  double t_stage = 0, t_records = 0, t_sync = 0;
   auto quiesce = [&]() {
-    for (auto &s : slot) HIP_CHECK(hipStreamSynchronize(s.st));
+    for (int k = 0; k < NS; ++k) HIP_CHECK(hipStreamSynchronize(slot[k].st));
   };
   int copy_threads = 8;
   if (const char *e = getenv("BREAKID_THREADS"))
@@ -1504,7 +1522,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   // the bytes of chunk k = file range [k C, (k + 1) C + slack) arrive in page-locked staging buffers, read() by the pool's threads
   // (the first three straight from the mapping while the buffers are being registered) - as in the aligned case
   const uint64_t nchunks = (file.size() + chunk_bytes - 1) / chunk_bytes;
-  StagePool pool(file.data(), getenv("BREAKID_FEED_STAGE_MMAP") ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, 0, nchunks);
+  StagePool pool(file.data(), getenv("BREAKID_FEED_STAGE_MMAP") ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, 0, nchunks, 0, file.size(), 1);
   // chunk k -> slot: the blocks that start inside it: hop over their headers in the staged bytes, copy, inflate behind the reserve
   auto stage = [&](PackedSlot &s, uint64_t k) {
     if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
@@ -1517,7 +1535,14 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
     const uint64_t src_lo = k * chunk_bytes, src_n = std::min<uint64_t>(file.size() - src_lo, chunk_bytes + StagePool::SLACK);
     const uint8_t *fdata = sb ? sb->p : file.data() + src_lo;
     uint64_t rel = off - src_lo;  // offsets are relative to the start of the range from here on
-    if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, s.total, why, 1)) throw bk_error(BK_ERR_IO, why);
+    if (sb && sb->scanned)
+    {
+      s.blocks.swap(sb->blocks);
+      s.total = sb->total;
+      rel = sb->rel_end;
+    }
+    else if (rel < chunk_bytes && !bgzf_scan_range(fdata, src_n, rel, chunk_bytes - rel, s.blocks, s.total, why, 1))
+      throw bk_error(BK_ERR_IO, why);
     off = src_lo + rel;
     const uint32_t nb = (uint32_t) s.blocks.size();
     nblk_all += nb;
@@ -1585,7 +1610,9 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
     HIP_CHECK(hipMemcpyAsync(&s.tot[2], na + nb, 8, hipMemcpyDeviceToHost, s.st));
     HIP_CHECK(hipMemcpyAsync(&s.tot[3], de, 4, hipMemcpyDeviceToHost, s.st));
     HIP_CHECK(hipMemcpyAsync(&s.tot[4], tail, 8, hipMemcpyDeviceToHost, s.st));
+    const double tsy = now_s2();
     HIP_CHECK(hipStreamSynchronize(s.st));
+    t_sync += now_s2() - tsy;
     if (s.tot[3] & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
     if (s.tot[3] & 2u) throw bk_error(BK_ERR_IO, "corrupt BAM record");
     if (s.tot[3] & 4u) throw bk_error(BK_ERR_IO, "the record boundaries of this BAM could not be established on the GPU: use the host decoder");
@@ -1615,20 +1642,29 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   };
   // the inflates of chunks c + 1 .. c + LAG are queued before the host waits for the totals of chunk c
   nchunk = nchunks;
+  const double t_loop0 = now_s2();
   for (uint64_t k = 0; k < nchunks + LAG; ++k)
   {
+    const double ta = now_s2();
     if (k < nchunks) stage(slot[k % NS], k);
+    const double tb = now_s2();
+    t_stage += tb - ta;
     // (the last chunk with blocks is the one whose hop reached the end of the file: chunks behind it hold no block start)
     if (k >= (uint64_t) LAG) records(slot[(k - LAG) % NS], slot[(k - LAG) % NS].file_hi == file.size());
+    t_records += now_s2() - tb;
   }
+  const double t_loop1 = now_s2();
   if (off != file.size()) throw bk_error(BK_ERR_IO, "BGZF blocks do not end at the end of the file");
   if (carry_len) throw bk_error(BK_ERR_IO, "truncated BAM record at the end of the file");
   sink.reserve(sink.n_rec, sink.n_cig, sink.n_aux, quiesce);
   quiesce();
   sink.finish(cols);
+  pool.shutdown();
+  if (keep_slots)
+    for (int k = 0; k < NS; ++k) packed_cache->give(device, std::move(slot.p[k]));  // (every stream is idle: quiesce above)
   if (getenv("BREAKID_FEED_STATS"))
-    fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks, records across blocks (boundaries guessed and verified per chunk): file -> device table %.3f s\n",
-            (unsigned long long) sink.n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, now_s2() - t0);
+    fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks, records across blocks (boundaries guessed and verified per chunk): file -> device table %.3f s (driver thread: before the loop %.3f s, staging calls %.3f s, record phases %.3f s of which waiting for the chunk's totals %.3f s, after the loop %.3f s)\n",
+            (unsigned long long) sink.n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, now_s2() - t0, t_loop0 - t0, t_stage, t_records, t_sync, now_s2() - t_loop1);
 }
 
 // Does the first block of records end with a record?  (htslib never lets a record leave its block, htsjdk does; the
