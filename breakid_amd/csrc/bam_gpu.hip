@@ -586,6 +586,13 @@ struct StageCache
           return p;
         }
     }
+    if (getenv("BREAKID_FEED_STAGE_HOSTMALLOC"))  // (comparison: the runtime's own page-locked allocation)
+    {
+      void *q = nullptr;
+      if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+      memset(q, 0, bytes);
+      return (uint8_t *) q;
+    }
     uint8_t *p = (uint8_t *) aligned_alloc(2u << 20, (bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20));
     if (!p) return nullptr;
     (void) madvise(p, bytes, MADV_HUGEPAGE);  // fewer first-touch faults and a shorter registration where the kernel allows it
@@ -1044,6 +1051,8 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     int copy_threads = 8;
     if (const char *e = getenv("BREAKID_THREADS"))
       if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
+    if (const char *e = getenv("BREAKID_FEED_COPY_THREADS"))
+      if (atoi(e) > 0) copy_threads = std::min(atoi(e), 32);
     const bool stage_from_mapping = getenv("BREAKID_FEED_STAGE_MMAP") != nullptr;  // the staging threads copy out of the mapping (comparison)
     // chunks in flight; how far the driver thread runs ahead of the totals it waits for (a slot is reused LAG + 1 .. NS chunks later)
     constexpr int NS_MAX = 12;

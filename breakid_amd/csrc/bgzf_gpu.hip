@@ -52,6 +52,9 @@ constexpr uint32_t LANE_STAGE_DW = 2120;
 #else
 constexpr uint32_t LANE_STAGE_DW = 64 * (LANE_PART_BITS / 32) + 4 + (64 * (LANE_PART_BITS / 32) + 4) / 32 + 4;
 #endif
+#ifndef BGZF_SHARED_WAVES
+#define BGZF_SHARED_WAVES 4  // waves per SIMD of the lanes decoder inside the streaming feed (its 15.5 KiB of LDS allow 10 waves per CU; 2 or 3 per SIMD measured the same: tools/gpu_lane_variants2.sh)
+#endif
 constexpr uint32_t RESOLVE_THREADS = 256;
 constexpr uint32_t RES_WIN = 16384;            // output positions whose parents are in LDS at a time (k_bgzf_resolve)
 
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode(const uint8_t *__restrict__ 
 // on every CU - room for a resolve block; without the cap the decoders fill the LDS (22 x 7 KiB) and the resolve blocks of
 // a chunk wait until the other chunks' decoders have drained.
 template <int LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, LANES ? BGZF_SHARED_WAVES : 4))) void k_bgzf_decode_shared(const uint8_t *__restrict__ file, const BgzfBlock *__restrict__ blk, uint32_t first,
                                                                                                       uint32_t nblk, uint8_t *__restrict__ out, unsigned long long *__restrict__ slab,
                                                                                                       uint32_t *__restrict__ ntok, uint32_t *__restrict__ err)
 {
