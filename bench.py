@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 def from_bam_side_line(n_pairs, device, fast):
     """File -> calls, end to end (SURVEY 8(f2/f3)): the metric of the headline line is defined on the resident table; this is
-    what a user of the command line sees.  Three timings of the same block-aligned BAM (page cache warm, best of 3): the GPU feed
+    what a user of the command line sees.  Three timings of the same block-aligned BAM (page cache warm, best of 5): the GPU feed
     alone (file -> device table), the feed with the stream pass overlapped (file -> table + candidates + sums), and the rest
     of the hot path on the resident table."""
     import torch
@@ -41,7 +41,7 @@ def from_bam_side_line(n_pairs, device, fast):
     path = "/tmp/bench_from_bam_%d.bam" % n_pairs
     n, raw, comp = gpu_feedbench.write_bam(path, n_pairs)
     feed, over, rest, total = [], [], [], []
-    for rep in range(3):
+    for rep in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         table = capi.decode_bam_device(path, device)
