@@ -1103,10 +1103,20 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       for (int k = 0; k < NS; ++k) HIP_CHECK(hipStreamSynchronize(slot[k].st));
     };
     // columns for at least (r, g, a) records / CIGAR words / aux bytes; the emits in flight finish before a buffer moves
+    double t_grow = 0, t_grow_sync = 0;
     auto reserve = [&](uint64_t r, uint64_t g, uint64_t a) {
       if (r <= cap_rec && g <= cap_cig && a <= cap_aux) return;
-      sync_all();
-      if (fc && fc->before_move) fc->before_move(fc->user);
+      const double tg0 = now_s2();
+      // (the first allocation moves nothing: no emit has been launched yet, the chunks in flight go on)
+      const bool moves = cap_rec || cap_cig || cap_aux;
+      if (moves) sync_all();
+      t_grow_sync += now_s2() - tg0;
+      struct GrowTimer
+      {
+        double &acc, t0;
+        ~GrowTimer() { acc += now_s2() - t0; }
+      } grow_timer{t_grow, tg0};
+      if (moves && fc && fc->before_move) fc->before_move(fc->user);
       if (r > cap_rec)
       {
         const uint64_t nc = std::max(r, cap_rec + cap_rec / 2) + 1024;
@@ -1289,6 +1299,8 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
         for (DevBuf *b : {&slot[k].dfile, &slot[k].dblk, &slot[k].ddata, &slot[k].dslab, &slot[k].dcnt, &slot[k].dnr, &slot[k].dnc, &slot[k].dna, &slot[k].dscan, &slot[k].derr, &slot[k].dindex}) b->release();
     const double td2 = now_s2();
     if (getenv("BREAKID_FEED_STATS"))
+      fprintf(stderr, "[feed/gpu] columns: %.3f s allocating / growing them, of which %.3f s waiting for the chunks in flight first\n", t_grow, t_grow_sync);
+    if (getenv("BREAKID_FEED_STATS"))
       fprintf(stderr, "[feed/gpu] producer: %.3f s waiting for a free staging buffer, %.3f s copying (%d threads), %.3f s waiting for the header hops of the chunk before\n", pool.t_wait_buf, pool.t_copy, copy_threads,
               pool.t_scan_join);
     if (getenv("BREAKID_FEED_STATS"))
@@ -1397,7 +1409,7 @@ struct ColumnSink
   template <class F> void reserve(uint64_t r, uint64_t g, uint64_t a, F quiesce)
   {
     if (r <= cap_rec && g <= cap_cig && a <= cap_aux) return;
-    quiesce();
+    if (cap_rec || cap_cig || cap_aux) quiesce();  // (the first allocation moves nothing: no kernel writes the columns yet)
     if (r > cap_rec)
     {
       const uint64_t nc = std::max(r, cap_rec + cap_rec / 2) + 1024;
