@@ -122,7 +122,7 @@ if __name__ == "__main__":
     # the same records in fixed-size blocks (records across BGZF blocks, as htsjdk / Picard write them): one-batch variant
     path2 = "/tmp/feed_%d_across.bam" % n_pairs
     n2, raw2, comp2 = write_bam(path2, n_pairs, aligned=False)
-    for rep in range(3):
+    for rep in range(6):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         table = capi.decode_bam_device(path2)
