@@ -1,11 +1,16 @@
-// BGZF inflate on the GPU (RFC 1951 DEFLATE) in two kernels.
+// BGZF inflate on the GPU (RFC 1951 DEFLATE) in two kernels (decode, resolve).
 //
 // the host decoder is the feed limit (all cores of the box: ~3.6 GB/s of inflated BAM).  BGZF blocks are
 // independent <= 64 KiB deflate streams, so a file is thousands to millions of independent jobs, but inside a block
 // the Huffman decode is one serial chain (a code's position depends on every code before it) and the LZ77 copies
 // depend on earlier output.  The two dependences are separated:
 //
-//  k_bgzf_decode   one wavefront per block walks the bit stream, 64 bit positions per round.  Lane k decodes the
+//  k_bgzf_decode<1>  one wavefront per block; the 64 lanes WALK 64 parts of a Huffman block symbol by symbol, each from a
+//                  guessed bit, and the entries are made true by handing every lane its neighbour's exit (Huffman streams
+//                  synchronise) - "one Huffman block, every lane walking its own part" below.  Literals and match tokens
+//                  as in <0>; a block whose parts do not synchronise is finished by the rounds of <0>.
+//  k_bgzf_decode<0>  (rounds 1-2; BK_BGZF_ROUNDS=1, and the fallback of <1>)
+//                  one wavefront per block walks the bit stream, 64 bit positions per round.  Lane k decodes the
 //                  symbol that WOULD start at bit k of the unread input - literal/length code from a 10-bit direct
 //                  table whose entries carry the pre-computed base value and extra-bit count, the length's extra
 //                  bits, the distance code (8-bit direct table) and its extra bits - and so knows where the next
@@ -361,13 +366,9 @@ __device__ __forceinline__ void lane_segment(LaneWalk &k, const HuffLds &h, uint
         if (done_match)
         {
           if (val >= opos) bad = 1;  // distance = val + 1 beyond the start of the output
-#ifndef LANE_EXPERIMENT_NO_TOKENS
           tok[nm] = (unsigned long long) opos | ((unsigned long long) len << 16) | ((unsigned long long) (val + 1u) << 32);
-#endif
         }
-#ifndef LANE_EXPERIMENT_NO_LITERALS
         if (put_lit) gout[opos] = (uint8_t) val;
-#endif
       }
       opos += done_match ? len : put_lit;
       nm += done_match;
