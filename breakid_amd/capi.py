@@ -40,7 +40,7 @@ def build(verbose=False):
 EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_get_stream", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_timing_touched", "bk_group_stats", "bk_qname_hash", "bk_qname_check",
-           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_decode_device_part", "bk_bam_decode_device_ctx", "bk_bam_dev_free", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
+           "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_decode_device_part", "bk_bam_decode_device_ctx", "bk_bam_dev_free", "bk_feed_release_caches", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",
            "bk_shard_sd_local", "bk_shard_sd_finish", "bk_shard_buffer", "bk_shard_set_buffer", "bk_shard_group_sizes",
            "bk_shard_own_groups", "bk_shard_route_candidates", "bk_shard_group_keys", "bk_shard_route_pairs", "bk_shard_group_pairs", "bk_shard_bp_cov", "bk_shard_bp_vote", "bk_shard_bp_vote_slice", "bk_shard_bp_set_voted", "bk_shard_bp_depth", "bk_shard_bp_finish"]
 
@@ -117,6 +117,8 @@ def lib():
         L.bk_bam_decode_device_part.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(abi.Soa), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)),
                                            C.POINTER(C.POINTER(C.c_uint32)), C.c_char_p, C.c_size_t]
         L.bk_bam_dev_free.argtypes = [vp]
+        L.bk_feed_release_caches.argtypes = []
+        L.bk_feed_release_caches.restype = None
         L.bk_bam_decode_device_ctx.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char_p)),
                                                C.POINTER(C.POINTER(C.c_uint32)), C.c_char_p, C.c_size_t]
         L.bk_debug_bgzf_inflate.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.c_char_p, C.c_size_t]

@@ -608,6 +608,19 @@ struct StageCache
     std::lock_guard<std::mutex> g(mu);
     idle.emplace_back(p, bytes);
   }
+  void release_all()
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto &e : idle)
+      if (getenv("BREAKID_FEED_STAGE_HOSTMALLOC"))
+        (void) hipHostFree(e.first);
+      else
+      {
+        (void) hipHostUnregister(e.first);
+        free(e.first);
+      }
+    idle.clear();
+  }
   int idle_of(uint64_t bytes)
   {
     std::lock_guard<std::mutex> g(mu);
@@ -984,6 +997,19 @@ template <class Slot> struct SlotCacheOf
         return r;
       }
     return std::unique_ptr<Slot>(new Slot());
+  }
+  void release_all()
+  {
+    std::vector<std::pair<int, std::unique_ptr<Slot>>> gone;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      gone.swap(idle);
+    }
+    for (auto &e : gone)
+    {
+      (void) hipSetDevice(e.first);
+      e.second.reset();  // the slot's buffers, stream and events
+    }
   }
   void give(int device, std::unique_ptr<Slot> s)
   {
@@ -1488,6 +1514,22 @@ struct PackedSlot
   }
 };
 
+static SlotCacheOf<PackedSlot> &packed_slot_cache()
+{
+  static SlotCacheOf<PackedSlot> *c = new SlotCacheOf<PackedSlot>();  // never destroyed: the buffers go with the process
+  return *c;
+}
+
+extern "C" void bk_feed_release_caches(void)
+{
+  int dev = 0;
+  const bool have = hipGetDevice(&dev) == hipSuccess;
+  slot_cache().release_all();
+  packed_slot_cache().release_all();
+  stage_cache().release_all();
+  if (have) (void) hipSetDevice(dev);
+}
+
 static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols)
 {
   (void) device;
@@ -1504,7 +1546,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   if (const char *e = getenv("BREAKID_FEED_PACKED_LAG"))
     if (atoi(e) >= 1) LAG = atoi(e);
   LAG = std::min(LAG, NS - 1);
-  static SlotCacheOf<PackedSlot> *packed_cache = new SlotCacheOf<PackedSlot>();  // as slot_cache(): a finished decode leaves its slots to the next file
+  SlotCacheOf<PackedSlot> *packed_cache = &packed_slot_cache();  // as slot_cache(): a finished decode leaves its slots to the next file
   const bool keep_slots = !getenv("BREAKID_FEED_NO_SLOT_CACHE");
   struct SlotSet
   {

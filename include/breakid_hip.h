@@ -302,6 +302,11 @@ int bk_bam_decode_device(const char *path, int device, bk_bam_dev **out, bk_soa 
 int bk_bam_decode_device_part(const char *path, int device, int part, int parts, bk_bam_dev **out, bk_soa *cols, int *n_targets, const char *const **names,
                               const uint32_t **lens, char *err, size_t errlen);
 void bk_bam_dev_free(bk_bam_dev *h);
+/* What the GPU feed keeps between files so that the second file of a process starts at full speed: three page-locked staging
+ * buffers per chunk size (32 or 64 MiB each), and per device the feed slots of the last decode (streams, events, device buffers:
+ * ~0.3 GB per slot, four to eight slots).  This call gives all of it back; no decode may be running.  The next file pays the
+ * first-file cost again (~60 ms: registration of the staging buffers, allocations). */
+void bk_feed_release_caches(void);
 /* Feed and hot path overlapped: the reference reads the BAM twice, one pass after the other (BreakID.cc:1929,
  * :1414); here the file is read once, and the record-level kernel of the hot path (insert-size sums, discordant filter,
  * SA gate: k_stream) runs on the records of a feed chunk while the following chunks are still being copied and inflated.

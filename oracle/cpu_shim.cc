@@ -166,6 +166,7 @@ int bk_bam_decode_device_part(const char *, int, int, int, bk_bam_dev **, bk_soa
   return BK_ERR_NO_DEVICE;
 }
 void bk_bam_dev_free(bk_bam_dev *) {}
+void bk_feed_release_caches(void) {}
 int bk_multi_run(const bk_soa *, const uint32_t *, const char *const *, int, int, int, int, int, double *, uint64_t *, bk_ctx **, char *err, size_t errlen)
 {
   if (err && errlen) snprintf(err, errlen, "no GPU in this build (oracle/cpu_shim.cc)");

@@ -319,6 +319,32 @@ def test_device_decode_in_chunks_equals_one_chunk():
             table.close()
 
 
+def test_feed_keeps_its_buffers_between_files_and_gives_them_back():
+    """the second and third file of a process go through the staging buffers, copy threads and slots the first one left
+    (every chunk staged, header hops on the producer side): same table; bk_feed_release_caches() gives everything back and
+    the next file starts from nothing again: same table; both layouts (records inside / across BGZF blocks)"""
+    contigs, ds = _dataset()
+    ref = ds.to_soa()
+    with tempfile.TemporaryDirectory() as t:
+        for aligned in (True, False):
+            p = os.path.join(t, "a%d.bam" % aligned)
+            ds.write_bam(p, aligned=aligned)
+            os.environ["BREAKID_FEED_CHUNK_MB"] = repr(os.path.getsize(p) / 7 / 1048576.0)  # more than three chunks: the staging pool runs
+            try:
+                for rep in range(5):
+                    if rep == 3:
+                        capi.lib().bk_feed_release_caches()
+                    table = capi.decode_bam_device(p)
+                    got = _device_cols(table)
+                    assert table.contigs == contigs
+                    for k, _ in abi.SOA_COLS_ALL:
+                        assert np.array_equal(got[k], ref[k]), (aligned, rep, k)
+                    table.close()
+            finally:
+                os.environ.pop("BREAKID_FEED_CHUNK_MB", None)
+    capi.lib().bk_feed_release_caches()
+
+
 @pytest.mark.parametrize("parts", [2, 3, 7, 64])
 def test_parts_of_a_file_tile_its_record_table(parts):
     """bk_bam_decode_device_part: the blocks that start in the k-th part of the file's bytes, for every k - concatenated in order
