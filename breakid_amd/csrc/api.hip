@@ -103,6 +103,7 @@ struct bk_ctx
   DevBuf d_glex;
 
   // mask + cluster
+  SortService svc;  // resident sort service of the stage (sortsvc.inc)
   ClusterBufs cb;
   PairList list;
   DevBuf iso_idx, iso_goff, d_cluster;
@@ -673,8 +674,61 @@ static void run_lane(const bk_pair *pairs, const uint32_t *gof, const uint64_t *
     ahc_cluster_all(pairs, L, w, d_cluster, ab, cb, st);
 }
 
+static bool sort_service_on()
+{
+  // BREAKID_SORT_SERVICE=0: every std::sort replay as its own chain of launches (the earlier form)
+  static const bool on = !(getenv("BREAKID_SORT_SERVICE") && atoi(getenv("BREAKID_SORT_SERVICE")) == 0);
+  return on;
+}
+// The resident sort service runs while one of these lives: every sort through the context's (and its lanes') buffers is a job.
+struct SvcStage
+{
+  bk_ctx *ctx;
+  bool on;
+  SvcStage(bk_ctx *c, bool want, uint64_t n_bound, uint64_t max_group) : ctx(c), on(want && sort_service_on())
+  {
+    set(on ? &ctx->svc : nullptr);
+    if (on) ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
+  }
+  void set(SortService *s)
+  {
+    ctx->cb.se.svc = s;
+    ctx->cb.se.svc_slot = 0xFFFFFFFFu;
+    for (auto &l : ctx->lanes)
+    {
+      l->cb.se.svc = s;
+      l->cb.se.svc_slot = 0xFFFFFFFFu;
+    }
+  }
+  void finish()
+  {
+    if (!on) return;
+    on = false;
+    set(nullptr);
+    // every job has been waited for on its caller's stream: the streams must be through before the workgroups are told to leave
+    hipError_t e = hipStreamSynchronize(ctx->st);
+    for (auto &l : ctx->lanes)
+      if (l->st && e == hipSuccess) e = hipStreamSynchronize(l->st);
+    ctx->svc.stop();
+    if (e != hipSuccess) throw bk_error(BK_ERR_HIP, std::string("sort service: ") + hipGetErrorString(e));
+  }
+  ~SvcStage()
+  {
+    try
+    {
+      finish();
+    }
+    catch (const bk_error &)
+    {
+    }
+  }
+};
 static int lanes_wanted()
 {
+  // with the resident sort service a lane's sort is a submit and a wait kernel, so there can be a lane for every one or two of the
+  // groups that carry long heap segments: twelve by default
+  static const int want_svc = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 12;
+  if (sort_service_on()) return want_svc < 1 ? 1 : (want_svc > 26 ? 26 : want_svc);
   // four lanes unless the caller says otherwise (BREAKID_GROUP_LANES=1: one pass); lanes_apply decides from the data whether they
   // pay.  Measured on the 30x WGS shape with the segment-per-workgroup tail of the level loop: 2 lanes 42.0 ms, 3 lanes 42.6,
   // 4 lanes 39.6, 5 lanes 48.5 (more lanes shorten a lane's "longest heap of any of its groups" per sort, and cost a level loop,
@@ -855,7 +909,9 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
 {
   const uint32_t ng = ctx->jr.n_groups;
   const int K = lanes_wanted();
-  static const bool adapt = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
+  const bool use_svc = sort_service_on() && fast;
+  static const bool adapt_env = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
+  const bool adapt = adapt_env && !use_svc;  // (the service does not report the groups' longest heap segments back to the host)
   while ((int) ctx->lanes.size() < K - 1)
   {
     ctx->lanes.emplace_back(new bk_ctx::Lane());
@@ -928,6 +984,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   };
   const bk_pair *pairs = ctx->jr.pairs;
   upload_plan(plan_blind(ctx, K));
+  SvcStage svc_stage(ctx, use_svc, ctx->jr.n_pairs + 2ull * ng + 4096, ctx->cb.max_group_bound);  // the service runs from here to the end of the lanes (also when one of them throws)
   if (!adapt)
   {
     in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l).get<uint32_t>(), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l), ctx->gstart_host.data(), keep[l].data()); });
@@ -988,6 +1045,8 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
         ahc_cluster_all(pairs, L, w, lane_cl(l), ctx->ab, lane_cb(l), st);
     });
   }
+  svc_stage.finish();  // (throws what a task reported)
+  if (use_svc && getenv("BK_DEBUG_LANES")) fprintf(stderr, "[svc] tasks: %u wide, %u narrow\n", ctx->svc.stats[0], ctx->svc.stats[1]);
   // one list in group order again
   PairList &iso_m = ctx->lane_iso_m;
   PairList *iacc = ctx->lane_acc, *lacc = ctx->lane_acc + 2;
@@ -1019,6 +1078,7 @@ int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
       if (n_clustered) *n_clustered = ctx->list.n;
       return;
     }
+    SvcStage svc_stage(ctx, true, ctx->jr.n_pairs + 2ull * ctx->jr.n_groups + 4096, ctx->cb.max_group_bound);
     {
       Scope s(ctx, "remove_isolated");
       const uint32_t *drop = nullptr;
@@ -1047,6 +1107,7 @@ int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
       else
         ahc_cluster_all(ctx->jr.pairs, ctx->list, w, ctx->d_cluster, ctx->ab, ctx->cb, ctx->st);
     }
+    svc_stage.finish();
     ctx->clustered = true;
     if (n_clustered) *n_clustered = ctx->list.n;
   });
@@ -1449,7 +1510,11 @@ int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_of
     HIP_CHECK(hipMemcpy(dp.as<uint32_t>(n + 1), iota.data(), n * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dgof.as<uint32_t>(n + 1), gof.data(), n * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dgoff.as<uint64_t>((uint64_t) n_groups + 1), group_off, ((uint64_t) n_groups + 1) * 8, hipMemcpyHostToDevice));
+    uint64_t max_group = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) max_group = std::max<uint64_t>(max_group, group_off[g + 1] - group_off[g]);
+    SvcStage svc_stage(ctx, true, n + 2ull * n_groups + 4096, max_group);
     std_sort_groups(dk.get<uint32_t>(), dp.get<uint32_t>(), dgof.get<uint32_t>(), dgoff.get<uint64_t>(), n_groups, n, ctx->cb.se, ctx->st);
+    svc_stage.finish();
     HIP_CHECK(hipMemcpyAsync(perm_out, dp.get<uint32_t>(), n * 4, hipMemcpyDeviceToHost, ctx->st));
     HIP_CHECK(hipStreamSynchronize(ctx->st));
   });

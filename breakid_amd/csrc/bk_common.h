@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 
 #include "../../include/breakid_hip.h"
 
@@ -28,6 +29,37 @@ struct bk_error : std::exception
       throw bk_error(BK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" +   \
                                      std::to_string(__LINE__) + ")");                                           \
   } while (0)
+
+// hipFree waits for the device to go idle: while a persistent kernel runs (the resident sort service) that is "until the service
+// gives up", so buffers that are outgrown meanwhile are kept and freed when the last service has stopped.
+struct DeferredFrees
+{
+  static inline std::mutex m;
+  static inline int active = 0;
+  static inline std::vector<void *> ptrs;
+  static void begin()
+  {
+    std::lock_guard<std::mutex> l(m);
+    ++active;
+  }
+  static void end()
+  {
+    std::vector<void *> now;
+    {
+      std::lock_guard<std::mutex> l(m);
+      if (--active > 0) return;
+      now.swap(ptrs);
+    }
+    for (void *p : now) (void) hipFree(p);
+  }
+  static bool defer(void *p)
+  {
+    std::lock_guard<std::mutex> l(m);
+    if (active <= 0) return false;
+    ptrs.push_back(p);
+    return true;
+  }
+};
 
 // growable device buffer (never shrinks; bench steps reuse the allocation)
 struct DevBuf
@@ -57,7 +89,7 @@ struct DevBuf
   ~DevBuf() { release(); }
   void release()
   {
-    if (p) (void) hipFree(p);
+    if (p && !DeferredFrees::defer(p)) (void) hipFree(p);
     p = nullptr;
     cap = 0;
   }

@@ -4,8 +4,39 @@
 #include "prims.h"
 #include <vector>
 
+// Resident sort service (sortsvc.inc): two persistent kernels that play the introsort replay of every std_sort_groups call made
+// through a SortEmuBufs that points at a running service, as tasks.  One per device context; start() .. stop() bracket a stage.
+struct SortService
+{
+  DevBuf ctl, slots[2], seq[2], jobs, dbg, pos[2];
+  uint32_t pos_cap[2] = {0, 0};
+  uint32_t cap[2] = {0, 0};
+  hipStream_t st[2] = {nullptr, nullptr}, st_ctl = nullptr;
+  uint32_t *quit_host = nullptr;  // mapped host memory the workgroups poll
+  uint32_t *quit_dev = nullptr;
+  uint32_t cap32 = 0;
+  uint32_t quit_word = 0, starts = 0;
+  size_t wide_lds = 0;
+  bool running = false;
+  uint32_t next_slot = 0;
+  uint32_t stats[8] = {};
+  // n_bound = elements of all lists that will be sorted while the service runs (sizes the task rings), max_group = the largest
+  // group among them
+  void start(uint64_t n_bound, uint64_t max_group, hipStream_t after);
+  // ends the kernels; throws when a task reported an error
+  void stop();
+  uint32_t new_slot() { return next_slot++; }
+  ~SortService();
+  SortService() = default;
+  SortService(const SortService &) = delete;
+  SortService &operator=(const SortService &) = delete;
+};
+
 struct SortEmuBufs
 {
+  SortService *svc = nullptr;  // set (and running): std_sort_groups submits to it instead of launching the phases itself
+  uint32_t svc_slot = 0xFFFFFFFFu, svc_epoch = 0;
+  DevBuf svc_hscratch;
   DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, scratch32b, fin_list, fin_cnt, lvl, lv_tile, lv_segbase, lv_tileseg, lv_bar, chk_key0, chk_cnt, chk_bad, rk_a, rk_b;
   prims::RadixBufs radix;
   // optional observer (host): heavy[g] = largest heapsort segment (elements) any sort through these buffers left to group g's

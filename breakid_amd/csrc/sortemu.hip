@@ -25,6 +25,7 @@
 #include <mutex>
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <ctime>
 
@@ -36,6 +37,10 @@ inline double now_ms()
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
+// A store that goes through to memory (sc1): what another workgroup of a running kernel reads after its acquire without the
+// storing workgroup having to write back its whole L2 (resident sort service, sortsvc.inc).  p is a global address.
+typedef __attribute__((address_space(1))) uint32_t gu32_t;
+__device__ __forceinline__ void st_through(uint32_t *p, uint32_t v) { __hip_atomic_store((gu32_t *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Live segments of one level are laid out back to back in a compact index space (cbase = first compact index of
 // the segment): the per-level passes touch only elements that are still being partitioned, not all n positions.
 struct Seg
@@ -1225,42 +1230,54 @@ __device__ void wg_ranked_entries(const uint32_t *gk, const uint32_t m, unsigned
     }
   }
 }
-template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_THREADS : 64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *__restrict__ key, uint32_t *__restrict__ idx,
-                                                                       hent *__restrict__ scratch, uint32_t lo, uint32_t hi,
-                                                                       const uint32_t *__restrict__ rank32, uint32_t *__restrict__ scratch32,
-                                                                       uint32_t *__restrict__ scratch32b, unsigned long long *rka, unsigned long long *rkb)
+// One heap segment of at most 4096 elements as packed 8-byte entries in LDS (buf): every thread of the workgroup calls this (NT of
+// them), the heap itself belongs to wave 0.
+__device__ __forceinline__ void heap_small_body(const uint32_t first, const uint32_t last, uint32_t *key, uint32_t *idx, hent *buf, const uint32_t NT)
 {
-  extern __shared__ __attribute__((aligned(16))) hent dyn[];
-  __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
-  const uint32_t s = blockIdx.x;
-  if (s >= nh) return;
-  const HeapSeg sg = hs[s];
-  const uint32_t m = sg.last - sg.first;
-  if (m <= lo || m > hi) return;
-  uint32_t *gk = key + sg.first, *gx = idx + sg.first;
-  hent *buf = CLS == 0 ? stat : (CLS == 1 ? dyn : scratch + sg.first);
-  const uint32_t NT = CLS == 2 ? HEAP_BIG_THREADS : 64;  // = blockDim.x
-  const bool w0 = threadIdx.x < 64;                       // the wave that owns the heap
+  const uint32_t m = last - first;
+  uint32_t *gk = key + first, *gx = idx + first;
   for (uint32_t i = threadIdx.x; i < m; i += NT) buf[i] = ((hent) gk[i] << 32) | gx[i];
   __syncthreads();
-  if (CLS == 2 && ASM && (rank32 != nullptr || rka != nullptr) && m <= HEAP_RANKED_MAX)
+  if (threadIdx.x < 64)
   {
-    // ranked 4-byte entries ((rank + 1) << 16 | local index, never 0): up to HEAP_LARGE32 of them fit LDS (slots 1..m of l32,
+    LdsMem mem{buf};
+    make_heap_wave(mem, m);
+    sort_heap_asm<false>(buf, m, 1);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < m; i += NT)
+  {
+    const hent e = buf[i];
+    st_through(gk + i, hkey(e));
+    st_through(gx + i, (uint32_t) e);
+  }
+}
+// One heap segment of more than HEAP_BIG_MIN elements by a workgroup of NT threads that owns `dyn`: 4 * (cap32 + 3) bytes of LDS
+// (cap32 odd; at least 8 * HEAP_LARGE bytes when segments beyond HEAP_RANKED_MAX elements may come).  The loads, the ranking and
+// the final gather of a 40 000-element segment are 700 dependent round trips for a lone wave (0.9 ms) and a fraction of that for
+// sixteen; the heap itself belongs to wave 0, the other waves sleep at the barriers meanwhile.
+__device__ __forceinline__ void heap_big_body(const uint32_t first, const uint32_t last, uint32_t *key, uint32_t *idx, hent *scratch, uint32_t *scratch32, uint32_t *scratch32b,
+                                              unsigned long long *rka, unsigned long long *rkb, hent *dyn, const uint32_t cap32, const uint32_t NT)
+{
+  const uint32_t m = last - first;
+  uint32_t *gk = key + first, *gx = idx + first;
+  hent *buf = scratch + first;
+  const bool w0 = threadIdx.x < 64;  // the wave that owns the heap
+  for (uint32_t i = threadIdx.x; i < m; i += NT) buf[i] = ((hent) gk[i] << 32) | gx[i];
+  __syncthreads();
+  if (m <= HEAP_RANKED_MAX)
+  {
+    // ranked 4-byte entries ((rank + 1) << 16 | local index, never 0): up to cap32 of them fit LDS (slots 1..m of l32,
     // slot 0 scratch, two zero slots behind).  buf keeps the packed originals; the sorted entries end up in g32.
     const unsigned long long tp0 = wall_clock64();
     uint32_t *l32 = reinterpret_cast<uint32_t *>(dyn);
-    uint32_t *g32 = scratch32 + sg.first;
-    const bool fits = m <= HEAP_LARGE32;
+    uint32_t *g32 = scratch32 + first;
+    const bool fits = m <= cap32;
     unsigned long long tp1, tp2, tp3;
     if (fits)
     {
-      if (CLS == 2 && rank32 == nullptr)
-      {
-        wg_ranked_entries(gk, m, rka + sg.first, rkb + sg.first, l32 + 1, l32, l32 + (NT / 64 + 1) * 256, NT);
-        __syncthreads();
-      }
-      else
-        for (uint32_t i = threadIdx.x; i < m; i += NT) l32[1 + i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      wg_ranked_entries(gk, m, rka + first, rkb + first, l32 + 1, l32, l32 + (NT / 64 + 1) * 256, NT);
+      __syncthreads();
       if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : m + threadIdx.x] = 0;
       __syncthreads();
       tp1 = wall_clock64();
@@ -1273,10 +1290,7 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_TH
     }
     else
     {
-      if (CLS == 2 && rank32 == nullptr)
-        wg_ranked_entries(gk, m, rka + sg.first, rkb + sg.first, g32, l32, l32 + (NT / 64 + 1) * 256, NT);
-      else
-        for (uint32_t i = threadIdx.x; i < m; i += NT) g32[i] = ((rank32[sg.first + i] + 1u) << 16) | i;
+      wg_ranked_entries(gk, m, rka + first, rkb + first, g32, l32, l32 + (NT / 64 + 1) * 256, NT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       tp1 = wall_clock64();
@@ -1285,37 +1299,37 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_TH
         make_heap_block(gmem, m, NT);
       }
       tp2 = wall_clock64();
-      if (scratch32b != nullptr && g_heap_no_hybrid == 0 && m < 2 * (HEAP_LARGE32 + 1))
+      if (m < 2 * (cap32 + 1))
       {
         // the upper levels to LDS, the rest (all leaves) to the overflow array; the pops that bring the heap down to the LDS part
-        uint32_t *ovf = scratch32b + sg.first;  // ovf[slot], slots HEAP_LARGE32 + 1 .. m + 2
+        uint32_t *ovf = scratch32b + first;  // ovf[slot], slots cap32 + 1 .. m + 2
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < m; i += NT)
         {
           const uint32_t e = g32[i];
-          if (i < HEAP_LARGE32) l32[1 + i] = e; else ovf[1 + i] = e;
+          if (i < cap32) l32[1 + i] = e; else ovf[1 + i] = e;
         }
-        if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
+        if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : cap32 + threadIdx.x] = 0;
         if (threadIdx.x < 2) ovf[m + 1 + threadIdx.x] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (w0) sort_heap_hybrid(l32 + 1, m, HEAP_LARGE32, ovf, g32);
+        if (w0) sort_heap_hybrid(l32 + 1, m, cap32, ovf, g32);
         tp3 = wall_clock64();
       }
       else
       {
         if (w0)
         {
-          sort_heap_asm32<true>(g32, m, HEAP_LARGE32);  // pops in global memory until the heap fits LDS
+          sort_heap_asm32<true>(g32, m, cap32);  // pops in global memory until the heap fits LDS
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         tp3 = wall_clock64();
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < HEAP_LARGE32; i += NT) l32[1 + i] = g32[i];
-        if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : HEAP_LARGE32 + threadIdx.x] = 0;
+        for (uint32_t i = threadIdx.x; i < cap32; i += NT) l32[1 + i] = g32[i];
+        if (threadIdx.x < 3) l32[threadIdx.x == 0 ? 0 : cap32 + threadIdx.x] = 0;
       }
       __syncthreads();
-      if (w0) sort_heap_lds_q(l32 + 1, HEAP_LARGE32, g32);
+      if (w0) sort_heap_lds_q(l32 + 1, cap32, g32);
     }
     __syncthreads();
     if (threadIdx.x == 0) g32[0] = l32[1];  // the last element never leaves the root
@@ -1333,85 +1347,51 @@ template <int CLS, bool ASM> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_TH
     for (uint32_t i = threadIdx.x; i < m; i += NT)
     {
       const hent e = buf[g32[i] & 0xFFFFu];
-      gk[i] = hkey(e);
-      gx[i] = (uint32_t) e;
+      st_through(gk + i, hkey(e));
+      st_through(gx + i, (uint32_t) e);
     }
     return;
   }
-  if (CLS == 2)
+  // beyond the ranked form: heapify and pop in global memory until the heap fits LDS as packed entries, then finish there
+  if (w0)
   {
-    // too large for LDS: heapify and pop in global memory until the heap fits, then finish in LDS
-    if (w0)
-    {
-      GlbMem gmem{buf};
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      make_heap_wave(gmem, m);
-      if (ASM) sort_heap_asm<true>(buf, m, HEAP_LARGE); else sort_heap_lag2(gmem, m, HEAP_LARGE);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += NT) dyn[i] = buf[i];
-    __syncthreads();
-    if (w0)
-    {
-      LdsMem lmem{dyn};
-      if (ASM) sort_heap_asm<false>(dyn, HEAP_LARGE, 1); else sort_heap_lag2(lmem, HEAP_LARGE, 1);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += NT) buf[i] = dyn[i];
+    GlbMem gmem{buf};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    make_heap_wave(gmem, m);
+    sort_heap_asm<true>(buf, m, HEAP_LARGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  else
-  {
-    LdsMem mem{buf};
-    make_heap_wave(mem, m);
-    if (ASM) sort_heap_asm<false>(buf, m, 1); else sort_heap_lag2(mem, m, 1);
-  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += NT) dyn[i] = buf[i];
+  __syncthreads();
+  if (w0) sort_heap_asm<false>(dyn, HEAP_LARGE, 1);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < HEAP_LARGE; i += NT) buf[i] = dyn[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += NT)
   {
     const hent e = buf[i];
-    gk[i] = hkey(e);
-    gx[i] = (uint32_t) e;
+    st_through(gk + i, hkey(e));
+    st_through(gx + i, (uint32_t) e);
   }
 }
-
-// ---- dense key ranks inside the heap segments of the ranked class (HEAP_RANKED_MIN < m <= HEAP_RANKED_MAX) ----------
-__global__ void k_hr_count(const HeapSeg *__restrict__ hs, uint32_t nh, unsigned long long *__restrict__ cnt)
+// cls 0: len <= HEAP_SMALL (static LDS), 1: <= HEAP_BIG_MIN (dynamic LDS), 2: larger, one workgroup of HEAP_BIG_THREADS per CU;
+// (lo, hi]: the sizes this launch takes
+template <int CLS> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_THREADS : 64) void k_se_heapsort(const HeapSeg *__restrict__ hs, uint32_t nh, uint32_t *key, uint32_t *idx, hent *scratch, uint32_t lo, uint32_t hi,
+                                                                                                    uint32_t *scratch32, uint32_t *scratch32b, unsigned long long *rka, unsigned long long *rkb)
 {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nh) return;
-  const uint32_t m = hs[s].last - hs[s].first;
-  cnt[s] = (m > HEAP_RANKED_MIN && m <= HEAP_RANKED_MAX) ? (1ull | ((unsigned long long) m << 32)) : 0ull;
-}
-// one block per heap segment: (ordinal << 32 | key, position) of every element of a ranked-class segment
-__global__ __launch_bounds__(256) void k_hr_gather(const HeapSeg *__restrict__ hs, uint32_t nh, const unsigned long long *__restrict__ off, const uint32_t *__restrict__ key,
-                                                   uint64_t *__restrict__ ck, uint32_t *__restrict__ val, uint32_t *__restrict__ ordbase)
-{
+  extern __shared__ __attribute__((aligned(16))) hent dyn[];
+  __shared__ hent stat[CLS == 0 ? HEAP_SMALL + HEAP_PAD : 1];
   const uint32_t s = blockIdx.x;
-  const uint32_t first = hs[s].first, m = hs[s].last - first;
-  if (!(m > HEAP_RANKED_MIN && m <= HEAP_RANKED_MAX)) return;
-  const uint32_t ord = (uint32_t) off[s], base = (uint32_t) (off[s] >> 32);
-  if (threadIdx.x == 0) ordbase[ord] = base;
-  for (uint32_t i = threadIdx.x; i < m; i += 256)
-  {
-    ck[base + i] = ((uint64_t) ord << 32) | key[first + i];
-    val[base + i] = first + i;
-  }
-}
-__global__ __launch_bounds__(256) void k_hr_flags(const uint64_t *__restrict__ ck, uint32_t n, uint32_t *__restrict__ f)
-{
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  f[i] = (i > 0 && ck[i] != ck[i - 1] && (ck[i] >> 32) == (ck[i - 1] >> 32)) ? 1u : 0u;
-}
-// ex = exclusive scan of the flags (n + 1 entries): rank = number of key changes since the segment's first element
-__global__ __launch_bounds__(256) void k_hr_scatter(const uint64_t *__restrict__ ck, const uint32_t *__restrict__ val, const uint32_t *__restrict__ ex,
-                                                    const uint32_t *__restrict__ ordbase, uint32_t n, uint32_t *__restrict__ rank32)
-{
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  rank32[val[i]] = ex[i + 1] - ex[ordbase[(uint32_t) (ck[i] >> 32)]];
+  if (s >= nh) return;
+  const HeapSeg sg = hs[s];
+  const uint32_t m = sg.last - sg.first;
+  if (m <= lo || m > hi) return;
+  if (CLS == 2)
+    heap_big_body(sg.first, sg.last, key, idx, scratch, scratch32, scratch32b, rka, rkb, dyn, HEAP_LARGE32, HEAP_BIG_THREADS);
+  else
+    heap_small_body(sg.first, sg.last, key, idx, CLS == 0 ? stat : dyn, 64);
 }
 
 __device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t c)
@@ -2284,22 +2264,52 @@ template <uint32_t T> __device__ __forceinline__ uint32_t fin_scan(uint32_t v, u
   return prims::block_exclusive_scan(v, lds, total);
 }
 
-// FMAX = capacity in elements, T = threads; `step` = +1 / -1 walks the list from the front / the back
-template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_finish(const FinSeg *__restrict__ fl, uint32_t nf, int step, uint32_t *__restrict__ key,
-                                                                                        uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
+// the LDS of one finisher workgroup (FMAX = capacity in elements)
+template <uint32_t FMAX> struct FinLds
+{
+  uint32_t key[FMAX], idx[FMAX];
+  uint32_t lr[FMAX + 1];  // exclusive prefix of (L-stopper | R-stopper << 16)
+  uint16_t posL[FMAX + 2], posR[FMAX + 2];
+  uint16_t segof[FMAX];
+  LSeg seg[2][FMAX / 16 + 2];  // > FMAX / 17 live sub-segments
+  uint32_t scan[prims::WAVES];
+  uint32_t ns;
+};
+// where the finisher leaves the sub-segments that exhaust the depth limit: the sort's heap list (launch-per-phase form) ...
+struct FinHeapToList
+{
+  uint32_t *err;
+  uint2 *heap_list;
+  __device__ __forceinline__ void add(uint32_t first, uint32_t last) const
+  {
+    const uint32_t slot = atomicAdd(err + 3, 1u), sz = last - first;
+    heap_list[slot] = make_uint2(first, last);
+    atomicAdd(err + 2, sz);
+    atomicMax(err + 1, sz);
+  }
+};
+// ... or a list in the workgroup's LDS (resident service: they become tasks once the segment is back in global memory)
+struct FinHeapToLds
+{
+  uint32_t *cnt;  // [0] = entries, [1] = elements in them
+  uint2 *list;
+  __device__ __forceinline__ void add(uint32_t first, uint32_t last) const
+  {
+    list[atomicAdd(cnt, 1u)] = make_uint2(first, last);
+    atomicAdd(cnt + 1, last - first);
+  }
+};
+// one segment [fs.first, fs.last) by the T threads of a workgroup (all of them call this)
+template <uint32_t FMAX, uint32_t T, class HOUT> __device__ __forceinline__ void fin_body(FinLds<FMAX> &L, const FinSeg fs, uint32_t *key, uint32_t *idx, const HOUT &hout)
 {
   constexpr uint32_t FIN_EPT = FMAX / T;
-  constexpr uint32_t FIN_SEGS = FMAX / 16 + 2;  // > FMAX / 17 live sub-segments
+  constexpr uint32_t FIN_SEGS = FMAX / 16 + 2;
   static_assert(FIN_SEGS <= T, "one thread per sub-segment");
-  __shared__ uint32_t s_key[FMAX], s_idx[FMAX];
-  __shared__ uint32_t s_lr[FMAX + 1];  // exclusive prefix of (L-stopper | R-stopper << 16)
-  __shared__ uint16_t s_posL[FMAX + 2], s_posR[FMAX + 2];
-  __shared__ uint16_t s_segof[FMAX];
-  __shared__ LSeg s_seg[2][FIN_SEGS];
-  __shared__ uint32_t s_scan[prims::WAVES];
-  __shared__ uint32_t s_ns;
-  if (blockIdx.x >= nf) return;
-  const FinSeg fs = fl[(long long) step * blockIdx.x];
+  uint32_t *s_key = L.key, *s_idx = L.idx, *s_lr = L.lr;
+  uint16_t *s_posL = L.posL, *s_posR = L.posR, *s_segof = L.segof;
+  LSeg(*s_seg)[FIN_SEGS] = L.seg;
+  uint32_t *s_scan = L.scan;
+  uint32_t &s_ns = L.ns;
   const uint32_t m = fs.last - fs.first, g0 = fs.first, tid = threadIdx.x;
   for (uint32_t e = tid; e < m; e += T)
   {
@@ -2332,10 +2342,7 @@ template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_f
       if (sg.depth == 0)
       {
         S[tid].depth = -1;
-        const uint32_t slot = atomicAdd(err + 3, 1u), sz = (uint32_t) sg.last - sg.first;
-        heap_list[slot] = make_uint2(g0 + sg.first, g0 + sg.last);
-        atomicAdd(err + 2, sz);
-        atomicMax(err + 1, sz);
+        hout.add(g0 + sg.first, g0 + sg.last);
       }
       else
       {
@@ -2540,25 +2547,20 @@ template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_f
   }
   for (uint32_t e = tid; e < m; e += T)
   {
-    key[g0 + e] = s_key[e];
-    idx[g0 + e] = s_idx[e];
+    st_through(key + g0 + e, s_key[e]);
+    st_through(idx + g0 + e, s_idx[e]);
   }
+}
+// `step` = +1 / -1 walks the list from the front / the back
+template <uint32_t FMAX, uint32_t T> __global__ __launch_bounds__(T) void k_se_finish(const FinSeg *__restrict__ fl, uint32_t nf, int step, uint32_t *__restrict__ key,
+                                                                                        uint32_t *__restrict__ idx, uint32_t *__restrict__ err, uint2 *__restrict__ heap_list)
+{
+  __shared__ FinLds<FMAX> L;
+  if (blockIdx.x >= nf) return;
+  fin_body<FMAX, T>(L, fl[(long long) step * blockIdx.x], key, idx, FinHeapToList{err, heap_list});
 }
 
-__global__ __launch_bounds__(256) void k_se_compose(const uint32_t *__restrict__ key, const uint32_t *__restrict__ gof, uint32_t n, uint64_t *__restrict__ ck)
-{
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) ck[p] = ((uint64_t) gof[p] << 32) | key[p];
-}
-__global__ __launch_bounds__(256) void k_se_decompose(const uint64_t *__restrict__ ck, const uint32_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
-{
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n)
-  {
-    key[p] = (uint32_t) ck[p];
-    idx[p] = v[p];
-  }
-}
+#include "sortsvc.inc"
 }  // namespace
 
 // __final_insertion_sort.  What the introsort loop (and the heapsorts) leave is ordered between segments and arbitrary
@@ -2651,6 +2653,203 @@ static void sort_check(const char *phase, const uint32_t *key, const uint32_t *i
   }
 }
 
+// ---- the resident sort service (sortsvc.inc), host side -----------------------------------------------------------------------
+static SvcParams svc_params(SortService &S)
+{
+  SvcParams P;
+  uint32_t *ctl = S.ctl.get<uint32_t>();
+  for (int k = 0; k < 2; ++k)
+  {
+    P.q[k].head = ctl + 64 * k;
+    P.q[k].tail = ctl + 64 * k + 32;
+    P.q[k].slots = S.slots[k].get<SvcTask>();
+    P.q[k].seq = S.seq[k].get<uint32_t>();
+    P.q[k].mask = S.cap[k] - 1;
+    P.q[k].mode = getenv("BREAKID_SVC_MODE") ? (uint32_t) atoi(getenv("BREAKID_SVC_MODE")) : 0u;
+  }
+  P.error = ctl + 128;
+  P.stats = ctl + 160;
+  P.jobs = S.jobs.get<SvcJob>();
+  P.quit = S.quit_dev;
+  P.quit_d = ctl + 192;
+  P.started = S.quit_dev + 16;
+  P.cap32 = S.cap32;
+  P.quit_word = S.quit_word;
+  P.dbg = S.dbg.get<uint32_t>();
+  for (int k = 0; k < 2; ++k)
+  {
+    P.pos[k] = S.pos[k].get<uint32_t>();
+    P.pos_cap[k] = S.pos_cap[k];
+  }
+  P.timeout_ticks = getenv("BREAKID_SVC_TIMEOUT_MS") ? 100000ull * (unsigned long long) atoi(getenv("BREAKID_SVC_TIMEOUT_MS")) : SVC_TIMEOUT_TICKS;
+  return P;
+}
+void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
+{
+  if (running) return;
+  static const int n_wide_env = getenv("BREAKID_SVC_WIDE") ? atoi(getenv("BREAKID_SVC_WIDE")) : 0;
+  static const int n_narrow_env = getenv("BREAKID_SVC_NARROW") ? atoi(getenv("BREAKID_SVC_NARROW")) : 0;
+  int dev = 0, cus = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // a quarter of the CUs to the wide workgroups (each takes a whole CU's LDS), two narrow ones on each of the others
+  const int n_wide = std::min(1024, n_wide_env > 0 ? n_wide_env : std::max(4, cus / 4));
+  const int n_narrow = n_narrow_env > 0 ? n_narrow_env : std::max(8, 2 * (cus - n_wide));
+  if (!quit_host)
+  {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&quit_host), 64 + 4 * 1024, hipHostMallocMapped));  // [0] quit, [16 ..] one word per wide workgroup
+    HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&quit_dev), quit_host, 0));
+    for (int k = 0; k < 2; ++k) HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&st_ctl, hipStreamNonBlocking));
+    hipFuncAttributes fa;
+    HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sort_service<true>)));
+    // all of a CU's 160 KB but the kernel's static LDS; the ranked entries that fit (+ slot 0 and two zero slots), an odd count
+    wide_lds = (size_t) ((160u * 1024u - (uint32_t) fa.sharedSizeBytes) & ~15u);
+    cap32 = (uint32_t) (wide_lds / 4 - 3);
+    if ((cap32 & 1u) == 0) --cap32;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_service<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) wide_lds));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_service<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) SVC_NARROW_LDS));
+  }
+  // rings: every live segment holds more than 16 elements; the wide ring only sees segments above HEAP_BIG_MIN elements
+  auto pow2 = [](uint64_t v) {
+    uint32_t c = 1024;
+    while (c < v && c < (1u << 30)) c <<= 1;
+    return c;
+  };
+  cap[0] = pow2(n_bound / HEAP_BIG_MIN + 4096);
+  cap[1] = pow2(n_bound / 16 + 4096);
+  (void) ctl.as<uint32_t>(256);
+  for (int k = 0; k < 2; ++k)
+  {
+    (void) slots[k].as<SvcTask>(cap[k]);
+    (void) seq[k].as<uint32_t>(cap[k]);
+  }
+  (void) jobs.as<SvcJob>(SVC_MAX_JOBS);
+  // every workgroup's own position lists (two per partition node): a wide one may be handed a whole group, a narrow one a node
+  // of at most SVC_WIDE_MIN elements
+  pos_cap[0] = (uint32_t) std::max<uint64_t>(max_group, SVC_WIDE_MIN) + 64;
+  pos_cap[1] = SVC_WIDE_MIN + 64;
+  (void) pos[0].as<uint32_t>(2ull * pos_cap[0] * (uint64_t) n_wide);
+  (void) pos[1].as<uint32_t>(2ull * pos_cap[1] * (uint64_t) n_narrow);
+  if (getenv("BK_DEBUG_SVC"))
+  {
+    (void) dbg.as<uint32_t>(4 * 8192);
+    HIP_CHECK(hipMemsetAsync(dbg.p, 0, 4 * 8192 * 4, after));
+  }
+  __atomic_store_n(quit_host, 0u, __ATOMIC_SEQ_CST);
+  quit_word = 0xC0DE0000u | (++starts & 0xFFFFu);
+  for (int k = 0; k < n_wide; ++k) quit_host[16 + k] = 0u;
+  next_slot = 0;
+  const SvcParams P = svc_params(*this);
+  hipLaunchKernelGGL(k_svc_reset, dim3(cdiv(std::max(cap[0], cap[1]), 256)), dim3(256), 0, after, P);
+  HIP_CHECK(hipStreamSynchronize(after));
+  DeferredFrees::begin();
+  running = true;
+  hipLaunchKernelGGL(k_sort_service<true>, dim3(n_wide), dim3(1024), wide_lds, st[0], P);
+  HIP_CHECK(hipGetLastError());
+  // a wide workgroup needs a CU to itself: the narrow ones, which fit anywhere, are only launched when every wide one has its CU
+  // (the other way round they could sit on every CU and keep the wide ones out for good)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile uint32_t *started = quit_host + 16;
+    for (;;)
+    {
+      int have = 0;
+      for (int k = 0; k < n_wide; ++k) have += started[k] != 0u;
+      if (have == n_wide) break;
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) break;  // (a busy device: the rest start when CUs free up)
+    }
+  }
+  hipLaunchKernelGGL(k_sort_service<false>, dim3(n_narrow), dim3(256), SVC_NARROW_LDS, st[1], P);
+  HIP_CHECK(hipGetLastError());
+}
+void SortService::stop()
+{
+  if (!running) return;
+  running = false;
+  __atomic_store_n(quit_host, quit_word, __ATOMIC_SEQ_CST);
+  HIP_CHECK(hipMemcpyAsync(ctl.get<uint32_t>() + 192, quit_host, 4, hipMemcpyHostToDevice, st_ctl));
+  HIP_CHECK(hipStreamSynchronize(st_ctl));
+  HIP_CHECK(hipStreamSynchronize(st[0]));
+  HIP_CHECK(hipStreamSynchronize(st[1]));
+  uint32_t h[40] = {};
+  HIP_CHECK(hipMemcpy(h, ctl.get<uint32_t>() + 128, sizeof h, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; ++k) stats[k] = h[32 + k];
+  DeferredFrees::end();
+  if (getenv("BK_DEBUG_SVC"))
+  {
+    uint32_t c[128] = {};
+    SvcJob j0 = {};
+    HIP_CHECK(hipMemcpy(c, ctl.get<uint32_t>(), sizeof c, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&j0, jobs.get<SvcJob>(), sizeof j0, hipMemcpyDeviceToHost));
+    if (dbg.p)
+    {
+      std::vector<uint32_t> d(4 * 8192);
+      HIP_CHECK(hipMemcpy(d.data(), dbg.p, d.size() * 4, hipMemcpyDeviceToHost));
+      for (int kind = 0; kind < 2; ++kind)
+      {
+        std::map<uint32_t, int> hist;
+        const uint32_t n = kind == 0 ? stats[2] : stats[3];
+        for (uint32_t w = 0; w < n && w < 4096; ++w) hist[d[4 * (w + 4096 * kind)]]++;
+        fprintf(stderr, "[svc]   %s workgroups by last state (1 polling, 5 took a task, 9 left):", kind ? "narrow" : "wide");
+        for (auto &kv : hist) fprintf(stderr, " %u:%d", kv.first, kv.second);
+        fprintf(stderr, "; first ones (state, polls, time of the last poll in 10 ns, how it left 6 error 7 quit 8 timeout):");
+        for (uint32_t w = 0; w < 6 && w < n; ++w) fprintf(stderr, " [%u %u %u %u]", d[4 * (w + 4096 * kind)], d[4 * (w + 4096 * kind) + 1], d[4 * (w + 4096 * kind) + 2], d[4 * (w + 4096 * kind) + 3]);
+        fprintf(stderr, "\n");
+      }
+    }
+    uint32_t sq[4] = {};
+    HIP_CHECK(hipMemcpy(sq, seq[1].get<uint32_t>(), sizeof sq, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[svc] tasks %u wide / %u narrow; workgroups started %u / %u, left on their own %u / %u, odd quit words read %u; error %u; wide queue head %u tail %u, narrow queue head %u tail %u (seq %u %u %u %u); job 0: remaining %u done %u heaps %u (longest %u)\n",
+            stats[0], stats[1], stats[2], stats[3], stats[4], stats[5], stats[6], h[0], c[0], c[32], c[64], c[96], sq[0], sq[1], sq[2], sq[3], j0.remaining, j0.done, j0.n_heap, j0.max_heap);
+  }
+  if (h[0]) throw bk_error(h[0] & 2u ? BK_ERR_LIMIT : BK_ERR_HIP, "sort service: task error " + std::to_string(h[0]) + " (2 = ring overflow, 4 = a job timed out, 8 = a cut outside its segment, 16 = a task in the wrong queue, 32 = a node beyond the position lists)");
+}
+SortService::~SortService()
+{
+  if (running)
+  {
+    running = false;
+    if (quit_host) __atomic_store_n(quit_host, quit_word, __ATOMIC_SEQ_CST);
+    if (quit_host && st_ctl) (void) hipMemcpyAsync(ctl.get<uint32_t>() + 192, quit_host, 4, hipMemcpyHostToDevice, st_ctl);
+    for (int k = 0; k < 2; ++k)
+      if (st[k]) (void) hipStreamSynchronize(st[k]);
+    DeferredFrees::end();
+  }
+  for (int k = 0; k < 2; ++k)
+    if (st[k]) (void) hipStreamDestroy(st[k]);
+  if (st_ctl) (void) hipStreamDestroy(st_ctl);
+  if (quit_host) (void) hipHostFree(quit_host);
+}
+
+static void window_sorts(uint32_t *key, uint32_t *idx, const uint32_t *gof, uint32_t n, hipStream_t st);
+
+// the sort as ONE job of the resident service: submit, wait (both on the caller's stream), then the insertion sort's windows
+static void std_sort_groups_svc(uint32_t *key, uint32_t *idx, const uint32_t *gof, const uint64_t *goff, uint32_t ng, uint32_t n, SortEmuBufs &b, hipStream_t st)
+{
+  SortService &S = *b.svc;
+  if (b.svc_slot == 0xFFFFFFFFu)
+  {
+    b.svc_slot = S.new_slot();
+    if (b.svc_slot >= SVC_MAX_JOBS) throw bk_error(BK_ERR_LIMIT, "sort service: more than 64 callers");
+  }
+  SvcJob d = {};
+  d.key = key;
+  d.idx = idx;
+  d.posL = b.posL.as<uint32_t>((uint64_t) n + 2);
+  d.posR = b.posR.as<uint32_t>((uint64_t) n + 2);
+  d.hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
+  d.scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
+  d.scratch32b = b.scratch32b.as<uint32_t>((uint64_t) n + HEAP_PAD);
+  d.rka = b.rk_a.as<unsigned long long>((uint64_t) n + HEAP_PAD);
+  d.rkb = b.rk_b.as<unsigned long long>((uint64_t) n + HEAP_PAD);
+  d.epoch = (++b.svc_epoch) & 0xFFFFFu;
+  const SvcParams P = svc_params(S);
+  hipLaunchKernelGGL(k_svc_submit, dim3(1), dim3(256), 0, st, P, d, b.svc_slot, goff, ng);
+  hipLaunchKernelGGL(k_svc_wait, dim3(1), dim3(64), 0, st, P, b.svc_slot);
+  window_sorts(key, idx, gof, n, st);
+}
+
 void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const uint64_t *goff, uint32_t ng, uint64_t n64, SortEmuBufs &b, hipStream_t st)
 {
   if (n64 == 0 || ng == 0) return;
@@ -2673,6 +2872,11 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     }
   }
   const uint32_t n = (uint32_t) n64;
+  if (b.svc && b.svc->running)
+  {
+    std_sort_groups_svc(key, idx, gof, goff, ng, n, b, st);
+    return;
+  }
   static const bool chk = getenv("BK_SORT_CHECK") != nullptr;
   DevBuf &chk_key0 = b.chk_key0;  // (BK_SORT_CHECK: per buffer set, i.e. per lane and device)
   uint32_t *key0 = nullptr;
@@ -2941,14 +3145,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   const uint32_t nfin = nfin2[0] + nfin2[1];
   const uint32_t nh1 = e[3], max1 = e[1], n_big = e[4];  // heap segments of the level loop; those above HEAP_BIG_MIN
   const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
-  static const bool use_asm = getenv("BK_HEAP_CXX") == nullptr;  // BK_HEAP_CXX=1: the C++ statement of the pop loop (debugging)
   static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
-  const size_t dyn = (HEAP_LARGE + HEAP_PAD) * 8;
   hent *hscratch = nullptr;
-  const uint32_t *rank32 = nullptr;
   uint32_t *scratch32 = nullptr, *scratch32b = nullptr;
   unsigned long long *rka = nullptr, *rkb = nullptr;  // scratch of the ranking inside the big heaps' own workgroups (wg_ranked_entries)
-  int used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg)
   {
@@ -2956,24 +3156,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     HIP_CHECK(hipEventCreate(&ev1));
     HIP_CHECK(hipEventRecord(ev0, st));
   }
-  if (nh1 || nfin)
-  {
-    hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
-    if (!b.fork) HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
-  }
-  auto side = [&](auto k, size_t lds, const HeapSeg *list, uint32_t count, uint32_t lo, uint32_t hi, uint32_t threads = 64) {
-    if (!b.aux[used])
-    {
-      // side streams are made when they are first needed (two per sort unless BK_HEAP_CLASSES): every stream takes one of the
-      // runtime's hardware queues in turn, and two lanes' heap kernels on one queue would run one after the other
-      HIP_CHECK(hipStreamCreateWithFlags(&b.aux[used], hipStreamNonBlocking));
-      HIP_CHECK(hipEventCreateWithFlags(&b.join[used], hipEventDisableTiming));
-    }
-    HIP_CHECK(hipStreamWaitEvent(b.aux[used], b.fork, 0));
-    hipLaunchKernelGGL(k, dim3(count), dim3(threads), lds, b.aux[used], list, count, key, idx, hscratch, lo, hi, rank32, scratch32, scratch32b, rka, rkb);
-    HIP_CHECK(hipEventRecord(b.join[used], b.aux[used]));
-    ++used;
-  };
+  if (nh1 || nfin) hscratch = b.heap_scratch.as<hent>((uint64_t) n + HEAP_PAD);
   if (b.heavy && nh1 && (max1 > HEAP_RANKED_MIN || b.heavy_all))
   {
     // the caller balances its lanes of groups on the longest heap segment per group
@@ -2991,127 +3174,33 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       if (g < ng && (*b.heavy)[g] < m) (*b.heavy)[g] = m;
     }
   }
+  bool forked = false;
   if (nh1 && max1 > HEAP_SMALL)
   {
-    const uint32_t nh = nh1;
-    if (getenv("BK_DEBUG_SORT_TIES"))
-    {
-      // how many equal keys do the big heap segments hold?  (debugging aid)
-      std::vector<HeapSeg> hh(nh);
-      HIP_CHECK(hipMemcpy(hh.data(), hl, (size_t) nh * sizeof(HeapSeg), hipMemcpyDeviceToHost));
-      for (const HeapSeg &g : hh)
-      {
-        const uint32_t m = g.last - g.first;
-        if (m < 16384) continue;
-        std::vector<uint32_t> kk(m);
-        HIP_CHECK(hipMemcpy(kk.data(), key + g.first, (size_t) m * 4, hipMemcpyDeviceToHost));
-        uint32_t inv = 0;
-        for (uint32_t i = 1; i < m; ++i) inv += kk[i] < kk[i - 1];
-        std::sort(kk.begin(), kk.end());
-        uint32_t distinct = 1, in_ties = 0, maxrun = 1, run = 1;
-        for (uint32_t i = 1; i < m; ++i)
-        {
-          if (kk[i] == kk[i - 1])
-          {
-            ++run;
-            if (run == 2) in_ties += 2; else ++in_ties;
-            if (run > maxrun) maxrun = run;
-          }
-          else
-          {
-            ++distinct;
-            run = 1;
-          }
-        }
-        fprintf(stderr, "[sortemu]   heap segment of %u: %u distinct keys, %u elements in tie groups (largest %u), key range %u..%u, %u descents in arrival order\n", m, distinct, in_ties, maxrun,
-                kk.front(), kk.back(), inv);
-      }
-    }
-    if (dbg)
-    {
-      // which groups own the big heap segments?  (size : group, largest first)
-      std::vector<HeapSeg> hh(nh);
-      std::vector<uint64_t> go((size_t) ng + 1);
-      HIP_CHECK(hipMemcpy(hh.data(), hl, (size_t) nh * sizeof(HeapSeg), hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(go.data(), goff, ((size_t) ng + 1) * 8, hipMemcpyDeviceToHost));
-      std::sort(hh.begin(), hh.end(), [](const HeapSeg &a, const HeapSeg &c) { return a.last - a.first > c.last - c.first; });
-      fprintf(stderr, "[sortemu]   big heap segments (size:group/group size):");
-      for (uint32_t i = 0; i < nh && i < 10; ++i)
-      {
-        const uint32_t g = (uint32_t) (std::upper_bound(go.begin(), go.end(), (uint64_t) hh[i].first) - go.begin()) - 1;
-        fprintf(stderr, " %u:%u/%llu", hh[i].last - hh[i].first, g, (unsigned long long) (go[g + 1] - go[g]));
-      }
-      fprintf(stderr, "\n");
-    }
-    // heaps of HEAP_LARGE+1 .. HEAP_RANKED_MAX elements run on ranked 4-byte entries: rank their keys first
-    static const bool no_ranked = getenv("BK_HEAP_NO_RANKED") != nullptr;
-    const bool ranked_on = use_asm && !no_ranked;
-    const uint32_t big_lo = ranked_on ? HEAP_RANKED_MIN : HEAP_LARGE;  // heaps above this size go to the one-per-CU kernel
-    // BK_HEAP_RANK_PRE=1: the device-wide ranking in front of the heap kernels (the earlier form; comparison / debugging)
-    static const bool rank_pre = getenv("BK_HEAP_RANK_PRE") != nullptr;
-    if (max1 > HEAP_RANKED_MIN && ranked_on && !rank_pre)
+    // heaps above HEAP_BIG_MIN elements: ranked 4-byte entries, one workgroup per CU, on a side stream (the longest of them is the
+    // critical path of the sort); the mid-size heaps of the level loop (~1.5 ms) in front of the finisher on the caller's own stream
+    if (max1 > HEAP_BIG_MIN)
     {
       rka = b.rk_a.as<unsigned long long>((uint64_t) n + HEAP_PAD);
       rkb = b.rk_b.as<unsigned long long>((uint64_t) n + HEAP_PAD);
       scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
       if (max1 > HEAP_LARGE32) scratch32b = b.scratch32b.as<uint32_t>((uint64_t) n + HEAP_PAD);  // overflow slots of the heaps beyond the LDS
-    }
-    if (max1 > HEAP_RANKED_MIN && ranked_on && rank_pre)
-    {
-      unsigned long long *hc = b.hr_cnt.as<unsigned long long>((uint64_t) nh + 1);
-      hipLaunchKernelGGL(k_hr_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, hl, nh, hc);
-      prims::exclusive_scan<unsigned long long>(hc, hc, nh, b.scan_tmp, st);
-      unsigned long long tot2 = 0;
-      HIP_CHECK(hipMemcpyAsync(&tot2, hc + nh, 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      const uint32_t n_ord = (uint32_t) tot2, e2 = (uint32_t) (tot2 >> 32);
-      if (e2)
+      if (!b.fork) HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
+      if (!b.aux[0])
       {
-        uint64_t *hck = b.hr_ck.as<uint64_t>(e2);
-        uint32_t *hval = b.hr_val.as<uint32_t>(e2), *hf = b.hr_f.as<uint32_t>((uint64_t) e2 + 1), *hord = b.hr_ord.as<uint32_t>(n_ord);
-        uint32_t *r32 = b.rank32.as<uint32_t>(n);
-        scratch32 = b.scratch32.as<uint32_t>((uint64_t) n + HEAP_PAD);
-        if (max1 > HEAP_LARGE32) scratch32b = b.scratch32b.as<uint32_t>((uint64_t) n + HEAP_PAD);  // overflow slots of the heaps beyond the LDS
-        hipLaunchKernelGGL(k_hr_gather, dim3(nh), dim3(256), 0, st, hl, nh, hc, key, hck, hval, hord);
-        int obits = 1;
-        while ((1u << obits) < n_ord && obits < 31) ++obits;
-        uint64_t *sk;
-        uint32_t *sv;
-        prims::radix_sort_pairs(hck, hval, e2, 0, 32 + obits, b.radix, st, &sk, &sv);
-        hipLaunchKernelGGL(k_hr_flags, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, e2, hf);
-        prims::exclusive_scan<uint32_t>(hf, hf, e2, b.scan_tmp, st);
-        hipLaunchKernelGGL(k_hr_scatter, dim3(cdiv(e2, 256)), dim3(256), 0, st, sk, sv, hf, hord, e2, r32);
-        rank32 = r32;
+        HIP_CHECK(hipStreamCreateWithFlags(&b.aux[0], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&b.join[0], hipEventDisableTiming));
       }
-    }
-    auto big = [&](auto k1, auto k2) {
-      // largest class first
       HIP_CHECK(hipEventRecord(b.fork, st));
-      if (max1 > big_lo)
-      {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_BIG_LDS));
-        side(k2, HEAP_BIG_LDS, hl + (max_segs - n_big), n_big, big_lo, 0xFFFFFFFFu, HEAP_BIG_THREADS);  // (the list of the long ones only)
-      }
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-      const uint32_t bounds[5] = {HEAP_LARGE, 10240, 5120, 2560, HEAP_SMALL};  // 1, 2, 4, 8 heaps per CU
-      // one launch per LDS footprint (BK_HEAP_CLASSES=1) packs more mid-size heaps per CU but measured slower
-      // end to end (197 vs 187 ms per step): the extra activity slows the lone wave on the critical path
-      static const bool split = getenv("BK_HEAP_CLASSES") != nullptr;
-      // the mid-size heaps of the level loop (at most big_lo elements, ~1.5 ms) go in front of the finisher on the caller's own
-      // stream: only the big heaps need a side stream, and every stream of every lane of groups costs a hardware queue
-      static const bool mid_side = getenv("BK_HEAP_MID_SIDE") != nullptr;
-      if ((!split || ranked_on) && !mid_side)
-        hipLaunchKernelGGL(k1, dim3(nh1), dim3(64), ((size_t) big_lo + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, big_lo, rank32, scratch32, scratch32b, rka, rkb);
-      else if (!split || ranked_on)
-        side(k1, ((size_t) big_lo + HEAP_PAD) * 8, hl, nh1, HEAP_SMALL, big_lo);
-      else
-        for (int c = 0; c < 4; ++c)
-          if (max1 > bounds[c + 1]) side(k1, ((size_t) bounds[c] + HEAP_PAD) * 8, hl, nh1, bounds[c + 1], bounds[c]);
-    };
-    if (use_asm)
-      big(k_se_heapsort<1, true>, k_se_heapsort<2, true>);
-    else
-      big(k_se_heapsort<1, false>, k_se_heapsort<2, false>);
+      HIP_CHECK(hipStreamWaitEvent(b.aux[0], b.fork, 0));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<2>), hipFuncAttributeMaxDynamicSharedMemorySize, HEAP_BIG_LDS));
+      hipLaunchKernelGGL(k_se_heapsort<2>, dim3(n_big), dim3(HEAP_BIG_THREADS), HEAP_BIG_LDS, b.aux[0], hl + (max_segs - n_big), n_big, key, idx, hscratch, HEAP_BIG_MIN, 0xFFFFFFFFu, scratch32, scratch32b, rka,
+                         rkb);  // (the list of the long ones only)
+      HIP_CHECK(hipEventRecord(b.join[0], b.aux[0]));
+      forked = true;
+    }
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ((size_t) HEAP_BIG_MIN + HEAP_PAD) * 8));
+    hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh1), dim3(64), ((size_t) HEAP_BIG_MIN + HEAP_PAD) * 8, st, hl, nh1, key, idx, hscratch, HEAP_SMALL, HEAP_BIG_MIN, scratch32, scratch32b, rka, rkb);
   }
   if (nfin2[1]) hipLaunchKernelGGL((k_se_finish<FIN_MAX, 256>), dim3(nfin2[1]), dim3(256), 0, st, fin_list + (fin_cap - 1), nfin2[1], -1, key, idx, err, heap_list);
   if (nfin2[0]) hipLaunchKernelGGL((k_se_finish<FIN_SMALL, 64>), dim3(nfin2[0]), dim3(64), 0, st, fin_list, nfin2[0], 1, key, idx, err, heap_list);
@@ -3126,27 +3215,16 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     const uint32_t nh2 = e[3];
     if (nh2)
     {
-      auto small = [&](auto k0, auto k1) {
-        // the finisher's segments (at most FIN_MAX elements) in ONE launch whatever their size - the short ones used to wait in a
-        // second launch behind the long ones - then the few short segments the level loop itself left
-        static const bool two = getenv("BK_HEAP_SMALL_APART") != nullptr;  // (the earlier form: comparison)
-        if (nh2 > nh1 && (e[1] > HEAP_SMALL || !two))
-        {
-          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-          hipLaunchKernelGGL(k1, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, two ? HEAP_SMALL : 0u, HEAP_LARGE, rank32, scratch32, scratch32b, rka,
-                             rkb);
-        }
-        if (two)
-          hipLaunchKernelGGL(k0, dim3(nh2), dim3(64), 0, st, hl, nh2, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b, rka, rkb);
-        else if (nh1)
-          hipLaunchKernelGGL(k0, dim3(nh1), dim3(64), 0, st, hl, nh1, key, idx, hscratch, 0u, HEAP_SMALL, rank32, scratch32, scratch32b, rka, rkb);
-      };
-      if (use_asm)
-        small(k_se_heapsort<0, true>, k_se_heapsort<1, true>);
-      else
-        small(k_se_heapsort<0, false>, k_se_heapsort<1, false>);
+      // the finisher's segments (at most FIN_MAX elements) in ONE launch whatever their size, then the few short segments the level
+      // loop itself left
+      if (nh2 > nh1)
+      {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_se_heapsort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ((size_t) HEAP_BIG_MIN + HEAP_PAD) * 8));
+        hipLaunchKernelGGL(k_se_heapsort<1>, dim3(nh2 - nh1), dim3(64), ((size_t) FIN_MAX + HEAP_PAD) * 8, st, hl + nh1, nh2 - nh1, key, idx, hscratch, 0u, HEAP_BIG_MIN, scratch32, scratch32b, rka, rkb);
+      }
+      if (nh1) hipLaunchKernelGGL(k_se_heapsort<0>, dim3(nh1), dim3(64), 0, st, hl, nh1, key, idx, hscratch, 0u, HEAP_SMALL, scratch32, scratch32b, rka, rkb);
     }
-    for (int i = 0; i < used; ++i) HIP_CHECK(hipStreamWaitEvent(st, b.join[i], 0));
+    if (forked) HIP_CHECK(hipStreamWaitEvent(st, b.join[0], 0));
     if (dbg)
     {
       float ms = 0;
@@ -3169,20 +3247,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   if (ev1) (void) hipEventDestroy(ev1);
   if (chk) sort_check("after the heaps and the finisher", key, idx, key0, n, goff, ng, st, b);
   // __final_insertion_sort == stable sort by key of what the introsort loop left: two tilings of 32-element windows
-  static const bool radix_final = getenv("BK_FINAL_RADIX") != nullptr;  // the general stable radix sort (debugging)
-  if (!radix_final)
-  {
-    hipLaunchKernelGGL(k_se_window_sort, dim3(cdiv(n, 256)), dim3(256), 0, st, key, idx, gof, n, 0u);
-    if (n > 16) hipLaunchKernelGGL(k_se_window_sort, dim3(cdiv(n - 16, 256)), dim3(256), 0, st, key, idx, gof, n, 16u);
-    return;
-  }
-  uint64_t *ck = b.ck.as<uint64_t>(n);
-  hipLaunchKernelGGL(k_se_compose, dim3(cdiv(n, 256)), dim3(256), 0, st, key, gof, n, ck);
-  int gbits = 1;
-  while ((1u << gbits) < ng && gbits < 31) ++gbits;
-  uint64_t *ko;
-  uint32_t *vo;
-  prims::radix_sort_pairs(ck, idx, n, 0, 32 + gbits, b.radix, st, &ko, &vo);
-  // vo may alias idx: element p is read and written by the same lane only
-  hipLaunchKernelGGL(k_se_decompose, dim3(cdiv(n, 256)), dim3(256), 0, st, ko, vo, n, key, idx);
+  window_sorts(key, idx, gof, n, st);
+}
+static void window_sorts(uint32_t *key, uint32_t *idx, const uint32_t *gof, uint32_t n, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_se_window_sort, dim3(cdiv(n, 256)), dim3(256), 0, st, key, idx, gof, n, 0u);
+  if (n > 16) hipLaunchKernelGGL(k_se_window_sort, dim3(cdiv(n - 16, 256)), dim3(256), 0, st, key, idx, gof, n, 16u);
 }

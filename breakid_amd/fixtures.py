@@ -66,4 +66,19 @@ def panelfull():
     return _from_table("panelfull", contigs, synth_gpu.to_numpy_cols(cols), synth.random_refgene(PANEL_CONTIGS, 80, 5), nib=True)
 
 
-ALL = {"g3": g3, "panel": panel, "deep": deep, "deepw": deepw, "panelfull": panelfull}
+def wgs100():
+    """BASELINE.json configs[1] shape at 100 M records: the hg19 table of tests/test_gpu_parity.py::test_wgs_shape_100M... (same
+    generator, same seed, made on the CPU so that it is the same table on every machine) - the largest hg19-shaped input the
+    REAL reference was run on (-fast, tools/make_golden_big.py wgs100).  Same-chromosome groups of ~27 K pairs whose later sorts
+    run into libstdc++'s depth limit inside the reference binary."""
+    import torch
+    from . import synth_gpu
+    contigs, cols = synth_gpu.make_wgs(100_000_000, 2024, torch.device("cpu"))
+    cols, names = synth.name_records(synth_gpu.to_numpy_cols(cols))
+    cols["target_len"] = np.asarray([l for _, l in contigs], np.uint32)
+    fx = Fixture("wgs100", contigs, cols, lambda path: bamio.write_bam_from_soa_fast(path, contigs, cols, names), synth.random_refgene(contigs, 400, 11), nib=True)
+    fx.max_nib_len = 300_000_000
+    return fx
+
+
+ALL = {"g3": g3, "panel": panel, "deep": deep, "deepw": deepw, "panelfull": panelfull, "wgs100": wgs100}
