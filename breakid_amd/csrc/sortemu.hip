@@ -2665,7 +2665,7 @@ static SvcParams svc_params(SortService &S)
     P.q[k].slots = S.slots[k].get<SvcTask>();
     P.q[k].seq = S.seq[k].get<uint32_t>();
     P.q[k].mask = S.cap[k] - 1;
-    P.q[k].mode = getenv("BREAKID_SVC_MODE") ? (uint32_t) atoi(getenv("BREAKID_SVC_MODE")) : 0u;
+    P.q[k].pad = 0;
   }
   P.error = ctl + 128;
   P.stats = ctl + 160;
@@ -2733,8 +2733,8 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   (void) pos[1].as<uint32_t>(2ull * pos_cap[1] * (uint64_t) n_narrow);
   if (getenv("BK_DEBUG_SVC"))
   {
-    (void) dbg.as<uint32_t>(4 * 8192);
-    HIP_CHECK(hipMemsetAsync(dbg.p, 0, 4 * 8192 * 4, after));
+    (void) dbg.as<uint32_t>(12 * 8192);
+    HIP_CHECK(hipMemsetAsync(dbg.p, 0, 12 * 8192 * 4, after));
   }
   __atomic_store_n(quit_host, 0u, __ATOMIC_SEQ_CST);
   quit_word = 0xC0DE0000u | (++starts & 0xFFFFu);
@@ -2784,10 +2784,22 @@ void SortService::stop()
     HIP_CHECK(hipMemcpy(&j0, jobs.get<SvcJob>(), sizeof j0, hipMemcpyDeviceToHost));
     if (dbg.p)
     {
-      std::vector<uint32_t> d(4 * 8192);
+      std::vector<uint32_t> d(12 * 8192);
       HIP_CHECK(hipMemcpy(d.data(), dbg.p, d.size() * 4, hipMemcpyDeviceToHost));
       for (int kind = 0; kind < 2; ++kind)
       {
+        // the workgroups' own accounts: time waiting and inside tasks by type (sums over the workgroups, ms), the longest task
+        const uint32_t nw = kind == 0 ? stats[2] : stats[3];
+        double sum[8] = {};
+        uint32_t longest = 0;
+        for (uint32_t w = 0; w < nw && w < 4096; ++w)
+        {
+          const uint32_t *a = d.data() + 4 * 8192 + 8 * (w + 4096 * kind);
+          for (int k = 0; k < 7; ++k) sum[k] += a[k];
+          longest = std::max(longest, a[7]);
+        }
+        fprintf(stderr, "[svc]   %s workgroups (%u): waiting %.2f ms; partition nodes %.0f in %.2f ms, finisher %.0f in %.2f ms, heaps %.0f in %.2f ms (sums over the workgroups); longest task %.3f ms\n", kind ? "narrow" : "wide", nw,
+                sum[0] * 1e-5, sum[4], sum[1] * 1e-5, sum[5], sum[2] * 1e-5, sum[6], sum[3] * 1e-5, longest * 1e-5);
         std::map<uint32_t, int> hist;
         const uint32_t n = kind == 0 ? stats[2] : stats[3];
         for (uint32_t w = 0; w < n && w < 4096; ++w) hist[d[4 * (w + 4096 * kind)]]++;
