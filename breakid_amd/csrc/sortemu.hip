@@ -2733,8 +2733,8 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   (void) pos[1].as<uint32_t>(2ull * pos_cap[1] * (uint64_t) n_narrow);
   if (getenv("BK_DEBUG_SVC"))
   {
-    (void) dbg.as<uint32_t>(12 * 8192);
-    HIP_CHECK(hipMemsetAsync(dbg.p, 0, 12 * 8192 * 4, after));
+    (void) dbg.as<uint32_t>(12 * 8192 + 32);
+    HIP_CHECK(hipMemsetAsync(dbg.p, 0, (12 * 8192 + 32) * 4, after));
   }
   __atomic_store_n(quit_host, 0u, __ATOMIC_SEQ_CST);
   quit_word = 0xC0DE0000u | (++starts & 0xFFFFu);
@@ -2784,8 +2784,14 @@ void SortService::stop()
     HIP_CHECK(hipMemcpy(&j0, jobs.get<SvcJob>(), sizeof j0, hipMemcpyDeviceToHost));
     if (dbg.p)
     {
-      std::vector<uint32_t> d(12 * 8192);
+      std::vector<uint32_t> d(12 * 8192 + 32);
       HIP_CHECK(hipMemcpy(d.data(), dbg.p, d.size() * 4, hipMemcpyDeviceToHost));
+      for (int kind = 0; kind < 2; ++kind)
+      {
+        fprintf(stderr, "[svc]   %s tasks by size (2^k ..):", kind ? "narrow heap" : "finisher");
+        for (int k = 4; k < 13; ++k) fprintf(stderr, " %d:%u", k, d[12 * 8192 + 16 * kind + k]);
+        fprintf(stderr, "\n");
+      }
       for (int kind = 0; kind < 2; ++kind)
       {
         // the workgroups' own accounts: time waiting and inside tasks by type (sums over the workgroups, ms), the longest task
