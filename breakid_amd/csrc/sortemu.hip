@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <ctime>
 
@@ -2670,9 +2671,8 @@ static SvcParams svc_params(SortService &S)
   P.error = ctl + 128;
   P.stats = ctl + 160;
   P.jobs = S.jobs.get<SvcJob>();
-  P.quit = S.quit_dev;
   P.quit_d = ctl + 192;
-  P.started = S.quit_dev + 16;
+  P.host = S.quit_dev;
   P.cap32 = S.cap32;
   P.quit_word = S.quit_word;
   P.dbg = S.dbg.get<uint32_t>();
@@ -2697,7 +2697,7 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   const int n_narrow = n_narrow_env > 0 ? n_narrow_env : std::max(8, 2 * (cus - n_wide));
   if (!quit_host)
   {
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&quit_host), 64 + 4 * 1024, hipHostMallocMapped));  // [0] quit, [16 ..] one word per wide workgroup
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&quit_host), SVC_H_WORDS * 4, hipHostMallocMapped));  // SvcParams::host
     HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&quit_dev), quit_host, 0));
     for (int k = 0; k < 2; ++k) HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&st_ctl, hipStreamNonBlocking));
@@ -2738,7 +2738,7 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   }
   __atomic_store_n(quit_host, 0u, __ATOMIC_SEQ_CST);
   quit_word = 0xC0DE0000u | (++starts & 0xFFFFu);
-  for (int k = 0; k < n_wide; ++k) quit_host[16 + k] = 0u;
+  for (uint32_t k = 1; k < SVC_H_WORDS; ++k) quit_host[k] = 0u;
   next_slot = 0;
   const SvcParams P = svc_params(*this);
   hipLaunchKernelGGL(k_svc_reset, dim3(cdiv(std::max(cap[0], cap[1]), 256)), dim3(256), 0, after, P);
@@ -2751,7 +2751,7 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   // (the other way round they could sit on every CU and keep the wide ones out for good)
   {
     const auto t0 = std::chrono::steady_clock::now();
-    volatile uint32_t *started = quit_host + 16;
+    volatile uint32_t *started = quit_host + SVC_H_STARTED;
     for (;;)
     {
       int have = 0;
@@ -2861,10 +2861,29 @@ static void std_sort_groups_svc(uint32_t *key, uint32_t *idx, const uint32_t *go
   d.scratch32b = b.scratch32b.as<uint32_t>((uint64_t) n + HEAP_PAD);
   d.rka = b.rk_a.as<unsigned long long>((uint64_t) n + HEAP_PAD);
   d.rkb = b.rk_b.as<unsigned long long>((uint64_t) n + HEAP_PAD);
-  d.epoch = (++b.svc_epoch) & 0xFFFFFu;
+  d.epoch = (b.svc_epoch++ % 0xFFFFFu) + 1u;  // (never 0)
   const SvcParams P = svc_params(S);
   hipLaunchKernelGGL(k_svc_submit, dim3(1), dim3(256), 0, st, P, d, b.svc_slot, goff, ng);
-  hipLaunchKernelGGL(k_svc_wait, dim3(1), dim3(64), 0, st, P, b.svc_slot);
+  HIP_CHECK(hipGetLastError());
+  // The caller's thread waits, not its stream: a kernel that spins on the stream until the job is done keeps the stream's hardware
+  // queue busy, and the command processor serves the other queues' dependent launches the slower the more queues hold a running
+  // kernel (twelve lanes' wait kernels: 21 us per dependent launch against 3, tools/ubench/beside.hip - the lanes' ~160 other
+  // kernels then cost more than their sorts).
+  {
+    volatile const uint32_t *done = S.quit_host + SVC_H_DONE + b.svc_slot, *err = S.quit_host + SVC_H_ERROR;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *done != d.epoch; ++spins)
+    {
+      if (*err != 0u) throw bk_error(BK_ERR_HIP, "sort service: a task failed (error " + std::to_string(*err) + ")");
+      if ((spins & 1023u) == 1023u)
+      {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) throw bk_error(BK_ERR_HIP, "sort service: a job did not finish");
+        std::this_thread::yield();
+      }
+      else
+        __builtin_ia32_pause();
+    }
+  }
   window_sorts(key, idx, gof, n, st);
 }
 
