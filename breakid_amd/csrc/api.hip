@@ -919,7 +919,12 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
     ctx->lanes.back()->cb.max_group_bound = ctx->cb.max_group_bound;
   }
   auto lane_cb = [&](int l) -> ClusterBufs & { return l == 0 ? ctx->cb : ctx->lanes[l - 1]->cb; };
-  auto lane_st = [&](int l) { return l == 0 ? ctx->st : ctx->lanes[l - 1]->st; };
+  // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), and the
+  // command processor serves at most four queues at full rate (tools/ubench/beside.hip: a kernel of a chain costs 2.7-3.7 us with
+  // up to four chains at once, 16 with eight, 34 with twelve): the lanes share S streams.
+  static const int lane_streams_env = getenv("BREAKID_LANE_STREAMS") ? atoi(getenv("BREAKID_LANE_STREAMS")) : 3;
+  const int S = use_svc ? std::max(1, std::min(lane_streams_env, K)) : K;
+  auto lane_st = [&](int l) { const int k = l % S; return k == 0 ? ctx->st : ctx->lanes[k - 1]->st; };
   auto lane_list = [&](int l) -> PairList & { return l == 0 ? ctx->listA : ctx->lanes[l - 1]->list; };
   auto lane_iso = [&](int l) -> PairList & { return l == 0 ? ctx->isoA : ctx->lanes[l - 1]->iso; };
   auto lane_cl = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_clusterA : ctx->lanes[l - 1]->d_cluster; };

@@ -2666,7 +2666,7 @@ static SvcParams svc_params(SortService &S)
     P.q[k].slots = S.slots[k].get<SvcTask>();
     P.q[k].seq = S.seq[k].get<uint32_t>();
     P.q[k].mask = S.cap[k] - 1;
-    P.q[k].pad = 0;
+    P.q[k].pad = getenv("BREAKID_SVC_RELEASE") ? (uint32_t) atoi(getenv("BREAKID_SVC_RELEASE")) : 1u;  // (experiment) an agent-scope release in front of every push
   }
   P.error = ctl + 128;
   P.stats = ctl + 160;
@@ -2821,7 +2821,7 @@ void SortService::stop()
     fprintf(stderr, "[svc] tasks %u wide / %u narrow; workgroups started %u / %u, left on their own %u / %u, odd quit words read %u; error %u; wide queue head %u tail %u, narrow queue head %u tail %u (seq %u %u %u %u); job 0: remaining %u done %u heaps %u (longest %u)\n",
             stats[0], stats[1], stats[2], stats[3], stats[4], stats[5], stats[6], h[0], c[0], c[32], c[64], c[96], sq[0], sq[1], sq[2], sq[3], j0.remaining, j0.done, j0.n_heap, j0.max_heap);
   }
-  if (h[0]) throw bk_error(h[0] & 2u ? BK_ERR_LIMIT : BK_ERR_HIP, "sort service: task error " + std::to_string(h[0]) + " (2 = ring overflow, 4 = a job timed out, 8 = a cut outside its segment, 16 = a task in the wrong queue, 32 = a node beyond the position lists)");
+  if (h[0]) throw bk_error(h[0] & 2u ? BK_ERR_LIMIT : BK_ERR_HIP, "sort service: task error " + std::to_string(h[0]) + " (2 = ring overflow, 4 = a job timed out, 8 = a cut outside its segment, 16 = a task in the wrong queue, 32 = a node beyond the position lists, 64 = the finisher); first failing task: code " + std::to_string(h[8]) + ", " + std::to_string(h[9]) + " " + std::to_string(h[10]) + " " + std::to_string(h[11]));
 }
 SortService::~SortService()
 {
@@ -2874,7 +2874,8 @@ static void std_sort_groups_svc(uint32_t *key, uint32_t *idx, const uint32_t *go
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0; *done != d.epoch; ++spins)
     {
-      if (*err != 0u) throw bk_error(BK_ERR_HIP, "sort service: a task failed (error " + std::to_string(*err) + ")");
+      if (*err != 0u)
+        throw bk_error(BK_ERR_HIP, "sort service: a task failed (error " + std::to_string(*err) + "; first failing task: code " + std::to_string(err[1]) + ", " + std::to_string(err[2]) + " " + std::to_string(err[3]) + " " + std::to_string(err[4]) + ")");
       if ((spins & 1023u) == 1023u)
       {
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) throw bk_error(BK_ERR_HIP, "sort service: a job did not finish");

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <atomic>
 #include <vector>
 __global__ void k_small(unsigned *p, unsigned n)
 {
@@ -83,5 +84,46 @@ int main()
       CK(hipStreamSynchronize(sp));
       for (int w = 0; w < waiters; ++w) CK(hipStreamSynchronize(sw[w]));
     }
+  // K chains at once, each on its own stream and host thread: what one kernel of a chain costs then
+  for (int persist : {0, 1})
+  {
+    if (persist)
+    {
+      CK(hipMemset(quit, 0, 256));
+      hipLaunchKernelGGL(k_persist, dim3(n_wg), dim3(256), 0, sp, region, words, quit, 0, sink);
+    }
+    for (int K : {1, 2, 4, 8, 12})
+    {
+      std::vector<std::thread> th;
+      std::vector<double> per(K);
+      std::atomic<int> ready{0};
+      for (int t = 0; t < K; ++t)
+        th.emplace_back([&, t] {
+          hipSetDevice(0);
+          const int N = 300;
+          unsigned *mine = small + (size_t) t * 65536;
+          hipLaunchKernelGGL(k_small, dim3(1), dim3(256), 0, sw[t], mine, 256u);
+          hipStreamSynchronize(sw[t]);
+          ++ready;
+          while (ready.load() < K) {}
+          auto t0 = std::chrono::steady_clock::now();
+          for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_small, dim3(1), dim3(256), 0, sw[t], mine, 256u);
+          hipStreamSynchronize(sw[t]);
+          auto t1 = std::chrono::steady_clock::now();
+          per[t] = std::chrono::duration<double, std::micro>(t1 - t0).count() / N;
+        });
+      for (auto &x : th) x.join();
+      double a = 0, mx = 0;
+      for (double v : per) { a += v / K; mx = v > mx ? v : mx; }
+      printf("  %2d chains at once%s: %6.2f us per kernel of a chain (slowest chain %6.2f) = one kernel per %5.2f us overall\n", K, persist ? " beside a polling persistent kernel" : "", a, mx, a / K);
+    }
+    if (persist)
+    {
+      const unsigned one = 1;
+      CK(hipMemcpyAsync(quit, &one, 4, hipMemcpyHostToDevice, sq));
+      CK(hipStreamSynchronize(sq));
+      CK(hipStreamSynchronize(sp));
+    }
+  }
   return 0;
 }
