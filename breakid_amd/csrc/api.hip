@@ -912,18 +912,19 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   const bool use_svc = sort_service_on() && fast;
   static const bool adapt_env = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
   const bool adapt = adapt_env && !use_svc;  // (the service does not report the groups' longest heap segments back to the host)
+  // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), so more lanes
+  // than streams are possible: the lanes share S streams (every stream of the process needs a hardware queue of its own while the
+  // service's persistent kernels run - a stream that shares theirs never gets its turn).
+  static const int lane_streams_env = getenv("BREAKID_LANE_STREAMS") ? atoi(getenv("BREAKID_LANE_STREAMS")) : 12;
+  const int S = use_svc ? std::max(1, std::min(lane_streams_env, K)) : K;
   while ((int) ctx->lanes.size() < K - 1)
   {
     ctx->lanes.emplace_back(new bk_ctx::Lane());
-    HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes.back()->st, hipStreamNonBlocking));
     ctx->lanes.back()->cb.max_group_bound = ctx->cb.max_group_bound;
   }
+  for (int k = 0; k < S - 1; ++k)
+    if (!ctx->lanes[k]->st) HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes[k]->st, hipStreamNonBlocking));
   auto lane_cb = [&](int l) -> ClusterBufs & { return l == 0 ? ctx->cb : ctx->lanes[l - 1]->cb; };
-  // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), and the
-  // command processor serves at most four queues at full rate (tools/ubench/beside.hip: a kernel of a chain costs 2.7-3.7 us with
-  // up to four chains at once, 16 with eight, 34 with twelve): the lanes share S streams.
-  static const int lane_streams_env = getenv("BREAKID_LANE_STREAMS") ? atoi(getenv("BREAKID_LANE_STREAMS")) : 3;
-  const int S = use_svc ? std::max(1, std::min(lane_streams_env, K)) : K;
   auto lane_st = [&](int l) { const int k = l % S; return k == 0 ? ctx->st : ctx->lanes[k - 1]->st; };
   auto lane_list = [&](int l) -> PairList & { return l == 0 ? ctx->listA : ctx->lanes[l - 1]->list; };
   auto lane_iso = [&](int l) -> PairList & { return l == 0 ? ctx->isoA : ctx->lanes[l - 1]->iso; };

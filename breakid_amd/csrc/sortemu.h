@@ -3,6 +3,7 @@
 #include "bk_common.h"
 #include "prims.h"
 #include <vector>
+#include <atomic>
 
 // Resident sort service (sortsvc.inc): two persistent kernels that play the introsort replay of every std_sort_groups call made
 // through a SortEmuBufs that points at a running service, as tasks.  One per device context; start() .. stop() bracket a stage.
@@ -18,14 +19,14 @@ struct SortService
   uint32_t quit_word = 0, starts = 0;
   size_t wide_lds = 0;
   bool running = false;
-  uint32_t next_slot = 0;
+  std::atomic<uint32_t> next_slot{0};  // (the lanes' threads draw their slots at the same time)
   uint32_t stats[8] = {};
   // n_bound = elements of all lists that will be sorted while the service runs (sizes the task rings), max_group = the largest
   // group among them
   void start(uint64_t n_bound, uint64_t max_group, hipStream_t after);
   // ends the kernels; throws when a task reported an error
   void stop();
-  uint32_t new_slot() { return next_slot++; }
+  uint32_t new_slot() { return next_slot.fetch_add(1u); }
   ~SortService();
   SortService() = default;
   SortService(const SortService &) = delete;

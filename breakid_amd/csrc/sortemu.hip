@@ -2885,6 +2885,13 @@ static void std_sort_groups_svc(uint32_t *key, uint32_t *idx, const uint32_t *go
         __builtin_ia32_pause();
     }
   }
+  if (getenv("BK_DEBUG_SVC"))
+  {
+    SvcJob j;
+    HIP_CHECK(hipMemcpy(&j, S.jobs.get<SvcJob>() + b.svc_slot, sizeof j, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[svc] slot %u sort %u: %u elements in %u groups; partitions and finisher done after %.3f ms, job after %.3f ms; %u elements in heaps, the longest %u, the heap that ended last %u elements in %.3f ms\n", b.svc_slot,
+            b.svc_epoch, n, ng, (double) (j.t_parts - j.t_submit) * 1e-5, (double) (j.t_done - j.t_submit) * 1e-5, j.n_heap, j.max_heap, (uint32_t) j.last_heap, (double) (j.last_heap >> 32) * 1e-5);
+  }
   window_sorts(key, idx, gof, n, st);
 }
 
