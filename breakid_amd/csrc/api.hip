@@ -934,14 +934,14 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   auto upload_plan = [&](const LanePlan &p) {
     for (int l = 0; l < K; ++l)
       for (uint32_t g = 0; g < ng; ++g) keep[l][g] = p.lane_of[g] == l ? 1 : 0;
-    std::vector<uint32_t> drop(ng);
+    std::vector<std::vector<uint32_t>> drop(K, std::vector<uint32_t>(ng));
     for (int l = 0; l < K; ++l)
     {
-      for (uint32_t g = 0; g < ng; ++g) drop[g] = p.lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
+      for (uint32_t g = 0; g < ng; ++g) drop[l][g] = p.lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
       uint32_t *d = lane_drop(l).as<uint32_t>((uint64_t) ng + 1);
-      HIP_CHECK(hipMemcpyAsync(d, drop.data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
-      HIP_CHECK(hipStreamSynchronize(ctx->st));  // (drop is reused; the pair table and the masks are ready for all lanes)
+      HIP_CHECK(hipMemcpyAsync(d, drop[l].data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
     }
+    HIP_CHECK(hipStreamSynchronize(ctx->st));  // (the pair table and the masks are ready for all lanes)
   };
   // runs body(l) for every lane, lane 0 on this thread; the lanes' streams are synchronised when this returns
   auto in_lanes = [&](auto body) {
@@ -975,22 +975,26 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       if (code[l] != BK_OK) throw bk_error(code[l], err[l]);
   };
   // folds the lanes' lists (disjoint groups) into one list in group order; cl = the cluster numbers travel along
-  auto merge_all = [&](auto list_of, auto cl_of, PairList &out, DevBuf *cl_out, PairList *acc, DevBuf *cacc) {
-    const PairList *cur = &list_of(0);
-    const uint32_t *ccur = cl_of(0);
-    for (int l = 1; l < K; ++l)
+  auto merge_all = [&](auto list_of, auto cl_of, PairList &out, DevBuf *cl_out, PairList *, DevBuf *) {
+    std::vector<const PairList *> ls(K);
+    std::vector<const uint32_t *> cs(K);
+    for (int l = 0; l < K; ++l)
     {
-      const bool last = l == K - 1;
-      PairList &lo = last ? out : acc[l & 1];
-      DevBuf *co = cl_out ? (last ? cl_out : &cacc[l & 1]) : nullptr;
-      merge_lists(*cur, ccur, list_of(l), cl_of(l), lo, co, ctx->st);
-      cur = &lo;
-      ccur = co ? co->get<uint32_t>() : nullptr;
+      ls[l] = &list_of(l);
+      cs[l] = cl_of(l);
     }
+    merge_lists_many(ls.data(), cl_out ? cs.data() : nullptr, K, out, cl_out, ctx->st);
   };
   const bk_pair *pairs = ctx->jr.pairs;
+  static const bool dbg_phases = getenv("BK_DEBUG_LANES") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto phase = [&](const char *what) {
+    if (dbg_phases) fprintf(stderr, "[lanes] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+  };
   upload_plan(plan_blind(ctx, K));
+  phase("plan uploaded");
   SvcStage svc_stage(ctx, use_svc, ctx->jr.n_pairs + 2ull * ng + 4096, ctx->cb.max_group_bound);  // the service runs from here to the end of the lanes (also when one of them throws)
+  phase("service started");
   if (!adapt)
   {
     in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l).get<uint32_t>(), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l), ctx->gstart_host.data(), keep[l].data()); });
@@ -1051,7 +1055,9 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
         ahc_cluster_all(pairs, L, w, lane_cl(l), ctx->ab, lane_cb(l), st);
     });
   }
+  phase("lanes done");
   svc_stage.finish();  // (throws what a task reported)
+  phase("service stopped");
   if (use_svc && getenv("BK_DEBUG_LANES")) fprintf(stderr, "[svc] tasks: %u wide, %u narrow\n", ctx->svc.stats[0], ctx->svc.stats[1]);
   // one list in group order again
   PairList &iso_m = ctx->lane_iso_m;
@@ -1060,6 +1066,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   merge_all([&](int l) -> const PairList & { return lane_iso(l); }, [&](int) -> const uint32_t * { return nullptr; }, iso_m, nullptr, iacc, icacc);
   merge_all([&](int l) -> const PairList & { return lane_list(l); }, [&](int l) -> const uint32_t * { return lane_cl(l).get<uint32_t>(); }, ctx->list, &ctx->d_cluster, lacc, lcacc);
   HIP_CHECK(hipStreamSynchronize(ctx->st));
+  phase("lists merged");
   ctx->iso_n = iso_m.n;
   std::swap(ctx->iso_idx, iso_m.idx);
   std::swap(ctx->iso_goff, iso_m.goff);

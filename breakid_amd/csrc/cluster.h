@@ -45,6 +45,7 @@ void drop_small_groups(PairList &L, ClusterBufs &b, hipStream_t st);
 void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluster_out, ClusterBufs &b, hipStream_t st);
 // two lists over disjoint sets of groups (both with offsets for all ng groups) -> one list in group order; cl_* = the cluster
 // numbers that travel with the elements (may be null)
+void merge_lists_many(const PairList *const *lists, const uint32_t *const *cls, int K, PairList &out, DevBuf *cl_out, hipStream_t st);
 void merge_lists(const PairList &A, const uint32_t *clA, const PairList &B, const uint32_t *clB, PairList &out, DevBuf *cl_out, hipStream_t st);
 // test hook: mask_pairs_chr_pos on the list in its current order
 void debug_mask_list(const bk_pair *pairs, PairList &L, long dist, ClusterBufs &b, hipStream_t st);

@@ -229,11 +229,11 @@ __global__ __launch_bounds__(256) void k_compact3(const uint32_t *__restrict__ k
   if (a2) o2[o] = a2[p];
   if (a3) o3[o] = a3[p];
 }
-__global__ __launch_bounds__(256) void k_pack_k(const uint32_t *__restrict__ k1, const uint32_t *__restrict__ k2, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+__global__ __launch_bounds__(256) void k_pack_k(const uint32_t *__restrict__ k1, const uint32_t *__restrict__ k2, uint64_t n, int kbits, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
 {
   uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  key[p] = ((uint64_t) k2[p] << 32) | k1[p];
+  key[p] = ((uint64_t) k2[p] << kbits) | k1[p];
   val[p] = (uint32_t) p;
 }
 // sorted (k2,k1) keys: run flags
@@ -572,6 +572,7 @@ void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &clust
 {
   drop_small_groups(L, b, st);
   DevBuf none;
+  const uint64_t n_first = L.n;  // (the window numbers of both passes stay below the length of the list the first pass sees)
   // pass 1 on x (list arrives x-sorted from remove_isolated_pairs), pass 2 on y after std::sort by y
   fast_pass(pairs, L, 0, w, none, b.k1, b, st);
   {
@@ -589,10 +590,14 @@ void fast_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &clust
   // ids "k1:k2" with >= 2 members survive; numeric cluster = order of first appearance in x order
   uint64_t *pk = b.pk.as<uint64_t>(n);
   uint32_t *pv = b.perm.as<uint32_t>(n);
-  hipLaunchKernelGGL(k_pack_k, dim3(nb(n)), dim3(256), 0, st, b.k1.get<uint32_t>(), b.k2.get<uint32_t>(), n, pk, pv);
+  // (k1 and k2 number windows of the list as the passes saw it: both are below n_first, so the pair needs 2 * bits(n_first) bits - the
+  // sort takes the passes over those)
+  int kbits = 1;
+  while (kbits < 32 && (n_first >> kbits) != 0) ++kbits;
+  hipLaunchKernelGGL(k_pack_k, dim3(nb(n)), dim3(256), 0, st, b.k1.get<uint32_t>(), b.k2.get<uint32_t>(), n, kbits, pk, pv);
   uint64_t *ks;
   uint32_t *vs;
-  prims::radix_sort_pairs(pk, pv, n, 0, 64, b.radix, st, &ks, &vs);
+  prims::radix_sort_pairs(pk, pv, n, 0, std::min(64, 2 * kbits), b.radix, st, &ks, &vs);
   uint32_t *flag = b.cnt.as<uint32_t>(n + 1), *fscan = b.off.as<uint32_t>(n + 1);
   hipLaunchKernelGGL(k_run_flag, dim3(nb(n)), dim3(256), 0, st, ks, n, flag);
   prims::exclusive_scan<uint32_t>(flag, fscan, n, b.scan_tmp, st);
@@ -647,6 +652,25 @@ __global__ __launch_bounds__(256) void k_merge_copy(const uint32_t *__restrict__
   if (cl) ocl[d] = cl[p];
 }
 }  // namespace
+
+// K lists of disjoint groups in one go: the merged offsets are the sum of all of them, then every list scatters itself
+void merge_lists_many(const PairList *const *lists, const uint32_t *const *cls, int K, PairList &out, DevBuf *cl_out, hipStream_t st)
+{
+  const uint32_t ng = lists[0]->ng;
+  out.ng = ng;
+  out.n = 0;
+  for (int l = 0; l < K; ++l) out.n += lists[l]->n;
+  uint32_t *oidx = out.idx.as<uint32_t>(out.n + 1), *ogof = out.gof.as<uint32_t>(out.n + 1);
+  uint64_t *ogoff = out.goff.as<uint64_t>((uint64_t) ng + 1);
+  uint32_t *ocl = cl_out ? cl_out->as<uint32_t>(out.n + 1) : nullptr;
+  HIP_CHECK(hipMemsetAsync(ogoff, 0, ((size_t) ng + 1) * 8, st));
+  for (int l = 0; l < K; ++l) hipLaunchKernelGGL(k_merge_goff, dim3(cdiv(ng + 1, 256)), dim3(256), 0, st, ogoff, lists[l]->goff.get<uint64_t>(), ng, ogoff);
+  for (int l = 0; l < K; ++l)
+  {
+    const PairList &A = *lists[l];
+    if (A.n) hipLaunchKernelGGL(k_merge_copy, dim3(nb(A.n)), dim3(256), 0, st, A.idx.get<uint32_t>(), A.gof.get<uint32_t>(), cls ? cls[l] : nullptr, A.goff.get<uint64_t>(), A.n, ogoff, oidx, ogof, ocl);
+  }
+}
 
 void merge_lists(const PairList &A, const uint32_t *clA, const PairList &B, const uint32_t *clB, PairList &out, DevBuf *cl_out, hipStream_t st)
 {
