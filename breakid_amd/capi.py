@@ -37,7 +37,7 @@ def build(verbose=False):
         raise RuntimeError("building libbreakid_hip.so failed:\n" + (r.stdout or "")[-4000:] + (r.stderr or "")[-4000:])
 
 
-EXPORTS = ["bk_init", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_get_stream", "bk_upload_records", "bk_isize_stats",
+EXPORTS = ["bk_init", "bk_prepare_process", "bk_free", "bk_last_error", "bk_set_stream", "bk_sync", "bk_get_stream", "bk_upload_records", "bk_isize_stats",
            "bk_discordant_pairs", "bk_mask_and_cluster", "bk_split_evidence", "bk_cluster_summary",
            "bk_split_breakpoints", "bk_run", "bk_fetch", "bk_timing", "bk_timing_enable", "bk_timing_touched", "bk_group_stats", "bk_qname_hash", "bk_qname_check",
            "bk_bam_open", "bk_bam_header", "bk_bam_decode", "bk_bam_close", "bk_bam_decode_device", "bk_bam_decode_device_part", "bk_bam_decode_device_ctx", "bk_bam_dev_free", "bk_feed_release_caches", "bk_debug_bgzf_inflate", "bk_debug_std_sort", "bk_debug_ahc", "bk_debug_points", "bk_debug_cigar", "bk_debug_vote", "bk_debug_region", "bk_shard_begin", "bk_shard_get_stats", "bk_shard_set_stats",

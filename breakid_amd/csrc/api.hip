@@ -104,6 +104,7 @@ struct bk_ctx
 
   // mask + cluster
   SortService svc;  // resident sort service of the stage (sortsvc.inc)
+  std::vector<hipEvent_t> svc_probe;
   ClusterBufs cb;
   PairList list;
   DevBuf iso_idx, iso_goff, d_cluster;
@@ -392,24 +393,29 @@ void ensure_splits_sorted(bk_ctx *c)
 
 extern "C" {
 
+// once per process, before its first HIP call if the caller allows: bk_multi_run* calls this before it starts its rank threads
+// (setenv must not run beside threads that read the environment)
+void bk_prepare_process()
+{
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    g_hw_queues_at_init = q ? atoi(q) : 4;
+    if (!q)
+    {
+      setenv("GPU_MAX_HW_QUEUES", "16", 0);
+      g_hw_queues_set_here = true;
+    }
+  });
+}
+
 int bk_init(int device, const uint32_t *target_len, const char *const *target_name, int n_targets, bk_ctx **out)
 {
   {
     // the lanes of bk_mask_and_cluster and the chunk streams of the GPU feed want more hardware queues than ROCm's default of 4;
     // the runtime reads the variable when it starts, so this helps a caller whose first HIP call is this one (a caller that has
     // initialised HIP already keeps what it had: lanes_apply tells it once on stderr)
-    static bool once = false;
-    if (!once)
-    {
-      once = true;
-      const char *q = getenv("GPU_MAX_HW_QUEUES");
-      g_hw_queues_at_init = q ? atoi(q) : 4;
-      if (!q)
-      {
-        setenv("GPU_MAX_HW_QUEUES", "16", 0);
-        g_hw_queues_set_here = true;
-      }
-    }
+    bk_prepare_process();
   }
   if (!out || n_targets < 0 || (n_targets && (!target_len || !target_name)))
   {
@@ -681,14 +687,65 @@ static bool sort_service_on()
   return on;
 }
 // The resident sort service runs while one of these lives: every sort through the context's (and its lanes') buffers is a job.
+// Its two persistent kernels occupy a hardware queue each until the stage ends, so a stream of this stage that shares one of those
+// queues (more streams in the process than the runtime has hardware queues: GPU_MAX_HW_QUEUES) would never get its turn.  That is
+// why the stage (a) is the only one on its device (contexts of one process on one GPU - `-comm local` - take turns: the others sort
+// by launches), and (b) probes every stream it is going to use after the kernels have started: an empty kernel that has not run
+// after 50 ms sends the whole stage back to the launch path (the service stops, the stream drains).
+__global__ void k_svc_probe() {}
+static std::mutex g_svc_device_m[64];
 struct SvcStage
 {
   bk_ctx *ctx;
   bool on;
-  SvcStage(bk_ctx *c, bool want, uint64_t n_bound, uint64_t max_group) : ctx(c), on(want && sort_service_on())
+  std::unique_lock<std::mutex> device_turn;
+  SvcStage(bk_ctx *c, bool want, uint64_t n_bound, uint64_t max_group, const std::vector<hipStream_t> &streams) : ctx(c), on(want && sort_service_on())
   {
-    set(on ? &ctx->svc : nullptr);
-    if (on) ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
+    if (on && ctx->device >= 0 && ctx->device < 64)
+    {
+      device_turn = std::unique_lock<std::mutex>(g_svc_device_m[ctx->device], std::try_to_lock);
+      on = device_turn.owns_lock();
+    }
+    if (!on) return;
+    ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
+    if (!reachable(streams))
+    {
+      ctx->svc.stop();
+      on = false;
+      device_turn.unlock();
+      static bool told = false;
+      if (!told && !getenv("BREAKID_QUIET"))
+      {
+        told = true;
+        fprintf(stderr, "[breakid] the resident sort service shares a hardware queue with a stream of its own stage (GPU_MAX_HW_QUEUES too low for the streams of this process): sorting by launches instead\n");
+      }
+      return;
+    }
+    set(&ctx->svc);
+  }
+  bool reachable(const std::vector<hipStream_t> &streams)
+  {
+    while (ctx->svc_probe.size() < streams.size())
+    {
+      hipEvent_t e;
+      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->svc_probe.push_back(e);
+    }
+    for (size_t k = 0; k < streams.size(); ++k)
+    {
+      hipLaunchKernelGGL(k_svc_probe, dim3(1), dim3(64), 0, streams[k]);
+      HIP_CHECK(hipEventRecord(ctx->svc_probe[k], streams[k]));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < streams.size(); ++k)
+      for (;;)
+      {
+        const hipError_t e = hipEventQuery(ctx->svc_probe[k]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) throw bk_error(BK_ERR_HIP, std::string("sort service probe: ") + hipGetErrorString(e));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) return false;
+      }
+    return true;
   }
   void set(SortService *s)
   {
@@ -705,11 +762,12 @@ struct SvcStage
     if (!on) return;
     on = false;
     set(nullptr);
-    // every job has been waited for on its caller's stream: the streams must be through before the workgroups are told to leave
+    // every job has been waited for by its caller: the streams must be through before the workgroups are told to leave
     hipError_t e = hipStreamSynchronize(ctx->st);
     for (auto &l : ctx->lanes)
       if (l->st && e == hipSuccess) e = hipStreamSynchronize(l->st);
     ctx->svc.stop();
+    device_turn.unlock();
     if (e != hipSuccess) throw bk_error(BK_ERR_HIP, std::string("sort service: ") + hipGetErrorString(e));
   }
   ~SvcStage()
@@ -723,12 +781,13 @@ struct SvcStage
     }
   }
 };
-static int lanes_wanted()
+static int lanes_wanted(bool svc)
 {
-  // with the resident sort service a lane's sort is a submit and a wait kernel, so there can be a lane for every one or two of the
-  // groups that carry long heap segments: twelve by default
+  // with the resident sort service a lane's sort is a submit and a wait of its thread, so there can be a lane for every one or two
+  // of the groups that carry long heap segments: twelve by default (each with a stream of its own; measured 12 / 16 / 18 / 24 lanes
+  // on 12 streams: 30.6 / 33.4 / 34.3 / 35.7 ms for the stage - every lane costs its ~160 other launches)
   static const int want_svc = getenv("BREAKID_GROUP_LANES") ? atoi(getenv("BREAKID_GROUP_LANES")) : 12;
-  if (sort_service_on()) return want_svc < 1 ? 1 : (want_svc > 26 ? 26 : want_svc);
+  if (svc) return want_svc < 1 ? 1 : (want_svc > 26 ? 26 : want_svc);
   // four lanes unless the caller says otherwise (BREAKID_GROUP_LANES=1: one pass); lanes_apply decides from the data whether they
   // pay.  Measured on the 30x WGS shape with the segment-per-workgroup tail of the level loop: 2 lanes 42.0 ms, 3 lanes 42.6,
   // 4 lanes 39.6, 5 lanes 48.5 (more lanes shorten a lane's "longest heap of any of its groups" per sort, and cost a level loop,
@@ -743,7 +802,7 @@ static bool lanes_apply(const bk_ctx *ctx, int fast)
   uint32_t large = 0;
   const uint64_t big = std::max<uint64_t>(2, min_pairs >> 6);  // 16 K pairs with the default threshold
   for (uint32_t g = 0; g < ctx->jr.n_groups && g + 1 < ctx->gstart_host.size(); ++g) large += ctx->gstart_host[g + 1] - ctx->gstart_host[g] >= big ? 1u : 0u;
-  const bool yes = lanes_wanted() >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->jr.n_pairs >= min_pairs && large >= 2;
+  const bool yes = lanes_wanted(sort_service_on() && fast) >= 2 && fast && ctx->jr.n_groups >= 4 && ctx->jr.n_pairs >= min_pairs && large >= 2;
   if (yes)
   {
     static bool told = false;
@@ -908,22 +967,36 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
 static void group_lanes(bk_ctx *ctx, double w, int fast)
 {
   const uint32_t ng = ctx->jr.n_groups;
-  const int K = lanes_wanted();
-  const bool use_svc = sort_service_on() && fast;
-  static const bool adapt_env = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
-  const bool adapt = adapt_env && !use_svc;  // (the service does not report the groups' longest heap segments back to the host)
   // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), so more lanes
-  // than streams are possible: the lanes share S streams (every stream of the process needs a hardware queue of its own while the
-  // service's persistent kernels run - a stream that shares theirs never gets its turn).
+  // than streams are possible: the lanes share S streams (BREAKID_LANE_STREAMS; measured worse than a stream each as soon as two
+  // lanes' other kernels queue behind each other: 12 lanes on 12 / 4 / 3 / 2 streams 31.6 / 31.2 / 35.0 / 40.2 ms).
   static const int lane_streams_env = getenv("BREAKID_LANE_STREAMS") ? atoi(getenv("BREAKID_LANE_STREAMS")) : 12;
-  const int S = use_svc ? std::max(1, std::min(lane_streams_env, K)) : K;
-  while ((int) ctx->lanes.size() < K - 1)
+  static const bool adapt_env = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
+  auto make_lanes = [&](int K, int S) {
+    while ((int) ctx->lanes.size() < K - 1)
+    {
+      ctx->lanes.emplace_back(new bk_ctx::Lane());
+      ctx->lanes.back()->cb.max_group_bound = ctx->cb.max_group_bound;
+    }
+    for (int k = 0; k < S - 1; ++k)
+      if (!ctx->lanes[k]->st) HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes[k]->st, hipStreamNonBlocking));
+  };
+  bool use_svc = sort_service_on() && fast;
+  int K = lanes_wanted(use_svc);
+  int S = use_svc ? std::max(1, std::min(lane_streams_env, K)) : K;
+  make_lanes(K, S);
+  std::vector<hipStream_t> stage_streams{ctx->st};
+  for (int k = 0; k < S - 1; ++k) stage_streams.push_back(ctx->lanes[k]->st);
+  SvcStage svc_stage(ctx, use_svc, ctx->jr.n_pairs + 2ull * ng + 4096, ctx->cb.max_group_bound, stage_streams);  // the service runs from here to the end of the lanes (also when one of them throws)
+  if (use_svc && !svc_stage.on)
   {
-    ctx->lanes.emplace_back(new bk_ctx::Lane());
-    ctx->lanes.back()->cb.max_group_bound = ctx->cb.max_group_bound;
+    // the service is not to be had (another context of this process has it on this device, or a hardware queue is shared): the lanes of the launch path
+    use_svc = false;
+    K = lanes_wanted(false);
+    S = K;
+    make_lanes(K, S);
   }
-  for (int k = 0; k < S - 1; ++k)
-    if (!ctx->lanes[k]->st) HIP_CHECK(hipStreamCreateWithFlags(&ctx->lanes[k]->st, hipStreamNonBlocking));
+  const bool adapt = adapt_env && !use_svc;  // (the service does not report the groups' longest heap segments back to the host)
   auto lane_cb = [&](int l) -> ClusterBufs & { return l == 0 ? ctx->cb : ctx->lanes[l - 1]->cb; };
   auto lane_st = [&](int l) { const int k = l % S; return k == 0 ? ctx->st : ctx->lanes[k - 1]->st; };
   auto lane_list = [&](int l) -> PairList & { return l == 0 ? ctx->listA : ctx->lanes[l - 1]->list; };
@@ -993,7 +1066,6 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   };
   upload_plan(plan_blind(ctx, K));
   phase("plan uploaded");
-  SvcStage svc_stage(ctx, use_svc, ctx->jr.n_pairs + 2ull * ng + 4096, ctx->cb.max_group_bound);  // the service runs from here to the end of the lanes (also when one of them throws)
   phase("service started");
   if (!adapt)
   {
@@ -1091,7 +1163,7 @@ int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
       if (n_clustered) *n_clustered = ctx->list.n;
       return;
     }
-    SvcStage svc_stage(ctx, true, ctx->jr.n_pairs + 2ull * ctx->jr.n_groups + 4096, ctx->cb.max_group_bound);
+    SvcStage svc_stage(ctx, true, ctx->jr.n_pairs + 2ull * ctx->jr.n_groups + 4096, ctx->cb.max_group_bound, {ctx->st});
     {
       Scope s(ctx, "remove_isolated");
       const uint32_t *drop = nullptr;
@@ -1113,6 +1185,7 @@ int bk_mask_and_cluster(bk_ctx *ctx, double w, int fast, uint64_t *n_clustered)
     uint64_t *ig = ctx->iso_goff.as<uint64_t>((uint64_t) ctx->list.ng + 1);
     if (ctx->list.n) HIP_CHECK(hipMemcpyAsync(ii, ctx->list.idx.get<uint32_t>(), ctx->list.n * 4, hipMemcpyDeviceToDevice, ctx->st));
     if (ctx->list.ng) HIP_CHECK(hipMemcpyAsync(ig, ctx->list.goff.get<uint64_t>(), ((uint64_t) ctx->list.ng + 1) * 8, hipMemcpyDeviceToDevice, ctx->st));
+    if (!fast) svc_stage.finish();  // (the exact UPGMA replay sorts nothing and may take long: the service's workgroups would hold their CUs, then leave on their own)
     {
       Scope s(ctx, fast ? "fast_cluster" : "ahc_cluster");
       if (fast)
@@ -1525,7 +1598,7 @@ int bk_debug_std_sort(bk_ctx *ctx, const uint32_t *key, const uint64_t *group_of
     HIP_CHECK(hipMemcpy(dgoff.as<uint64_t>((uint64_t) n_groups + 1), group_off, ((uint64_t) n_groups + 1) * 8, hipMemcpyHostToDevice));
     uint64_t max_group = 0;
     for (uint32_t g = 0; g < n_groups; ++g) max_group = std::max<uint64_t>(max_group, group_off[g + 1] - group_off[g]);
-    SvcStage svc_stage(ctx, true, n + 2ull * n_groups + 4096, max_group);
+    SvcStage svc_stage(ctx, true, n + 2ull * n_groups + 4096, max_group, {ctx->st});
     std_sort_groups(dk.get<uint32_t>(), dp.get<uint32_t>(), dgof.get<uint32_t>(), dgoff.get<uint64_t>(), n_groups, n, ctx->cb.se, ctx->st);
     svc_stage.finish();
     HIP_CHECK(hipMemcpyAsync(perm_out, dp.get<uint32_t>(), n * 4, hipMemcpyDeviceToHost, ctx->st));

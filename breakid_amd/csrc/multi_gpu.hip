@@ -516,6 +516,7 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
   };
   if (!ctx0_out || n_gpus < 1 || n_gpus > 64) return fail(BK_ERR_ARG, std::string(who) + ": bad arguments");
   *ctx0_out = nullptr;
+  bk_prepare_process();  // (the process's environment is settled before the runtime starts and before there are rank threads)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BK_ERR_NO_DEVICE, std::string(who) + ": no HIP device (this library has no CPU path)");
   if (transport == BK_TRANSPORT_AUTO) transport = ndev >= n_gpus ? BK_TRANSPORT_RCCL : BK_TRANSPORT_LOCAL;
