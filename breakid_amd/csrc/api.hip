@@ -1697,7 +1697,7 @@ void link_chunk(void *u, const bk_soa *cols, uint64_t n_ready, uint64_t n_est, h
   FeedLink *L = (FeedLink *) u;
   L->guard([&] {
     bk_ctx *c = L->ctx;
-    if (!c || n_ready < 5) return;
+    if (!c || n_ready < (uint64_t) STREAM_V + 1) return;
     c->rec = *cols;  // device pointers of the columns as they stand now
     c->have_records = true;
     c->mapq_min = L->mapq_min;
@@ -1707,11 +1707,11 @@ void link_chunk(void *u, const bk_soa *cols, uint64_t n_ready, uint64_t n_est, h
       L->prepared = true;
     }
     // the last ready record stays for the next piece: its quad reads the offset entry that follows it
-    const uint64_t lim = (n_ready - 1) / 4 * 4;
+    const uint64_t lim = (n_ready - 1) / STREAM_V * STREAM_V;
     if (lim <= L->done) return;
     HIP_CHECK(hipStreamWaitEvent(c->st, ready, 0));
     StreamArgs a = stream_args(c, lim);
-    a.q_begin = L->done / 4;
+    a.q_begin = L->done / STREAM_V;
     launch_stream(a, c->st);
     L->done = lim;
   });
@@ -1765,7 +1765,7 @@ int bk_bam_decode_device_ctx(const char *path, int device, int mapq_min, bk_bam_
     {
       Scope s(c, "k_stream", 39ull * cols.n + 4ull * cols.n_cigar_words);
       StreamArgs a = stream_args(c, cols.n);
-      a.q_begin = done / 4;
+      a.q_begin = done / STREAM_V;
       launch_stream(a, c->st);
       ok = stream_finish(c);
     }

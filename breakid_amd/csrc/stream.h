@@ -32,10 +32,19 @@ struct NameTableDev
   int32_t empty_id;
 };
 
+// records a lane of k_stream owns per iteration (consecutive ones).  Eight - every column incl. flag as 16-byte loads, mapq as 8-byte
+// loads, 94 VGPRs, still five blocks per CU - was measured against four on the 620 M-record table: 4.72 ms against 4.45-4.49 (two
+// 16-byte loads per lane and column at a 32-byte lane stride ask for every 128-byte line twice); -DBK_STREAM_V=8 builds that form.
+#ifndef BK_STREAM_V
+#define BK_STREAM_V 4
+#endif
+constexpr int STREAM_V = BK_STREAM_V;
+static_assert(STREAM_V == 4 || STREAM_V == 8, "k_stream is written for 4 or 8 records per lane");
+
 struct StreamArgs
 {
-  uint64_t n;        // records [4 * q_begin, n) are processed by this launch
-  uint64_t q_begin;  // first quad (4 records) of this launch; 0 unless the table arrives in pieces
+  uint64_t n;        // records [STREAM_V * q_begin, n) are processed by this launch
+  uint64_t q_begin;  // first group (STREAM_V records) of this launch; 0 unless the table arrives in pieces
   uint64_t rec_base;  // index of record 0 of this table in the whole sample (0 unless the sample is sharded)
   const int32_t *tid, *pos, *mtid, *mpos, *isize;
   const uint16_t *flag;

@@ -386,7 +386,7 @@ __device__ bool record_split(const StreamArgs &a, uint64_t i, uint16_t flag, int
 // ~1 % SA-bearing records) are staged in LDS bins and flushed with one global atomic per ~half-full bin:
 // a single device counter saturates near 90 returning atomics/us (MI355X_MICROARCH.md, dequeue row),
 // which a per-wave append would hit at this record rate.
-constexpr int ST_V = 4;             // records per lane per iteration
+constexpr int ST_V = STREAM_V;      // records per lane per iteration (stream.h)
 constexpr int ST_CAND_CAP = 640;    // LDS candidate bin (25 KiB of 40-byte candidates: 5 workgroups per CU still fit)
 constexpr int ST_SA_CAP = 1024;     // LDS bin of SA-bearing record indices (4 KiB)
 
@@ -459,18 +459,48 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     for (int k = 0; k < ST_V; ++k) cand[k] = sa[k] = false;
     if (live)
     {
-      const int4 t4 = reinterpret_cast<const int4 *>(a.tid)[q];
-      const int4 p4 = reinterpret_cast<const int4 *>(a.pos)[q];
-      const int4 z4 = reinterpret_cast<const int4 *>(a.isize)[q];
-      const ushort4 f4 = reinterpret_cast<const ushort4 *>(a.flag)[q];
-      const uchar4 m4 = reinterpret_cast<const uchar4 *>(a.mapq)[q];
-      const uint4 co = reinterpret_cast<const uint4 *>(a.cigar_off)[q];
-      const uint4 ao = reinterpret_cast<const uint4 *>(a.aux_off)[q];
-      // the neighbours' values (offset that ends the quad, record in front of it) sit in the neighbouring lanes' registers:
+      // ST_V consecutive records of every column: 32-bit columns as ST_V / 4 16-byte loads, flag as one 16-byte load (8 records) or one
+      // 8-byte load (4), mapq as one 8- / 4-byte load
+      int32_t izv[ST_V];
+      uint32_t cov[ST_V + 1], aov[ST_V + 1];
+#pragma unroll
+      for (int h = 0; h < ST_V / 4; ++h)
+      {
+        const int4 t4 = reinterpret_cast<const int4 *>(a.tid)[q * (ST_V / 4) + h];
+        const int4 p4 = reinterpret_cast<const int4 *>(a.pos)[q * (ST_V / 4) + h];
+        const int4 z4 = reinterpret_cast<const int4 *>(a.isize)[q * (ST_V / 4) + h];
+        const uint4 co = reinterpret_cast<const uint4 *>(a.cigar_off)[q * (ST_V / 4) + h];
+        const uint4 ao = reinterpret_cast<const uint4 *>(a.aux_off)[q * (ST_V / 4) + h];
+        tidv[4 * h + 0] = t4.x; tidv[4 * h + 1] = t4.y; tidv[4 * h + 2] = t4.z; tidv[4 * h + 3] = t4.w;
+        posv[4 * h + 0] = p4.x; posv[4 * h + 1] = p4.y; posv[4 * h + 2] = p4.z; posv[4 * h + 3] = p4.w;
+        izv[4 * h + 0] = z4.x; izv[4 * h + 1] = z4.y; izv[4 * h + 2] = z4.z; izv[4 * h + 3] = z4.w;
+        cov[4 * h + 0] = co.x; cov[4 * h + 1] = co.y; cov[4 * h + 2] = co.z; cov[4 * h + 3] = co.w;
+        aov[4 * h + 0] = ao.x; aov[4 * h + 1] = ao.y; aov[4 * h + 2] = ao.z; aov[4 * h + 3] = ao.w;
+      }
+      if (ST_V == 8)
+      {
+        const uint4 f8 = reinterpret_cast<const uint4 *>(a.flag)[q];
+        const uint2 m8 = reinterpret_cast<const uint2 *>(a.mapq)[q];
+        const uint32_t fw[4] = {f8.x, f8.y, f8.z, f8.w}, mw[2] = {m8.x, m8.y};
+#pragma unroll
+        for (int k = 0; k < ST_V; ++k)
+        {
+          flv[k] = (uint16_t) (fw[k >> 1] >> (16 * (k & 1)));
+          mqv[k] = (uint8_t) (mw[k >> 2] >> (8 * (k & 3)));
+        }
+      }
+      else
+      {
+        const ushort4 f4 = reinterpret_cast<const ushort4 *>(a.flag)[q];
+        const uchar4 m4 = reinterpret_cast<const uchar4 *>(a.mapq)[q];
+        flv[0] = f4.x; flv[1] = f4.y; flv[2] = f4.z; flv[3] = f4.w;
+        mqv[0] = m4.x; mqv[1] = m4.y; mqv[2] = m4.z; mqv[3] = m4.w;
+      }
+      // the neighbours' values (offset that ends the group, record in front of it) sit in the neighbouring lanes' registers:
       // only the lanes at the edge of the wave (or of the table) load them
-      uint32_t co_n = (uint32_t) __shfl_down((int) co.x, 1, 64), ao_n = (uint32_t) __shfl_down((int) ao.x, 1, 64);
-      uint32_t ptid = (uint32_t) __shfl_up(t4.w, 1, 64);
-      int32_t ppos = __shfl_up(p4.w, 1, 64);
+      uint32_t co_n = (uint32_t) __shfl_down((int) cov[0], 1, 64), ao_n = (uint32_t) __shfl_down((int) aov[0], 1, 64);
+      uint32_t ptid = (uint32_t) __shfl_up(tidv[ST_V - 1], 1, 64);
+      int32_t ppos = __shfl_up(posv[ST_V - 1], 1, 64);
       if (lane == 63 || q + 1 >= nq)
       {
         co_n = a.cigar_off[i0 + ST_V];
@@ -486,13 +516,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
           ppos = a.pos[i0 - 1];
         }
       }
-      tidv[0] = t4.x; tidv[1] = t4.y; tidv[2] = t4.z; tidv[3] = t4.w;
-      posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
-      flv[0] = f4.x; flv[1] = f4.y; flv[2] = f4.z; flv[3] = f4.w;
-      mqv[0] = m4.x; mqv[1] = m4.y; mqv[2] = m4.z; mqv[3] = m4.w;
-      const int32_t izv[ST_V] = {z4.x, z4.y, z4.z, z4.w};
-      const uint32_t cov[ST_V + 1] = {co.x, co.y, co.z, co.w, co_n};
-      const uint32_t aov[ST_V + 1] = {ao.x, ao.y, ao.z, ao.w, ao_n};
+      cov[ST_V] = co_n;
+      aov[ST_V] = ao_n;
 #pragma unroll
       for (int k = 0; k < ST_V; ++k)
       {
@@ -618,7 +643,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
       __syncthreads();
     }
   }
-  // ---- tail records (n % 4) : block 0, first lanes, straight to global ----
+  // ---- tail records (n % ST_V) : block 0, first lanes, straight to global ----
   if (blockIdx.x == 0 && threadIdx.x < (a.n - nq * ST_V))  // (a piece that is not the last one ends on a quad: no tail)
   {
     const uint64_t i = nq * ST_V + threadIdx.x;
@@ -884,8 +909,8 @@ __global__ __launch_bounds__(64) void k_sd_walk(const SdException *__restrict__ 
 // ---- host side ----------------------------------------------------------------------------------------
 void launch_stream(const StreamArgs &a, hipStream_t st)
 {
-  if (a.n <= 4 * a.q_begin) return;
-  unsigned blocks = cdiv(a.n / 4 - a.q_begin + 1, 256);
+  if (a.n <= (uint64_t) STREAM_V * a.q_begin) return;
+  unsigned blocks = cdiv(a.n / STREAM_V - a.q_begin + 1, 256);
   // exactly one resident set of blocks (grid-stride loop inside): a block more than fits leaves a tail that runs at
   // a fraction of the occupancy (measured 4.7 vs 6.1 TB/s at 6 vs 5 blocks per CU, LDS bins ~29 KiB per block)
   static unsigned resident = 0;
