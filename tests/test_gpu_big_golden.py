@@ -29,8 +29,10 @@ def _gpu(fx, fast):
     return ctx, mean, sd, w
 
 
-@pytest.mark.parametrize("name,mode", [("deep", "fast"), ("deepw", "fast"), ("panel", "fast"), ("panel", "ahc"), ("g3", "fast"), ("g3", "ahc"), ("panelfull", "fast")])
+@pytest.mark.parametrize("name,mode", [("deep", "fast"), ("deepw", "fast"), ("panel", "fast"), ("panel", "ahc"), ("g3", "fast"), ("g3", "ahc"), ("panelfull", "fast"), ("wgs100", "fast")])
 def test_stages_match_reference_on_large_inputs(name, mode):
+    """wgs100 = BASELINE.json configs[1]'s shape at 100 M records, the largest hg19-shaped table the REAL reference was run on (-fast,
+    755 s; its own std::sort heapsorts 4 558 segments of up to 22 852 elements there): every stage and every call of all 300 groups."""
     fx, meta = bigcases.load(name)
     if fx is None or not any(os.path.exists(os.path.join(bigcases.GOLD, "%s.%s.%s" % (name, mode, s))) for s in ("stages.txt.gz", "digest.json")):
         pytest.skip("golden %s/%s not generated" % (name, mode))
@@ -76,6 +78,28 @@ def test_cli_on_the_full_size_panel_matches_the_reference_files():
         fx.write_bam(bam)
         bamio.write_bai(bam)
         side = synth.write_side_files(fx.contigs, tmp, refgene_lines=fx.refgene, max_nib_len=60_000_000)
+        prefix = os.path.join(tmp, "out")
+        r = subprocess.run([BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all", "-fast"], env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for suffix in ("_fusion.txt", "_fusion_all.txt"):
+            got = open(prefix + suffix, "rb").read()
+            assert got.count(b"\n") == rows[suffix] and hashlib.sha256(got).hexdigest() == sha[suffix], (suffix, got[:600])
+        perf = open(prefix + "_performance.txt").read().split("\n")
+        assert perf[0] == perf5[0] and "\t".join(perf[1].split("\t")[:5]) == perf5[1], (perf, perf5)
+
+
+@pytest.mark.skipif(not os.environ.get("BREAKID_BIG_TESTS"), reason="writes a 12.6 GB BAM under the temporary directory: BREAKID_BIG_TESTS=1 asks for it (run and logged once per round: profiles/)")
+def test_cli_on_the_100M_record_wgs_table_matches_the_reference_files():
+    """configs[1]'s shape at 100 M records through bin/BreakID (GPU feed from the BAM file, annotation, writers): the txt files against
+    the sha256 of the REAL reference's, and the five deterministic columns of _performance.txt"""
+    import hashlib
+    sha, rows, perf5 = bigcases.expected_txt("wgs100", "fast")
+    fx, meta = bigcases.load("wgs100")
+    with tempfile.TemporaryDirectory() as tmp:
+        bam = os.path.join(tmp, "wgs100.bam")
+        fx.write_bam(bam)
+        bamio.write_bai(bam)
+        side = synth.write_side_files(fx.contigs, tmp, refgene_lines=fx.refgene, max_nib_len=fx.max_nib_len)
         prefix = os.path.join(tmp, "out")
         r = subprocess.run([BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all", "-fast"], env=dict(os.environ, BREAKID_INSTALLDIR=side["install"]), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]

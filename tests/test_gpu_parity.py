@@ -221,10 +221,9 @@ def test_wgs_shape_100M_oracle_determinism_and_invariants():
 
 def test_wgs_shape_full_size_620M_records():
     """BASELINE.json configs[1] at its full size (620 M records, the table bench.py times): the same bytes from two runs and from
-    the sharded driver at world size 1, the size-independent invariants of the cluster table and - where the host has the memory
-    for the 27 GB table (the single-thread oracle then takes ~40 s) - bit-identity of every final call with the CPU oracle."""
+    the sharded driver at world size 1 and the size-independent invariants of the cluster table (bit-identity with the CPU oracle at
+    this size: the next test)."""
     import zlib
-    import psutil
     import torch
     from breakid_amd import sharded, synth_gpu
     dev = torch.device("cuda", 0)
@@ -255,14 +254,37 @@ def test_wgs_shape_full_size_620M_records():
     cl2, _ = b.fetch(abi.STAGE_CLUSTERS)
     assert w2 == w and zlib.crc32(cl2.tobytes()) == crcs[0]
     b.close()
-    if psutil.virtual_memory().available > 90 * (1 << 30):
-        host = synth_gpu.to_numpy_cols(cols)
-        o = pyoracle.Oracle(contigs, host)
-        ow, rc = o.run(20, fast=True)
-        exp, _ = o.fetch(abi.STAGE_CLUSTERS)
-        assert rc == 0 and ow == w and np.array_equal(cl, exp)
-        assert n_valid == int(((exp["flags"] & 2) != 0).sum())
-        o.close()
+    ctx.close()
+
+
+def test_wgs_shape_full_size_620M_records_vs_the_cpu_oracle():
+    """The same 620 M-record table: every final call of the GPU run equal to the CPU oracle's (the single-thread oracle takes ~40 s).
+    Needs the 27 GB table on the host as well; a host without the memory SKIPS this test and says so - the test above does not
+    depend on it."""
+    import psutil
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 150 * (1 << 30):
+        pytest.skip("needs ~150 GB of free HBM (table, generator temporaries)")
+    avail = psutil.virtual_memory().available
+    if avail <= 90 * (1 << 30):
+        pytest.skip("full-size bit-identity with the CPU oracle NOT checked on this host: %.0f GiB of memory available, the 27 GB table and the oracle's tables need 90" % (avail / (1 << 30)))
+    contigs, cols = synth_gpu.make_wgs(620_000_000, 12346, dev)
+    torch.cuda.empty_cache()
+    ctx = capi.Context(contigs)
+    ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w, n_valid = ctx.run(qual=20, fast=True)
+    cl, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+    host = synth_gpu.to_numpy_cols(cols)
+    o = pyoracle.Oracle(contigs, host)
+    ow, rc = o.run(20, fast=True)
+    exp, _ = o.fetch(abi.STAGE_CLUSTERS)
+    assert rc == 0 and ow == w and np.array_equal(cl, exp)
+    assert n_valid == int(((exp["flags"] & 2) != 0).sum())
+    print("620 M records: %d clusters, %d valid calls, every row equal to the CPU oracle's" % (len(cl), n_valid))
+    o.close()
     ctx.close()
 
 
