@@ -260,6 +260,9 @@ struct AhcArgs
   uint32_t *out_idx_local, *out_cl;    // n each, group-local regions starting at goff[g]
   uint32_t *err;
   uint32_t ng;
+  // (BK_DEBUG_AHC) per group: [0] merges, [1] sum over the merges of the longest chain of ordered additions (the largest m * n of
+  // a (new node, root) pair: those additions depend on each other), [2] sum of all additions, [3] 10 ns ticks in the kernel
+  unsigned long long *dbg;
 };
 
 // order keys insert_sorted leaves among the entries of one node.  Entries must be visited in DESCENDING target
@@ -459,6 +462,14 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
   __shared__ uint32_t s_scan4[AT / 64];
   __shared__ int32_t s_first, s_second;
   __shared__ uint32_t s_scan[AT];
+  __shared__ uint32_t s_chain_max;
+  __shared__ unsigned long long s_dbg[3];
+  const unsigned long long t_in = wall_clock64();
+  if (threadIdx.x == 0)
+  {
+    s_chain_max = 0;
+    s_dbg[0] = s_dbg[1] = s_dbg[2] = 0ull;
+  }
   if (N < 2)
   {
     if (threadIdx.x == 0) a.out_cnt[g] = 0;
@@ -684,6 +695,11 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     {
       const int t = qe[idx].t;
       const uint32_t mt = npts[t];
+      if (a.dbg)
+      {
+        atomicMax(&s_chain_max, mq * mt);
+        atomicAdd(&s_dbg[2], (unsigned long long) mq * mt);
+      }
       if (mq * mt >= WAVE_WORK) continue;
       double total = 0.0;
       const uint2 leaf_xy = t < (int) N ? make_uint2(x[t], y[t]) : make_uint2(0u, 0u);
@@ -733,6 +749,12 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
       }
     }
     __syncthreads();
+    if (a.dbg && tid == 0)
+    {
+      s_dbg[0] += 1ull;
+      s_dbg[1] += s_chain_max;
+      s_chain_max = 0;
+    }
     // largest root index below q that belongs to another component: the newest root of every other component
     // (its latest merged node, or its last leaf before the first merge), or a leaf that is a component of its own
     {
@@ -908,6 +930,13 @@ __global__ __launch_bounds__(AT) void k_ahc_group(AhcArgs a)
     obase += otot;
   }
   if (tid == 0) a.out_cnt[g] = obase;
+  if (a.dbg && tid == 0)
+  {
+    a.dbg[4 * g] = s_dbg[0];
+    a.dbg[4 * g + 1] = s_dbg[1];
+    a.dbg[4 * g + 2] = s_dbg[2];
+    a.dbg[4 * g + 3] = wall_clock64() - t_in;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_gather_xy(const bk_pair *__restrict__ pairs, const uint32_t *__restrict__ idx, uint64_t n, uint32_t *__restrict__ x, uint32_t *__restrict__ y,
@@ -1022,6 +1051,14 @@ void ahc_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluste
   a.out_cl = ab.out_cl.as<uint32_t>(n);
   a.err = ab.err.as<uint32_t>(4);
   a.ng = ng;
+  static const bool dbg_ahc = getenv("BK_DEBUG_AHC") != nullptr;
+  DevBuf dbg_buf;
+  a.dbg = nullptr;
+  if (dbg_ahc)
+  {
+    a.dbg = dbg_buf.as<unsigned long long>(4ull * ng + 4);
+    HIP_CHECK(hipMemsetAsync(a.dbg, 0, (4ull * ng + 4) * 8, st));
+  }
   HIP_CHECK(hipMemsetAsync(a.err, 0, 16, st));
   hipLaunchKernelGGL(k_ahc_set_labels, dim3(nbk(n)), dim3(256), 0, st, ks, n, a.comp);
   hipLaunchKernelGGL(k_ahc_group, dim3(ng), dim3(AT), 0, st, a);
@@ -1031,6 +1068,23 @@ void ahc_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluste
   HIP_CHECK(hipMemcpyAsync(&total, newoff + ng, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  if (dbg_ahc)
+  {
+    // the group that took longest: its merges, the ordered additions on its critical path and what one of them cost
+    std::vector<unsigned long long> h(4ull * ng);
+    HIP_CHECK(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    uint32_t gm = 0;
+    unsigned long long all_adds = 0, all_chain = 0;
+    for (uint32_t g = 0; g < ng; ++g)
+    {
+      if (h[4 * g + 3] > h[4 * gm + 3]) gm = g;
+      all_adds += h[4 * g + 2];
+      all_chain += h[4 * g + 1];
+    }
+    fprintf(stderr, "[ahc] %u groups, %llu ordered additions in all (%llu on the groups' critical paths); slowest group %u: %.3f ms, %llu merges, %llu additions of which %llu depend on each other: %.1f ns of kernel time per dependent addition, %.2f us per merge\n",
+            ng, all_adds, all_chain, gm, (double) h[4 * gm + 3] * 1e-5, h[4 * gm], h[4 * gm + 2], h[4 * gm + 1], h[4 * gm + 1] ? (double) h[4 * gm + 3] * 10.0 / (double) h[4 * gm + 1] : 0.0,
+            h[4 * gm] ? (double) h[4 * gm + 3] * 1e-2 / (double) h[4 * gm] : 0.0);
+  }
   if (err) throw bk_error(BK_ERR_LIMIT, "AHC: point/entry pool of a component overflowed (very deep merge chain)");
   uint32_t *oidx = cb.idx2.as<uint32_t>((uint64_t) total + 1), *ogof = cb.gof2.as<uint32_t>((uint64_t) total + 1);
   uint64_t *ogoff = cb.goff2.as<uint64_t>((uint64_t) ng + 1);

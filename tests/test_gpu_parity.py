@@ -288,6 +288,54 @@ def test_wgs_shape_full_size_620M_records_vs_the_cpu_oracle():
     ctx.close()
 
 
+def test_ahc_default_mode_on_the_wgs_shape_vs_oracle():
+    """Default mode (exact UPGMA replay of src/util_cluster.cc) on the hg19 WGS shape the bench times: 3 M records, same-chromosome
+    groups of ~800 pairs, every stage against the CPU oracle."""
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    contigs, cols = synth_gpu.make_wgs(3_000_000, 2025, dev)
+    ctx = capi.Context(contigs)
+    ctx.attach_device(abi.device_ptrs(cols), cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+    w, nv = ctx.run(qual=20, fast=False)
+    o = pyoracle.Oracle(contigs, synth_gpu.to_numpy_cols(cols))
+    ow, rc = o.run(20, fast=False)
+    assert rc == 0 and w == ow and nv > 100
+    _compare_stages(ctx, o)
+    ctx.close()
+    o.close()
+
+
+def test_wgs_shape_full_size_default_mode_finishes_and_repeats():
+    """What `BreakID` without -fast does on BASELINE.json configs[1] (620 M records): the exact UPGMA replay finishes (its pools are
+    per connected component of the d <= T graph, and the components of this shape stay at a few dozen pairs) - the same bytes from
+    two runs and the invariants of the cluster table; no CPU implementation can be run at this size (the reference needs N^2 doubles
+    per group: 218 GB for one same-chromosome group)."""
+    import zlib
+    import torch
+    from breakid_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 150 * (1 << 30):
+        pytest.skip("needs ~150 GB of free HBM (table, generator temporaries)")
+    contigs, cols = synth_gpu.make_wgs(620_000_000, 12346, dev)
+    torch.cuda.empty_cache()
+    ptrs = abi.device_ptrs(cols)
+    ctx = capi.Context(contigs)
+    crcs = []
+    for rep in range(2):
+        ctx.attach_device(ptrs, cols["n"], cols["n_cigar_words"], cols["n_aux_bytes"])
+        w, n_valid = ctx.run(qual=20, fast=False)
+        cl, _ = ctx.fetch(abi.STAGE_CLUSTERS)
+        crcs.append(zlib.crc32(cl.tobytes()))
+    assert crcs[0] == crcs[1] and n_valid > 100_000
+    clustered, goff = ctx.fetch(abi.STAGE_CLUSTERED)
+    assert int(cl["n_drp"].sum()) == len(clustered) and len(goff) - 1 == 300
+    assert np.all(cl["p1_min"] <= cl["p1_mean"]) and np.all(cl["p1_mean"] <= cl["p1_max"])
+    assert np.all(np.diff(cl["group"].astype(np.int64)) >= 0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("fast", [True, False])
 def test_panel_shape_vs_oracle(fast):
     """BASELINE.json configs[3] at test size: reads piled over fusion loci, ~20 % split reads whose clip points
