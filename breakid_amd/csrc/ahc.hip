@@ -260,7 +260,7 @@ struct AhcArgs
   uint32_t *out_idx_local, *out_cl;    // n each, group-local regions starting at goff[g]
   uint32_t *err;
   uint32_t ng;
-  // (BK_DEBUG_AHC) per group: [0] merges, [1] sum over the merges of the longest chain of ordered additions (the largest m * n of
+  // (BK_DEBUG=ahc) per group: [0] merges, [1] sum over the merges of the longest chain of ordered additions (the largest m * n of
   // a (new node, root) pair: those additions depend on each other), [2] sum of all additions, [3] 10 ns ticks in the kernel
   unsigned long long *dbg;
 };
@@ -1051,7 +1051,7 @@ void ahc_cluster_all(const bk_pair *pairs, PairList &L, double w, DevBuf &cluste
   a.out_cl = ab.out_cl.as<uint32_t>(n);
   a.err = ab.err.as<uint32_t>(4);
   a.ng = ng;
-  static const bool dbg_ahc = getenv("BK_DEBUG_AHC") != nullptr;
+  static const bool dbg_ahc = bk_debug("ahc");
   DevBuf dbg_buf;
   a.dbg = nullptr;
   if (dbg_ahc)

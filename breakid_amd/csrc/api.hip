@@ -835,11 +835,6 @@ struct LanePlan
 {
   std::vector<int> lane_of;
 };
-static bool lane_bulk()
-{
-  static const bool b = getenv("BREAKID_LANE_BULK") && atoi(getenv("BREAKID_LANE_BULK")) != 0;
-  return b;
-}
 static LanePlan plan_blind(const bk_ctx *ctx, int K)
 {
   const uint32_t ng = ctx->jr.n_groups;
@@ -847,31 +842,13 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
   std::iota(order.begin(), order.end(), 0u);
   auto size_of = [&](uint32_t g) { return ctx->gstart_host[g + 1] - ctx->gstart_host[g]; };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size_of(a) > size_of(b); });
-  static const double wexp = getenv("BREAKID_LANE_WEIGHT_EXP") ? atof(getenv("BREAKID_LANE_WEIGHT_EXP")) : 2.0;
-  static const int solo_env = getenv("BREAKID_LANE_SOLO") ? atoi(getenv("BREAKID_LANE_SOLO")) : 0;
-  const int solo = std::max(0, std::min(solo_env, K - 1));
+  constexpr double wexp = 2.0;  // longest-processing-time on size^2
   LanePlan p;
   p.lane_of.assign(ng, 0);
   std::vector<double> load(K, 0.0);
   // sharded sample: this rank only masks and clusters the groups it owns (bk_shard_own_groups); the others belong to no lane
   const bool owned_only = !ctx->own_groups.empty();
   if (owned_only && ctx->own_groups.size() != ng) throw bk_error(BK_ERR_ARG, "bk_shard_own_groups: group count changed");
-  // lane 0 = the many groups of ordinary size (their sorts end after a few partition levels), lanes 1 .. K-1 = the outliers in size
-  // (on a WGS sample the same-chromosome groups: the ones whose sorts run into introsort's depth limit, i.e. ~36 launch-bound
-  // levels and lone-wave heaps): a lane that holds one of them pays those levels for all of its groups
-  const bool bulk = lane_bulk() && K >= 3;
-  uint64_t median = 0;
-  if (bulk)
-  {
-    std::vector<uint64_t> sz;
-    for (uint32_t g = 0; g < ng; ++g)
-      if (size_of(g) && !(owned_only && !ctx->own_groups[g])) sz.push_back(size_of(g));
-    if (!sz.empty())
-    {
-      std::nth_element(sz.begin(), sz.begin() + sz.size() / 2, sz.end());
-      median = sz[sz.size() / 2];
-    }
-  }
   for (uint32_t i = 0; i < ng; ++i)
   {
     const uint32_t g = order[i];
@@ -880,28 +857,10 @@ static LanePlan plan_blind(const bk_ctx *ctx, int K)
       p.lane_of[g] = -1;
       continue;
     }
-    int l;
-    if (bulk)
-    {
-      if (size_of(g) > 2 * median && size_of(g) > 16384)
-      {
-        l = 1;
-        for (int k = 2; k < K; ++k)
-          if (load[k] < load[l]) l = k;
-        load[l] += std::pow((double) size_of(g), wexp);
-      }
-      else
-        l = 0;
-    }
-    else if ((int) i < solo)
-      l = (int) i;
-    else
-    {
-      l = solo;
-      for (int k = solo + 1; k < K; ++k)
-        if (load[k] < load[l]) l = k;
-      load[l] += std::pow((double) size_of(g), wexp);
-    }
+    int l = 0;
+    for (int k = 1; k < K; ++k)
+      if (load[k] < load[l]) l = k;
+    load[l] += std::pow((double) size_of(g), wexp);
     p.lane_of[g] = l;
   }
   return p;
@@ -913,7 +872,7 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
   // in units of one pop of a lone wave in LDS (~0.15 us): a pair costs a lane ~0.15 ns in the two sorts that are left (most of a
   // lane's time outside the heaps is a fixed number of launches), an element of a heap segment beyond what fits the LDS of a
   // CU costs twice as much (the hybrid loop: 0.30 us per pop while the heap's tail is in global memory)
-  static const double per_pair = getenv("BREAKID_LANE_PAIR_COST") ? atof(getenv("BREAKID_LANE_PAIR_COST")) : 0.001;
+  constexpr double per_pair = 0.001;
   auto heap_cost = [](uint32_t m) { return (double) m + (m > 40947u ? 1.0 * (double) (m - 40947u) : 0.0); };
   std::vector<uint32_t> order(ng);
   std::iota(order.begin(), order.end(), 0u);
@@ -926,16 +885,9 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
   p.lane_of.assign(ng, 0);
   std::vector<double> mx(K, 0.0), my(K, 0.0), pairs(K, 0.0);
   auto cost = [&](int l) { return x_sorts * mx[l] + my[l] + per_pair * pairs[l]; };  // x_sorts: how many sorts by x are left (one by y)
-  const bool bulk = lane_bulk() && K >= 3;
   for (uint32_t g : order)
   {
-    if (bulk && hx[g] == 0 && hy[g] == 0)
-    {
-      p.lane_of[g] = 0;  // never ran into the depth limit: stays with the groups whose sorts end after a few levels
-      pairs[0] += (double) sizes[g];
-      continue;
-    }
-    const int l0 = bulk ? 1 : 0;
+    const int l0 = 0;
     int best = l0;
     double best_cost = 0;
     for (int l = l0; l < K; ++l)
@@ -953,7 +905,7 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
     pairs[best] += (double) sizes[g];
     p.lane_of[g] = best;
   }
-  if (getenv("BK_DEBUG_LANES"))
+  if (bk_debug("lanes"))
     for (int l = 0; l < K; ++l)
     {
       fprintf(stderr, "[lanes] lane %d: max heap x %.0f y %.0f, %.0f pairs, cost %.0f; heavy groups:", l, mx[l], my[l], pairs[l], cost(l));
@@ -968,10 +920,9 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
 {
   const uint32_t ng = ctx->jr.n_groups;
   // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), so more lanes
-  // than streams are possible: the lanes share S streams (BREAKID_LANE_STREAMS; measured worse than a stream each as soon as two
+  // than streams are possible: the lanes share S streams (at most twelve; measured worse than a stream each as soon as two
   // lanes' other kernels queue behind each other: 12 lanes on 12 / 4 / 3 / 2 streams 31.6 / 31.2 / 35.0 / 40.2 ms).
-  static const int lane_streams_env = getenv("BREAKID_LANE_STREAMS") ? atoi(getenv("BREAKID_LANE_STREAMS")) : 12;
-  static const bool adapt_env = !(getenv("BREAKID_LANE_ADAPT") && atoi(getenv("BREAKID_LANE_ADAPT")) == 0);
+  constexpr int lane_streams_max = 12;
   auto make_lanes = [&](int K, int S) {
     while ((int) ctx->lanes.size() < K - 1)
     {
@@ -983,7 +934,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   };
   bool use_svc = sort_service_on() && fast;
   int K = lanes_wanted(use_svc);
-  int S = use_svc ? std::max(1, std::min(lane_streams_env, K)) : K;
+  int S = use_svc ? std::max(1, std::min(lane_streams_max, K)) : K;
   make_lanes(K, S);
   std::vector<hipStream_t> stage_streams{ctx->st};
   for (int k = 0; k < S - 1; ++k) stage_streams.push_back(ctx->lanes[k]->st);
@@ -996,7 +947,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
     S = K;
     make_lanes(K, S);
   }
-  const bool adapt = adapt_env && !use_svc;  // (the service does not report the groups' longest heap segments back to the host)
+  const bool adapt = !use_svc;  // (the service does not report the groups' longest heap segments back to the host)
   auto lane_cb = [&](int l) -> ClusterBufs & { return l == 0 ? ctx->cb : ctx->lanes[l - 1]->cb; };
   auto lane_st = [&](int l) { const int k = l % S; return k == 0 ? ctx->st : ctx->lanes[k - 1]->st; };
   auto lane_list = [&](int l) -> PairList & { return l == 0 ? ctx->listA : ctx->lanes[l - 1]->list; };
@@ -1020,7 +971,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   auto in_lanes = [&](auto body) {
     std::vector<std::string> err(K);
     std::vector<int> code(K, BK_OK);
-    static const bool dbg_lanes = getenv("BK_DEBUG_LANES") != nullptr;
+    static const bool dbg_lanes = bk_debug("lanes");
     const auto t_start = std::chrono::steady_clock::now();
     auto guarded_body = [&](int l) {
       try
@@ -1059,7 +1010,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
     merge_lists_many(ls.data(), cl_out ? cs.data() : nullptr, K, out, cl_out, ctx->st);
   };
   const bk_pair *pairs = ctx->jr.pairs;
-  static const bool dbg_phases = getenv("BK_DEBUG_LANES") != nullptr;
+  static const bool dbg_phases = bk_debug("lanes");
   const auto tp0 = std::chrono::steady_clock::now();
   auto phase = [&](const char *what) {
     if (dbg_phases) fprintf(stderr, "[lanes] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
@@ -1073,16 +1024,16 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   }
   else
   {
-    // part 1: sorts 1-3, observed.  BREAKID_LANE_SPLIT=2 deals again after the second sort already (x from the first sort, y from the
-    // second, three sorts left): measured worse - 42.0 ms against 38.1 - because the heaps of the FIRST sort by x (short, on the
-    // unmasked list) say little about the later ones: the lanes of the second part then end between 12.8 and 26 ms
-    static const bool split_early = getenv("BREAKID_LANE_SPLIT") && atoi(getenv("BREAKID_LANE_SPLIT")) == 2;
+    // part 1: sorts 1-3, observed.  (Dealing again after the second sort already - x from the first sort, y from the second, three
+    // sorts left - was measured worse, 42.0 ms against 38.1: the heaps of the FIRST sort by x, short, on the unmasked list, say
+    // little about the later ones.)
+    constexpr bool split_early = false;
     in_lanes([&](int l) {
       ClusterBufs &cb = lane_cb(l);
       cb.heavy_x.assign(ng, 0u);
       cb.heavy_y.assign(ng, 0u);
       cb.observe = true;
-      cb.se.heavy_all = lane_bulk();
+      cb.se.heavy_all = false;
       remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>(), ctx->gstart_host.data(), keep[l].data());
       if (!split_early)
       {
@@ -1130,7 +1081,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   phase("lanes done");
   svc_stage.finish();  // (throws what a task reported)
   phase("service stopped");
-  if (use_svc && getenv("BK_DEBUG_LANES")) fprintf(stderr, "[svc] tasks: %u wide, %u narrow\n", ctx->svc.stats[0], ctx->svc.stats[1]);
+  if (use_svc && bk_debug("lanes")) fprintf(stderr, "[svc] tasks: %u wide, %u narrow\n", ctx->svc.stats[0], ctx->svc.stats[1]);
   // one list in group order again
   PairList &iso_m = ctx->lane_iso_m;
   PairList *iacc = ctx->lane_acc, *lacc = ctx->lane_acc + 2;
@@ -1773,7 +1724,7 @@ int bk_bam_decode_device_ctx(const char *path, int device, int mapq_min, bk_bam_
       stream_rare_path(c);
     else
       run_stream(c);  // file without chunked feed (records across BGZF blocks), or an output capacity estimated too small
-    if (getenv("BREAKID_FEED_STATS"))
+    if (bk_debug("feed"))
       fprintf(stderr, "[feed/stream] stream pass %s: %llu of %llu records went through k_stream while the file was still arriving\n", ok ? "overlapped" : "after the feed",
               (unsigned long long) (ok ? done : 0), (unsigned long long) cols.n);
   });

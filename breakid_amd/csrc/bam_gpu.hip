@@ -374,12 +374,12 @@ __global__ __launch_bounds__(256) void k_bam_emit(const uint8_t *__restrict__ da
 }
 
 // the columns of the n records a walk counted: once more over the length chains for where the records lie, then one lane per
-// record (BREAKID_FEED_EMIT_BY_BLOCK=1: the walk itself writes the columns, one lane per block - comparison)
+// record (the first form - the walk itself writes the columns, one lane per block - took 2.4-2.9 ms per chunk against 0.4)
 static void launch_emit(const uint8_t *dd, const BgzfBlock *db, uint32_t nb, uint32_t first_blk, uint32_t first_off, int32_t n_ref, BlockCount *dc, const uint64_t *nr, const uint64_t *nc,
                         const uint64_t *na, uint64_t rec0, uint64_t cig0, uint64_t aux0, const BamCols &c, const uint32_t *entry, uint64_t total, int allow_tail, uint64_t n, DevBuf &index,
                         hipStream_t st)
 {
-  if (n == 0 || getenv("BREAKID_FEED_EMIT_BY_BLOCK") != nullptr)
+  if (n == 0)
   {
     hipLaunchKernelGGL(k_bam_blocks<1>, dim3(cdiv(nb, 64)), dim3(64), 0, st, dd, db, nb, first_blk, first_off, n_ref, dc, nr, nc, na, rec0, cig0, aux0, c, entry, total, nullptr, allow_tail, nullptr);
     return;
@@ -586,13 +586,6 @@ struct StageCache
           return p;
         }
     }
-    if (getenv("BREAKID_FEED_STAGE_HOSTMALLOC"))  // (comparison: the runtime's own page-locked allocation)
-    {
-      void *q = nullptr;
-      if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-      memset(q, 0, bytes);
-      return (uint8_t *) q;
-    }
     uint8_t *p = (uint8_t *) aligned_alloc(2u << 20, (bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20));
     if (!p) return nullptr;
     (void) madvise(p, bytes, MADV_HUGEPAGE);  // fewer first-touch faults and a shorter registration where the kernel allows it
@@ -612,13 +605,10 @@ struct StageCache
   {
     std::lock_guard<std::mutex> g(mu);
     for (auto &e : idle)
-      if (getenv("BREAKID_FEED_STAGE_HOSTMALLOC"))
-        (void) hipHostFree(e.first);
-      else
-      {
-        (void) hipHostUnregister(e.first);
-        free(e.first);
-      }
+    {
+      (void) hipHostUnregister(e.first);
+      free(e.first);
+    }
     idle.clear();
   }
   int idle_of(uint64_t bytes)
@@ -738,7 +728,7 @@ struct StagePool
     for (auto &b : buf) HIP_CHECK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
     // the staging buffers of an earlier file are at hand: every chunk goes through them (a plain DMA each, no pageable copy on
     // the driver thread), and the producer hops over the block headers of a chunk as soon as it has read it
-    if (!getenv("BREAKID_FEED_FIRST_FROM_MAPPING") && stage_cache().idle_of(buf_bytes) >= NB)
+    if (stage_cache().idle_of(buf_bytes) >= NB)
     {
       first = 0;
       scan_off = b_lo;
@@ -1067,7 +1057,7 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     // A chunk's inflate kernel lasts as long as its slowest block (~3 ms) however few blocks it has, so the rate comes from
     // the chunks in flight: eight slots of 32 MiB when the process has a hardware queue for each of them (the runtime reads
     // GPU_MAX_HW_QUEUES when it starts, default 4: streams that share a queue make each other's launches wait), else four
-    // slots of 64 MiB.  BREAKID_FEED_SLOTS / _LAG / _CHUNK_MB override.
+    // slots of 64 MiB.  BREAKID_FEED_CHUNK_MB overrides the chunk size (tests: many chunks from a small file).
     const int hw_queues = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
     const bool wide = hw_queues >= 8;
     uint64_t chunk_bytes = wide ? 32ull << 20 : 64ull << 20;
@@ -1077,24 +1067,17 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
     int copy_threads = 8;
     if (const char *e = getenv("BREAKID_THREADS"))
       if (atoi(e) > 0) copy_threads = std::min(atoi(e), 16);
-    if (const char *e = getenv("BREAKID_FEED_COPY_THREADS"))
-      if (atoi(e) > 0) copy_threads = std::min(atoi(e), 32);
-    const bool stage_from_mapping = getenv("BREAKID_FEED_STAGE_MMAP") != nullptr;  // the staging threads copy out of the mapping (comparison)
+    const bool stage_from_mapping = false;  // (the staging threads read() the file; copying out of the mapping was the first form)
     // chunks in flight; how far the driver thread runs ahead of the totals it waits for (a slot is reused LAG + 1 .. NS chunks later)
     constexpr int NS_MAX = 12;
-    int NS = wide ? 8 : 4, LAG = wide ? 6 : 2;
-    if (const char *e = getenv("BREAKID_FEED_SLOTS"))
-      if (atoi(e) >= 2 && atoi(e) <= NS_MAX) NS = atoi(e);
-    if (const char *e = getenv("BREAKID_FEED_LAG"))
-      if (atoi(e) >= 1) LAG = atoi(e);
-    LAG = std::min(LAG, NS - 1);
+    const int NS = wide ? 8 : 4, LAG = wide ? 6 : 2;
     std::unique_ptr<FeedSlot> slot_store[NS_MAX];
     struct SlotRef  // slot[k] as before
     {
       std::unique_ptr<FeedSlot> *a;
       FeedSlot &operator[](int k) const { return *a[k]; }
     } slot = {slot_store};
-    const bool keep_slots = !getenv("BREAKID_FEED_NO_SLOT_CACHE");
+    const bool keep_slots = true;
     for (int k = 0; k < NS; ++k)
     {
       slot_store[k] = keep_slots ? slot_cache().take(device) : std::unique_ptr<FeedSlot>(new FeedSlot());
@@ -1324,12 +1307,12 @@ static void decode_chunked(const MappedFile &file, int device, bk_bam_dev *h, bk
       else
         for (DevBuf *b : {&slot[k].dfile, &slot[k].dblk, &slot[k].ddata, &slot[k].dslab, &slot[k].dcnt, &slot[k].dnr, &slot[k].dnc, &slot[k].dna, &slot[k].dscan, &slot[k].derr, &slot[k].dindex}) b->release();
     const double td2 = now_s2();
-    if (getenv("BREAKID_FEED_STATS"))
+    if (bk_debug("feed"))
       fprintf(stderr, "[feed/gpu] columns: %.3f s allocating / growing them, of which %.3f s waiting for the chunks in flight first\n", t_grow, t_grow_sync);
-    if (getenv("BREAKID_FEED_STATS"))
+    if (bk_debug("feed"))
       fprintf(stderr, "[feed/gpu] producer: %.3f s waiting for a free staging buffer, %.3f s copying (%d threads), %.3f s waiting for the header hops of the chunk before\n", pool.t_wait_buf, pool.t_copy, copy_threads,
               pool.t_scan_join);
-    if (getenv("BREAKID_FEED_STATS"))
+    if (bk_debug("feed"))
       fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks: file -> device table %.3f s (driver thread: setup %.3f s, waiting for a free slot %.3f s, waiting for staged bytes %.3f s, header hops %.3f s, buffers %.3f s, H2D calls %.3f s, kernel launches %.3f s, waiting for chunk totals + column growth %.3f s, emit launches %.3f s, final sync %.3f s, teardown %.3f s)\n",
               (unsigned long long) n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, t3 - t0, t_setup_done - t0, t_slot_wait, t_stage_wait, t_scan, t_alloc, t_h2d, t_launch, t_reserve, t_emit, t3 - t_end_loop, td2 - td0);
   }
@@ -1420,7 +1403,7 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
   cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
   cols->n_cigar_words = (uint32_t) tot[1];
   cols->n_aux_bytes = (uint32_t) tot[2];
-  if (getenv("BREAKID_FEED_STATS"))
+  if (bk_debug("feed"))
     fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %u BGZF blocks, records across blocks (one batch, boundaries guessed and verified): file -> device table %.3f s\n",
             (unsigned long long) n, file.size() / 1e6, nblk, now_s2() - t0);
 }
@@ -1540,14 +1523,9 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   chunk_bytes = std::max<uint64_t>(chunk_bytes, 70000) / 4096 * 4096 + 4096;  // a chunk is longer than the longest block
   // the inflates run LAG chunks ahead of the record phases (which follow each other: a chunk starts with the carry of the one before)
   constexpr int NS_MAX = 8;
-  int NS = 4, LAG = 2;
-  if (const char *e = getenv("BREAKID_FEED_PACKED_SLOTS"))
-    if (atoi(e) >= 2 && atoi(e) <= NS_MAX) NS = atoi(e);
-  if (const char *e = getenv("BREAKID_FEED_PACKED_LAG"))
-    if (atoi(e) >= 1) LAG = atoi(e);
-  LAG = std::min(LAG, NS - 1);
+  const int NS = 4, LAG = 2;
   SlotCacheOf<PackedSlot> *packed_cache = &packed_slot_cache();  // as slot_cache(): a finished decode leaves its slots to the next file
-  const bool keep_slots = !getenv("BREAKID_FEED_NO_SLOT_CACHE");
+  const bool keep_slots = true;
   struct SlotSet
   {
     std::unique_ptr<PackedSlot> p[NS_MAX];
@@ -1585,7 +1563,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   // the bytes of chunk k = file range [k C, (k + 1) C + slack) arrive in page-locked staging buffers, read() by the pool's threads
   // (the first three straight from the mapping while the buffers are being registered) - as in the aligned case
   const uint64_t nchunks = (file.size() + chunk_bytes - 1) / chunk_bytes;
-  StagePool pool(file.data(), getenv("BREAKID_FEED_STAGE_MMAP") ? -1 : file.descriptor(), file.size(), chunk_bytes, copy_threads, device, 0, nchunks, 0, file.size(), 1);
+  StagePool pool(file.data(), file.descriptor(), file.size(), chunk_bytes, copy_threads, device, 0, nchunks, 0, file.size(), 1);
   // chunk k -> slot: the blocks that start inside it: hop over their headers in the staged bytes, copy, inflate behind the reserve
   auto stage = [&](PackedSlot &s, uint64_t k) {
     if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_emit));
@@ -1725,7 +1703,7 @@ static void decode_packed_chunked(const MappedFile &file, int device, bk_bam_dev
   pool.shutdown();
   if (keep_slots)
     for (int k = 0; k < NS; ++k) packed_cache->give(device, std::move(slot.p[k]));  // (every stream is idle: quiesce above)
-  if (getenv("BREAKID_FEED_STATS"))
+  if (bk_debug("feed"))
     fprintf(stderr, "[feed/gpu] %llu records, %.1f MB file, %llu BGZF blocks in %llu chunks, records across blocks (boundaries guessed and verified per chunk): file -> device table %.3f s (driver thread: before the loop %.3f s, staging calls %.3f s, record phases %.3f s of which waiting for the chunk's totals %.3f s, after the loop %.3f s)\n",
             (unsigned long long) sink.n_rec, file.size() / 1e6, (unsigned long long) nblk_all, (unsigned long long) nchunk, now_s2() - t0, t_loop0 - t0, t_stage, t_records, t_sync, now_s2() - t_loop1);
 }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include "bk_debug.h"
 #include <thread>
 #include <vector>
 
@@ -524,7 +525,7 @@ static int bam_decode_impl(bk_bam *b, bk_soa *out, char *err, size_t errlen)
   out->n_cigar_words = (uint32_t) ncig;
   out->n_aux_bytes = (uint32_t) naux;
   b->t_decode_s = now_s() - t0;
-  if (getenv("BREAKID_FEED_STATS"))
+  if (bk_debug("feed"))
     fprintf(stderr, "[feed] %zu records, %.1f MB inflated: inflate %.3f s, decode %.3f s, %u threads, %s host columns\n", n, dsize / 1e6, b->t_inflate_s,
             b->t_decode_s, nt, b->tid.pinned ? "pinned" : "pageable");
   return BK_OK;

@@ -41,7 +41,7 @@
 namespace
 {
 constexpr int LIT_FAST = 11, DIST_FAST = 9;
-// symbol statistics (build with -DBGZF_STATS, run with BK_BGZF_STATS=1); off by default
+// symbol statistics (build with -DBGZF_STATS, run with BK_DEBUG=bgzf); off by default
 #ifdef BGZF_STATS
 __device__ unsigned long long g_bgzf_stats[8];
 __device__ unsigned long long g_lane_stats2[4];  // steps with a long code, lanes with a long code, walking lanes over all steps
@@ -964,7 +964,7 @@ void launch_bgzf_inflate(const uint8_t *file_dev, const BgzfBlock *blk_dev, uint
     hipLaunchKernelGGL(k_bgzf_resolve, dim3(nb), dim3(RESOLVE_THREADS), RES_WIN * 2, st, blk_dev, first, nb, out_dev, slab, ntok);
   }
 #ifdef BGZF_STATS
-  if (getenv("BK_BGZF_STATS"))
+  if (bk_debug("bgzf"))
   {
     unsigned long long h[8], z[8] = {0};
     HIP_CHECK(hipStreamSynchronize(st));

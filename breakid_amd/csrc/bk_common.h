@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "../../include/breakid_hip.h"
+#include "bk_debug.h"
 
 #define BK_WAVE 64
 
@@ -103,7 +104,7 @@ struct DevBuf
       {
         p = nullptr;
         (void) hipGetLastError();
-        if (getenv("BK_ABORT_ON_BAD_ALLOC"))  // (debugging: who asked - resolve the offsets with llvm-symbolizer -e libbreakid_hip.so)
+        if (bk_debug("alloc"))  // (debugging: who asked - resolve the offsets with llvm-symbolizer -e libbreakid_hip.so)
         {
           void *bt[24];
           const int nb = backtrace(bt, 24);

@@ -772,7 +772,7 @@ void bp_vote(const bk_split *sp, uint64_t nsp, bk_cluster *cl, uint64_t ncl, dou
   if (host[1] & 2u)
     throw bk_error(BK_ERR_COLLISION, "two different read names share one 64-bit name hash (their second hashes differ): the breakpoint vote would not be the reference's");
   if (host[1] & 1u) throw bk_error(BK_ERR_CIGAR, "error cigar: ");  // the reference's exit(-1), BreakID.cc:954-968
-  if (getenv("BK_DEBUG_BP"))
+  if (bk_debug("bp"))
   {
     std::vector<uint32_t> nm(ncl);
     std::vector<BpWork> wk(ncl);

@@ -458,7 +458,10 @@ int main(int argc, char *argv[])
   // one read of the file: BGZF inflate + record decode on the device, the stream pass of the hot path running on the chunks
   // already decoded while the rest of the file is still arriving (the reference reads the BAM twice, BreakID.cc:1929, :1414)
   if (!multi && !getenv("BREAKID_HOST_DECODE") && bk_bam_decode_device_ctx(inp_file.c_str(), device, qual, &dbam, &ctx, &nt, &names, &lens, err, sizeof err) == BK_OK)
+  {
     soa_where = BK_MEM_DEVICE;
+    bk_feed_release_caches();  // this process decodes one file: the feed's staging buffers and slots (1-2.5 GB of device memory) go back
+  }
   else if (!multi_from_file)
     host_decode();
   {

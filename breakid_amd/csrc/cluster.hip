@@ -108,39 +108,21 @@ __global__ __launch_bounds__(256) void k_fast_next(const uint32_t *__restrict__ 
   if (lo > ge - 1) lo = ge - 1;             // `i != n - 1`: the last element always breaks the window
   nxt[p] = (uint32_t) lo;
 }
-__global__ __launch_bounds__(256) void k_jump_double(const uint32_t *__restrict__ jin, uint64_t n, uint32_t *__restrict__ jout)
-{
-  uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  uint32_t a = jin[p];
-  jout[p] = a == END ? END : jin[a];
-}
 __global__ void k_mark_starts(const uint64_t *__restrict__ goff, uint32_t ng, uint32_t *__restrict__ mark)
 {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   if (goff[g + 1] > goff[g]) mark[goff[g]] = 1;
 }
-__global__ __launch_bounds__(256) void k_mark_jump(const uint32_t *__restrict__ jk, uint64_t n, uint32_t *__restrict__ mark)
-{
-  uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  if (mark[p])
-  {
-    uint32_t t = jk[p];
-    if (t != END) mark[t] = 1;
-  }
-}
 // ---- anchors of all windows: the positions a group's chain start -> nxt -> nxt ... visits ------------------------------
-// Pointer jumping over the whole list (k_jump_double / k_mark_jump: log2(largest group) launches each, every one a pass over n
-// elements) is kept as the reference statement (BK_FAST_JUMP_GLOBAL=1).  The chain is strictly increasing and never leaves its
-// group, so it is followed tile by tile instead:
+// (Pointer jumping over the whole list - log2(largest group) launches of doubling, as many of marking, every one a pass over n
+// elements - was the first form.)  The chain is strictly increasing and never leaves its group, so it is followed tile by tile:
 //   k_fw_exit   per tile of FW_TILE positions, in LDS: exit[p] = the first position of p's chain behind the tile (END if it ends
 //               inside)
 //   k_fw_chain  one thread per group: from the group's start, exit -> exit -> ...: the first anchor of every tile the chain
 //               visits is marked (at most one hop per tile)
 //   k_fw_mark   per tile, in LDS: exact 2^k-hop tables of the tile's part of nxt, then the marks spread from the seeds (group
-//               starts and chain entries) highest level first, as k_mark_jump does over the whole list
+//               starts and chain entries) highest level first
 constexpr uint32_t FW_TILE = 1024, FW_LEVELS = 10;
 __global__ __launch_bounds__(FW_TILE) void k_fw_exit(const uint32_t *__restrict__ nxt, uint64_t n, uint32_t *__restrict__ exitp)
 {
@@ -487,23 +469,11 @@ static void fast_pass(const bk_pair *pairs, PairList &L, int use_y, double w, De
   const uint64_t n = L.n;
   uint32_t *key = b.key.as<uint32_t>(n);
   hipLaunchKernelGGL(k_gather_key, dim3(nb(n)), dim3(256), 0, st, pairs, L.idx.get<uint32_t>(), n, use_y, key);
-  // a chain of anchors never leaves its group: 2^levels hops must cover the largest group, not the whole list
-  const uint64_t chain_bound = b.max_group_bound && b.max_group_bound < n ? b.max_group_bound : n;
-  int levels = 1;
-  while ((1ull << levels) < chain_bound) ++levels;
-  static const bool jump_global = getenv("BK_FAST_JUMP_GLOBAL") != nullptr;
-  uint32_t *jump = b.jump.as<uint32_t>(n * (uint64_t) (jump_global ? levels + 1 : 2));
+  uint32_t *jump = b.jump.as<uint32_t>(n * 2ull);
   hipLaunchKernelGGL(k_fast_next, dim3(nb(n)), dim3(256), 0, st, key, L.gof.get<uint32_t>(), L.goff.get<uint64_t>(), n, w, jump);
   uint32_t *mark = b.mark.as<uint32_t>(n + 1);
   HIP_CHECK(hipMemsetAsync(mark, 0, (n + 1) * 4, st));
   hipLaunchKernelGGL(k_mark_starts, dim3(cdiv(L.ng, 256)), dim3(256), 0, st, L.goff.get<uint64_t>(), L.ng, mark);
-  if (jump_global)
-  {
-    for (int k = 1; k <= levels; ++k)
-      hipLaunchKernelGGL(k_jump_double, dim3(nb(n)), dim3(256), 0, st, jump + (uint64_t) (k - 1) * n, n, jump + (uint64_t) k * n);
-    for (int k = levels; k >= 0; --k) hipLaunchKernelGGL(k_mark_jump, dim3(nb(n)), dim3(256), 0, st, jump + (uint64_t) k * n, n, mark);
-  }
-  else
   {
     uint32_t *exitp = jump + n;
     const unsigned tiles = (unsigned) cdiv(n, FW_TILE);

@@ -376,12 +376,13 @@ static uint64_t join_raw_pairs(const Cand *cand, uint64_t n_cand, double w, cons
   uint64_t *okey = b.okey.as<uint64_t>(cap);
   uint32_t *oval = b.oval.as<uint32_t>(cap);
   unsigned long long host[2] = {0, 0};
-  static const bool full_sort = getenv("BK_JOIN_FULL_SORT") != nullptr;  // all 64 bits from the start (debugging / comparison)
+  // BK_JOIN_ATTEMPT=1 / 2 starts at the second / third of the attempts below (tests: the fallbacks are otherwise only reached by
+  // read names that hash alike in their upper halves, or that more than 4096 candidates share)
+  static const int first_attempt = getenv("BK_JOIN_ATTEMPT") ? std::max(0, std::min(2, atoi(getenv("BK_JOIN_ATTEMPT")))) : 0;
   // attempt 0: candidates sorted by the upper half of the name hash, mixed runs put right; 1: by the whole hash; 2: by record index
   // and then stably by the whole hash, so that a run of ANY length is walked in record order as it lies (a read name that more than
   // 4096 candidates share: the selection of the next record inside a run is quadratic and gives up there)
-  static const bool ordered_only = getenv("BK_JOIN_ORDERED") != nullptr;  // (comparison / tests)
-  for (int attempt = ordered_only ? 2 : (full_sort ? 1 : 0); attempt < 3; ++attempt)
+  for (int attempt = first_attempt; attempt < 3; ++attempt)
   {
     if (n_cand)
     {

@@ -412,7 +412,7 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
     sum.mean = mean;
     sum.sd = sd;
     sum.groups.assign(gs, gs + ngs);
-    if (getenv("BK_DEBUG_MULTI"))
+    if (bk_debug("multi"))
     {
       uint64_t a = 0, b = 0, c = 0;
       for (uint32_t g = 0; g < ngs; ++g)
@@ -694,6 +694,7 @@ extern "C" int bk_multi_run_bam(const char *path, int n_gpus, int transport, int
     char e[512] = {0};
     const int drc = bk_bam_decode_device_part(path, dev, r, W, &bams[r], &cols, &nts[r], &nms[r], &lns[r], e, sizeof e);
     if (drc != BK_OK) throw bk_error(drc, e);
+    bk_feed_release_caches();  // (what is idle of the feed's staging buffers and slots: a rank decodes one part of one file)
     if (bk_init(dev, lns[r], nms[r], nts[r], &in.ctx) != BK_OK) throw bk_error(BK_ERR_NO_DEVICE, bk_last_error(nullptr));
     const int urc = bk_upload_records(in.ctx, &cols, BK_MEM_DEVICE);
     if (urc != BK_OK)

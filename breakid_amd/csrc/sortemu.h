@@ -37,8 +37,7 @@ struct SortEmuBufs
 {
   SortService *svc = nullptr;  // set (and running): std_sort_groups submits to it instead of launching the phases itself
   uint32_t svc_slot = 0xFFFFFFFFu, svc_epoch = 0;
-  DevBuf svc_hscratch;
-  DevBuf cnt, err, segs_a, segs_b, lr, segof, posL, posR, ck, scan_tmp, heap_list, heap_scratch, hr_cnt, hr_ck, hr_val, hr_f, hr_ord, rank32, scratch32, scratch32b, fin_list, fin_cnt, lvl, lv_tile, lv_segbase, lv_tileseg, lv_bar, chk_key0, chk_cnt, chk_bad, rk_a, rk_b;
+  DevBuf cnt, err, segs_a, segs_b, posL, posR, scan_tmp, heap_list, heap_scratch, scratch32, scratch32b, fin_list, lv_tile, lv_segbase, lv_tileseg, lv_bar, chk_key0, chk_cnt, chk_bad, rk_a, rk_b;
   prims::RadixBufs radix;
   // optional observer (host): heavy[g] = largest heapsort segment (elements) any sort through these buffers left to group g's
   // lone-wave heap kernels - what the lanes of api.hip balance on.  Set by the caller around the sorts it wants recorded.

@@ -287,7 +287,7 @@ template <class M> __device__ __forceinline__ bool sift_step(const M &mem, uint3
 
 constexpr uint32_t HEAP_PAD = 32;
 __device__ unsigned long long g_heap_iters[2];
-__device__ unsigned long long g_heap_phase[8];  // debug: 10 ns ticks of the phases of the largest ranked heap (BK_DEBUG_SORT)  // debug: loop iterations / pops of sort_heap (BK_DEBUG_SORT)
+__device__ unsigned long long g_heap_phase[8];  // debug: 10 ns ticks of the phases of the largest ranked heap (BK_DEBUG=sort)  // debug: loop iterations / pops of sort_heap (BK_DEBUG=sort)
 
 // the routines below are executed by one full wavefront (64 lanes, all active)
 // make_heap, bottom level first (nodes of one depth own disjoint subtrees)
@@ -1395,129 +1395,10 @@ template <int CLS> __global__ __launch_bounds__(CLS == 2 ? HEAP_BIG_THREADS : 64
     heap_small_body(sg.first, sg.last, key, idx, CLS == 0 ? stat : dyn, 64);
 }
 
-__device__ __forceinline__ uint32_t find_seg(const Seg *__restrict__ segs, uint32_t ns, uint32_t c)
-{
-  // segment that owns compact index c: largest s with segs[s].cbase <= c (segs[0].cbase == 0)
-  uint32_t lo = 0, hi = ns;
-  while (lo < hi)
-  {
-    uint32_t m = (lo + hi) >> 1;
-    if (segs[m].cbase <= c) lo = m + 1; else hi = m;
-  }
-  return lo - 1;
-}
-
-// lr[c] = (#L-stopper at c) | (#R-stopper at c) << 32 ; segof[c] = segment index
-// Live segments hold more than 16 elements, so the 256 consecutive compact indices of a block span at most 16
-// segments: one full binary search per block, then a 4-step search inside that window per lane.
-// (lvl != nullptr in all level kernels: live segment / element counts {ns, na} are read from device memory, the arguments
-// are only the bounds the grid was sized for)
-__global__ __launch_bounds__(256) void k_se_flags(const Seg *__restrict__ segs, uint32_t ns, const uint32_t *__restrict__ key, uint32_t na,
-                                                  unsigned long long *__restrict__ lr, uint32_t *__restrict__ segof, const uint32_t *__restrict__ lvl = nullptr)
-{
-  __shared__ uint32_t s_first;
-  if (lvl)
-  {
-    ns = lvl[0];
-    na = lvl[1];
-  }
-  if (blockIdx.x * blockDim.x >= na) return;
-  if (threadIdx.x == 0) s_first = find_seg(segs, ns, blockIdx.x * blockDim.x);
-  __syncthreads();
-  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= na) return;
-  uint32_t lo = s_first + 1, hi = s_first + 17 < ns ? s_first + 17 : ns;  // answer - 1 lies in [s_first, hi)
-  while (lo < hi)
-  {
-    uint32_t m = (lo + hi) >> 1;
-    if (segs[m].cbase <= c) lo = m + 1; else hi = m;
-  }
-  const uint32_t s = lo - 1;
-  segof[c] = s;
-  const Seg sg = segs[s];
-  unsigned long long v = 0;
-  if (sg.depth >= 0 && c > sg.cbase)
-  {
-    uint32_t k = key[sg.first + (c - sg.cbase)], pv = sg.pivot;
-    if (k >= pv) v |= 1ull;          // !(key < pivot): the left scan stops here
-    if (k <= pv) v |= 1ull << 32;    // !(pivot < key): the right scan stops here
-  }
-  lr[c] = v;
-}
-
-__global__ __launch_bounds__(256) void k_se_lists(const Seg *__restrict__ segs, const uint32_t *__restrict__ segof, const uint32_t *__restrict__ key, uint32_t na,
-                                                  const unsigned long long *__restrict__ LR, uint32_t *__restrict__ posL, uint32_t *__restrict__ posR, const uint32_t *__restrict__ lvl = nullptr)
-{
-  if (lvl) na = lvl[1];
-  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= na) return;
-  const Seg sg = segs[segof[c]];
-  if (sg.depth < 0 || c <= sg.cbase) return;
-  const uint32_t p = sg.first + (c - sg.cbase);
-  uint32_t k = key[p];
-  unsigned long long here = LR[c], base = LR[sg.cbase], end = LR[sg.cbase + (sg.last - sg.first)];
-  if (k >= sg.pivot)
-  {
-    uint32_t j = (uint32_t) here - (uint32_t) base;
-    posL[sg.cbase + 1 + j] = p;
-  }
-  if (k <= sg.pivot)
-  {
-    uint32_t nR = (uint32_t) (end >> 32) - (uint32_t) (base >> 32);
-    uint32_t jl = (uint32_t) (here >> 32) - (uint32_t) (base >> 32);
-    posR[sg.cbase + 1 + (nR - 1 - jl)] = p;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_se_swap(Seg *__restrict__ segs, const uint32_t *__restrict__ segof, uint32_t *__restrict__ key, uint32_t *__restrict__ idx, uint32_t na,
-                                                 const unsigned long long *__restrict__ LR, const uint32_t *__restrict__ posL, const uint32_t *__restrict__ posR, const uint32_t *__restrict__ lvl = nullptr)
-{
-  if (lvl) na = lvl[1];
-  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= na) return;
-  const uint32_t s = segof[c];
-  const Seg sg = segs[s];
-  if (sg.depth < 0) return;
-  const uint32_t first = sg.first, cb = sg.cbase;
-  unsigned long long base = LR[cb], end = LR[cb + (sg.last - first)];
-  uint32_t nL = (uint32_t) end - (uint32_t) base;
-  uint32_t nR = (uint32_t) (end >> 32) - (uint32_t) (base >> 32);
-  uint32_t m = nL < nR ? nL : nR;
-  uint32_t j = c - cb;
-  if (j > m) return;
-  const uint32_t INF = 0xFFFFFFFFu;
-  uint32_t lj = j < nL ? posL[cb + 1 + j] : INF;
-  uint32_t rj = j < nR ? posR[cb + 1 + j] : first;
-  bool cont = (j < nL) && (j < nR) && (lj < rj);
-  if (cont)
-  {
-    uint32_t k1 = key[lj], k2 = key[rj], x1 = idx[lj], x2 = idx[rj];
-    key[lj] = k2;
-    key[rj] = k1;
-    idx[lj] = x2;
-    idx[rj] = x1;
-  }
-  else
-  {
-    bool prev_cont = false;
-    uint32_t rprev = 0;
-    if (j > 0)
-    {
-      uint32_t lp = posL[cb + j];   // j-1 < m <= nL, nR
-      rprev = posR[cb + j];
-      prev_cont = lp < rprev;
-    }
-    if (j == 0)
-      segs[s].cut = lj;                               // J = 0: the left scan's first stop (exists: median-of-3 sentinel)
-    else if (prev_cont)
-      segs[s].cut = lj < rprev ? lj : rprev;          // cut = min(l_J, r_{J-1})
-  }
-}
-
-// ---- the same partition level in three passes over the keys instead of seven launches over five arrays ----------------
-// k_se_flags / scan / k_se_lists / k_se_swap materialise the stopper flags (8 B), their prefix sums (8 B read + 8 B written
-// twice), the owner of every compact index (4 B) and two position lists indexed per segment: ~96 B per live element and level.
-// Here a tile of LV_TILE compact indices recomputes its flags from the keys wherever it needs them:
+// ---- a partition level in three passes over the keys --------------------------------------------------------------------
+// (The first form materialised the stopper flags, their prefix sums, the owner of every compact index and two position lists in
+// seven launches: ~96 B per live element and level.)  A tile of LV_TILE compact indices recomputes its flags from the keys
+// wherever it needs them:
 //   k_lv_count   tile totals (#L-stoppers | #R-stoppers << 32)
 //   k_lv_sums    one workgroup: exclusive scan of the tile totals, grand total -> segbase[ns]
 //   k_lv_lists   running counts inside the tile -> the j-th L-stopper of the whole level goes to posL[j], the j-th R-stopper
@@ -1558,7 +1439,7 @@ __device__ __forceinline__ uint32_t lv_flags(const Seg &sg, uint32_t c, uint32_t
   }
   return v;
 }
-// one tile of a level pass: vb = tile number (blockIdx.x in the per-level launches, a loop variable in k_lv_persist); the shared
+// one tile of a level pass: vb = tile number (blockIdx.x); the shared
 // scratch belongs to the caller; every thread of the 256-thread workgroup calls it, ns / na are the level's live counts
 __device__ __forceinline__ void lv_count_tile(const Seg *segs, uint32_t ns, const uint32_t *key, uint32_t na, unsigned long long *tile_cnt,
                                               const uint32_t *tile_seg, uint32_t vb, LvTile *sh, uint32_t *s_scan)
@@ -1901,100 +1782,6 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_se_children_small(const Seg *
   __shared__ unsigned long long wsum[CHILD_THREADS / 64];
   __shared__ uint32_t s_max;
   children_small_body<CHILD_THREADS>(segs, lvl, out, fl, fin, key, idx, err, heap_list, tile_seg, wsum, &s_max);
-}
-
-// ---- every remaining level of the loop in ONE launch --------------------------------------------------------------------------
-// Once a level holds at most CHILD_FUSED segments the five launches of a level are bound by launch latency, not by work (a level
-// of a few tiles costs ~50 us of dependent launches and a host look every sixth level; the sorts of a WGS sample spend 25-30 of
-// their ~36 levels there).  k_lv_persist plays the same five phases - the same tile functions - for all levels that are left, in a
-// grid of at most LVP_MAX_WG resident workgroups that meet at a counter in global memory between the phases (~2-3.5 us for 8-32
-// workgroups, tools/ubench/gridbar.hip; a dependent launch costs ~10 us here).  The number of workgroups that take part follows
-// the live elements down (it never grows): a workgroup that is not needed any more leaves for good, and the last one runs the
-// tail of the loop with workgroup barriers only.
-constexpr uint32_t LVP_MAX_WG = 32, LVP_TILES_PER_WG = 4;
-struct LvPersist
-{
-  Seg *segs, *segs2;
-  uint32_t *lvl;  // [0] live segments [1] live elements [2] largest live segment [3] out: 1 when the loop ran out of levels
-  uint32_t *key, *idx;
-  unsigned long long *tile_cnt, *segbase;
-  uint32_t *posL, *posR, *tile_seg;
-  FinSeg *fl;
-  uint32_t *fin, *err;
-  uint2 *heap_list;
-  uint32_t *bar;  // zeroed by the host before the launch
-  uint32_t max_levels;
-};
-__device__ __forceinline__ void lvp_barrier(uint32_t *bar, uint32_t active, uint32_t &target)
-{
-  if (active == 1)
-  {
-    __syncthreads();  // one workgroup: its own stores are visible to it behind a workgroup barrier
-    return;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  target += active;
-  if (threadIdx.x == 0)
-  {
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__global__ __launch_bounds__(256) void k_lv_persist(LvPersist a)
-{
-  __shared__ LvTile sh;
-  __shared__ uint32_t s_scan[prims::WAVES];
-  __shared__ uint32_t s_key[LV_KEYS_LDS];
-  __shared__ unsigned long long s_base[3];
-  __shared__ unsigned long long wsum[256 / 64];
-  __shared__ uint32_t s_max;
-  Seg *cur = a.segs, *nxt = a.segs2;
-  uint32_t active = gridDim.x, target = 0;
-  const uint32_t b = blockIdx.x;
-  for (uint32_t level = 0;; ++level)
-  {
-    // (behind the barrier of the level before: WG 0 has left the counts of this level)
-    const uint32_t ns = __hip_atomic_load(a.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), na = __hip_atomic_load(a.lvl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ns == 0) return;
-    if (level >= a.max_levels)
-    {
-      if (b == 0 && threadIdx.x == 0) a.lvl[3] = 1;
-      return;
-    }
-    const uint32_t nt = (na + LV_TILE - 1) / LV_TILE;
-    uint32_t want = (nt + LVP_TILES_PER_WG - 1) / LVP_TILES_PER_WG;
-    want = want < 1 ? 1 : (want > active ? active : want);
-    if (b >= want) return;  // every workgroup computes the same `want` from the same counts: the barriers below count `want` arrivals
-    active = want;
-    for (uint32_t vb = b; vb < nt; vb += active)
-    {
-      lv_count_tile(cur, ns, a.key, na, a.tile_cnt, a.tile_seg, vb, &sh, s_scan);
-      __syncthreads();
-    }
-    lvp_barrier(a.bar, active, target);
-    if (b == 0) lv_sums_body<256>(a.tile_cnt, ns, na, a.segbase, wsum);
-    lvp_barrier(a.bar, active, target);
-    for (uint32_t vb = b; vb < nt; vb += active)
-    {
-      lv_lists_tile(cur, ns, a.key, na, a.tile_cnt, a.posL, a.posR, a.segbase, a.tile_seg, vb, &sh, s_scan, s_key);
-      __syncthreads();
-    }
-    lvp_barrier(a.bar, active, target);
-    for (uint32_t vb = b; vb < nt; vb += active)
-    {
-      lv_swap_tile(cur, ns, a.key, a.idx, na, a.segbase, a.posL, a.posR, a.tile_seg, vb, &sh, s_base);
-      __syncthreads();
-    }
-    lvp_barrier(a.bar, active, target);
-    if (b == 0) children_small_body<256>(cur, a.lvl, nxt, a.fl, a.fin, a.key, a.idx, a.err, a.heap_list, a.tile_seg, wsum, &s_max);
-    lvp_barrier(a.bar, active, target);
-    Seg *t = cur;
-    cur = nxt;
-    nxt = t;
-  }
 }
 
 #ifndef TL_UNROLL_N
@@ -2602,7 +2389,7 @@ __global__ __launch_bounds__(256) void k_se_window_sort(uint32_t *__restrict__ k
 }
 }  // namespace
 
-// BK_SORT_CHECK=1 (debugging): is idx still a permutation of 0 .. n-1 and does every element still carry its own key?
+// BK_DEBUG=sortcheck (debugging): is idx still a permutation of 0 .. n-1 and does every element still carry its own key?
 // (callers whose idx is not such a permutation must not set it)
 __global__ __launch_bounds__(256) void k_chk_count(const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ cnt, uint32_t *__restrict__ bad)
 {
@@ -2666,7 +2453,7 @@ static SvcParams svc_params(SortService &S)
     P.q[k].slots = S.slots[k].get<SvcTask>();
     P.q[k].seq = S.seq[k].get<uint32_t>();
     P.q[k].mask = S.cap[k] - 1;
-    P.q[k].pad = getenv("BREAKID_SVC_RELEASE") ? (uint32_t) atoi(getenv("BREAKID_SVC_RELEASE")) : 1u;  // (experiment) an agent-scope release in front of every push
+    P.q[k].pad = 1u;  // an agent-scope release in front of every push (sortsvc.inc, visibility)
   }
   P.error = ctl + 128;
   P.stats = ctl + 160;
@@ -2681,20 +2468,18 @@ static SvcParams svc_params(SortService &S)
     P.pos[k] = S.pos[k].get<uint32_t>();
     P.pos_cap[k] = S.pos_cap[k];
   }
-  P.timeout_ticks = getenv("BREAKID_SVC_TIMEOUT_MS") ? 100000ull * (unsigned long long) atoi(getenv("BREAKID_SVC_TIMEOUT_MS")) : SVC_TIMEOUT_TICKS;
+  P.timeout_ticks = SVC_TIMEOUT_TICKS;
   return P;
 }
 void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
 {
   if (running) return;
-  static const int n_wide_env = getenv("BREAKID_SVC_WIDE") ? atoi(getenv("BREAKID_SVC_WIDE")) : 0;
-  static const int n_narrow_env = getenv("BREAKID_SVC_NARROW") ? atoi(getenv("BREAKID_SVC_NARROW")) : 0;
   int dev = 0, cus = 0;
   HIP_CHECK(hipGetDevice(&dev));
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   // a quarter of the CUs to the wide workgroups (each takes a whole CU's LDS), two narrow ones on each of the others
-  const int n_wide = std::min(1024, n_wide_env > 0 ? n_wide_env : std::max(4, cus / 4));
-  const int n_narrow = n_narrow_env > 0 ? n_narrow_env : std::max(8, 2 * (cus - n_wide));
+  const int n_wide = std::min(1024, std::max(4, cus / 4));
+  const int n_narrow = std::max(8, 2 * (cus - n_wide));
   if (!quit_host)
   {
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&quit_host), SVC_H_WORDS * 4, hipHostMallocMapped));  // SvcParams::host
@@ -2731,7 +2516,7 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   pos_cap[1] = SVC_WIDE_MIN + 64;
   (void) pos[0].as<uint32_t>(2ull * pos_cap[0] * (uint64_t) n_wide);
   (void) pos[1].as<uint32_t>(2ull * pos_cap[1] * (uint64_t) n_narrow);
-  if (getenv("BK_DEBUG_SVC"))
+  if (bk_debug("svc"))
   {
     (void) dbg.as<uint32_t>(12 * 8192 + 32);
     HIP_CHECK(hipMemsetAsync(dbg.p, 0, (12 * 8192 + 32) * 4, after));
@@ -2776,7 +2561,7 @@ void SortService::stop()
   HIP_CHECK(hipMemcpy(h, ctl.get<uint32_t>() + 128, sizeof h, hipMemcpyDeviceToHost));
   for (int k = 0; k < 8; ++k) stats[k] = h[32 + k];
   DeferredFrees::end();
-  if (getenv("BK_DEBUG_SVC"))
+  if (bk_debug("svc"))
   {
     uint32_t c[128] = {};
     SvcJob j0 = {};
@@ -2885,7 +2670,7 @@ static void std_sort_groups_svc(uint32_t *key, uint32_t *idx, const uint32_t *go
         __builtin_ia32_pause();
     }
   }
-  if (getenv("BK_DEBUG_SVC"))
+  if (bk_debug("svc"))
   {
     SvcJob j;
     HIP_CHECK(hipMemcpy(&j, S.jobs.get<SvcJob>() + b.svc_slot, sizeof j, hipMemcpyDeviceToHost));
@@ -2911,7 +2696,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     {
       const int nq = getenv("BK_HEAP_NO_Q") != nullptr;
       HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_q), &nq, sizeof nq));
-      const int nhy = getenv("BK_HEAP_NO_HYBRID") != nullptr || nq;
+      const int nhy = nq;
       HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_heap_no_hybrid), &nhy, sizeof nhy));
       flag_set[dev] = true;
     }
@@ -2922,8 +2707,8 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
     std_sort_groups_svc(key, idx, gof, goff, ng, n, b, st);
     return;
   }
-  static const bool chk = getenv("BK_SORT_CHECK") != nullptr;
-  DevBuf &chk_key0 = b.chk_key0;  // (BK_SORT_CHECK: per buffer set, i.e. per lane and device)
+  static const bool chk = bk_debug("sortcheck");
+  DevBuf &chk_key0 = b.chk_key0;  // (BK_DEBUG=sortcheck: per buffer set, i.e. per lane and device)
   uint32_t *key0 = nullptr;
   if (chk)
   {
@@ -2986,16 +2771,12 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   if (ns)
   {
     hipLaunchKernelGGL(k_se_init_write, dim3(cdiv(ng, 256)), dim3(256), 0, st, goff, ng, cnt, segs, b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2), lvl);
-    // BK_SORT_OLD_LEVELS=1: the seven-launch partition level over materialised flags (debugging / comparison)
-    static const bool old_levels = getenv("BK_SORT_OLD_LEVELS") != nullptr;
-    unsigned long long *lr = old_levels ? b.lr.as<unsigned long long>((uint64_t) n + 1) : nullptr;
-    uint32_t *segof = old_levels ? b.segof.as<uint32_t>(n) : nullptr;
     unsigned long long *tile_cnt = b.lv_tile.as<unsigned long long>((uint64_t) n / LV_TILE + 2);
     unsigned long long *segbase = b.lv_segbase.as<unsigned long long>(max_segs + 1);
     uint32_t *tile_seg = b.lv_tileseg.as<uint32_t>((uint64_t) n / LV_TILE + 2);
     uint32_t *posL = b.posL.as<uint32_t>((uint64_t) n + 2), *posR = b.posR.as<uint32_t>((uint64_t) n + 2);
     int level = 0;
-    static const bool dbg_levels = getenv("BK_DEBUG_SORT") != nullptr;
+    static const bool dbg_levels = bk_debug("sort");
     double t_loop0 = 0;
     if (dbg_levels)
     {
@@ -3009,32 +2790,28 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       // how many levels may be queued before the host has to look: the segment count at most doubles per level and
       // the fused child kernel takes CHILD_FUSED segments
       // every live segment to a workgroup of its own for the rest of its introsort tree (k_se_tail) as soon as the largest one is
-      // small enough for a single CU to stream (BK_SORT_TAIL_MAX elements, default 2^19; BK_SORT_NO_TAIL=1: the level loop to the
-      // end) and the wide top of the trees is done (BK_SORT_TAIL_LEVEL, default 4: the first levels hold thousands of segments and
+      // small enough for a single CU to stream (2^19 elements; BK_SORT_NO_TAIL=1: the level loop to the
+      // end) and the wide top of the trees is done (from level 4 on: the first levels hold thousands of segments and
       // are one pass over everything for the device-wide kernels, while a single workgroup per ROOT would walk ~10^2 nodes; measured
       // with four lanes: level 2 41.3 ms, level 4 39.6, level 6 42.2 for the stage, 42.0-42.7 without the tail kernel)
-      static const bool no_tail = getenv("BK_SORT_NO_TAIL") != nullptr || getenv("BK_SORT_OLD_LEVELS") != nullptr;
-      static const uint32_t tail_max = getenv("BK_SORT_TAIL_MAX") ? (uint32_t) strtoul(getenv("BK_SORT_TAIL_MAX"), nullptr, 10) : (1u << 19);
-      static const int tail_level = getenv("BK_SORT_TAIL_LEVEL") ? atoi(getenv("BK_SORT_TAIL_LEVEL")) : 4;
+      static const bool no_tail = getenv("BK_SORT_NO_TAIL") != nullptr;
+      constexpr uint32_t tail_max = 1u << 19;
+      constexpr int tail_level = 4;
       if (!no_tail && level >= tail_level && max_live <= tail_max)
       {
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-        // spine rounds: a segment that is handed on is at most half of its parent and larger than FIN_MAX; in front of them
-        // BK_SORT_TAIL_WIDE rounds that play one level each (every node of the level at once, both sides handed on)
-        static const int wide_rounds = getenv("BK_SORT_TAIL_WIDE") ? atoi(getenv("BK_SORT_TAIL_WIDE")) : 0;
-        const int wide = level == 0 ? std::max(0, std::min(wide_rounds, 24)) : 0;
+        // spine rounds: a segment that is handed on is at most half of its parent and larger than FIN_MAX
         int rounds = 1;
         for (uint64_t sz = max_live; sz / 2 > FIN_MAX; sz /= 2) ++rounds;
-        rounds += wide;
         uint32_t *rc = b.lv_bar.as<uint32_t>((uint64_t) rounds + 2);
         HIP_CHECK(hipMemsetAsync(rc, 0, ((size_t) rounds + 2) * 4, st));
         HIP_CHECK(hipMemcpyAsync(rc, &ns, 4, hipMemcpyHostToDevice, st));
         const uint32_t cap = (uint32_t) std::min<uint64_t>(max_segs, (uint64_t) na / FIN_MAX + 1);
         for (int r = 0; r < rounds; ++r)
         {
-          const uint64_t bound = r < wide + 1 ? std::min<uint64_t>(cap, (uint64_t) ns << std::min(r, 20)) : cap;  // (a level at most doubles the segments)
+          const uint64_t bound = r < 1 ? std::min<uint64_t>(cap, ns) : cap;
           hipLaunchKernelGGL(k_se_tail_round, dim3((unsigned) std::max<uint64_t>(1, bound)), dim3(TL_THREADS), 0, st, (const Seg *) segs, (const uint32_t *) (rc + r), segs2, rc + r + 1, cap, key,
-                             idx, posL, posR, fin_list, fin, err, heap_list, r < wide ? 0 : 1);
+                             idx, posL, posR, fin_list, fin, err, heap_list, 1);
           std::swap(segs, segs2);
         }
         if (dbg_levels)
@@ -3044,51 +2821,8 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         }
         break;
       }
-      // the rest of the loop in one launch (k_lv_persist) once a level is down to BK_SORT_PERSIST_TILES tiles.  OFF unless that
-      // variable is set: measured on the 30x WGS shape (two lanes) it changes nothing - 42.7 ms for the stage without it, 43.1-43.4
-      // with thresholds of 4 / 16 / 64 tiles, 46.8 with 256 - because a level's kernels are busy for most of their 6-12 us
-      // (dependent loads inside them), not waiting for each other, and a grid barrier that crosses the XCDs' L2s costs as much as
-      // a launch boundary (tools/ubench/gridbar.hip); it does take load off the command processor (seven lanes: 64.8 -> 59.0 ms)
-      static const bool no_persist = getenv("BK_SORT_NO_PERSIST") != nullptr || getenv("BK_SORT_OLD_LEVELS") != nullptr;
-      static const uint32_t persist_tiles = getenv("BK_SORT_PERSIST_TILES") ? (uint32_t) atoi(getenv("BK_SORT_PERSIST_TILES")) : 0u;
-      if (!no_persist && persist_tiles && ns <= CHILD_FUSED && na / FIN_MAX <= CHILD_FUSED && cdiv(na, LV_TILE) <= persist_tiles)
-      {
-        if ((uint64_t) na / FIN_MAX + 1 > max_segs) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: segment list overflow");
-        const uint32_t cur[4] = {ns, na, 0u, 0u};
-        HIP_CHECK(hipMemcpyAsync(lvl, cur, 16, hipMemcpyHostToDevice, st));
-        if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-        uint32_t *bar = b.lv_bar.as<uint32_t>(4);
-        HIP_CHECK(hipMemsetAsync(bar, 0, 16, st));
-        LvPersist pa;
-        pa.segs = segs;
-        pa.segs2 = segs2;
-        pa.lvl = lvl;
-        pa.key = key;
-        pa.idx = idx;
-        pa.tile_cnt = tile_cnt;
-        pa.segbase = segbase;
-        pa.posL = posL;
-        pa.posR = posR;
-        pa.tile_seg = tile_seg;
-        pa.fl = fin_list;
-        pa.fin = fin;
-        pa.err = err;
-        pa.heap_list = heap_list;
-        pa.bar = bar;
-        pa.max_levels = (uint32_t) (200 - level);
-        const uint32_t wg = std::min<uint32_t>(LVP_MAX_WG, std::max<uint32_t>(1u, cdiv(cdiv(na, LV_TILE), LVP_TILES_PER_WG)));
-        hipLaunchKernelGGL(k_lv_persist, dim3(wg), dim3(256), 0, st, pa);
-        uint32_t now[4] = {0, 0, 0, 0};
-        HIP_CHECK(hipMemcpyAsync(now, lvl, 16, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (now[3] || now[0]) throw bk_error(BK_ERR_LIMIT, "std_sort_groups: runaway recursion");
-        if (dbg_levels) fprintf(stderr, "[sortemu]   levels %d.. in one launch (%u workgroups): %u segments, %u live elements, %.3f ms so far\n", level, wg, ns, na, now_ms() - t_loop0);
-        break;
-      }
       int batch = 0;
-      static const bool no_batch = getenv("BK_SORT_NO_BATCH") != nullptr;
-      static const int max_batch = getenv("BK_SORT_BATCH") ? atoi(getenv("BK_SORT_BATCH")) : 6;
-      if (!no_batch)
+      constexpr int max_batch = 6;
       {
         // a live segment holds more than FIN_MAX elements and the live elements never grow: na / FIN_MAX bounds the
         // segment count of every later level
@@ -3101,15 +2835,6 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
       {
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
         pivoted = false;
-        if (old_levels)
-        {
-          const unsigned nbk = cdiv(na, 256);
-          hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns, key, na, lr, segof, (const uint32_t *) nullptr);
-          prims::exclusive_scan<unsigned long long>(lr, lr, na, b.scan_tmp, st);
-          hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) nullptr);
-          hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) nullptr);
-        }
-        else
         {
           const unsigned nbt = cdiv(na, LV_TILE);
           hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns, key, na, tile_cnt, (const uint32_t *) nullptr, (const uint32_t *) tile_seg);
@@ -3134,18 +2859,10 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
         const uint32_t cur[2] = {ns, na};
         if (level > 0) HIP_CHECK(hipMemcpyAsync(lvl, cur, 8, hipMemcpyHostToDevice, st));  // (level 0: k_se_init_write left them; later batches: the children kernel did, but an unbatched level may lie between)
         if (!pivoted) hipLaunchKernelGGL(k_se_pivot, dim3(cdiv(ns, 256)), dim3(256), 0, st, segs, ns, key, idx, err, heap_list);
-        const unsigned nbk = cdiv(na, 256), nbt = cdiv(na, LV_TILE);
+        const unsigned nbt = cdiv(na, LV_TILE);
         uint32_t ns_bound = ns;
         for (int l = 0; l < batch; ++l)
         {
-          if (old_levels)
-          {
-            hipLaunchKernelGGL(k_se_flags, dim3(nbk), dim3(256), 0, st, segs, ns_bound, key, na, lr, segof, (const uint32_t *) lvl);
-            prims::exclusive_scan_devn<unsigned long long>(lr, lr, na, lvl + 1, b.scan_tmp, st);
-            hipLaunchKernelGGL(k_se_lists, dim3(nbk), dim3(256), 0, st, segs, segof, key, na, lr, posL, posR, (const uint32_t *) lvl);
-            hipLaunchKernelGGL(k_se_swap, dim3(nbk), dim3(256), 0, st, segs, segof, key, idx, na, lr, posL, posR, (const uint32_t *) lvl);
-          }
-          else
           {
             hipLaunchKernelGGL(k_lv_count, dim3(nbt), dim3(256), 0, st, segs, ns_bound, key, na, tile_cnt, (const uint32_t *) lvl, (const uint32_t *) tile_seg);
             hipLaunchKernelGGL(k_lv_sums, dim3(1), dim3(LV_SUM_THREADS), 0, st, tile_cnt, ns_bound, na, segbase, (const uint32_t *) lvl);
@@ -3190,7 +2907,7 @@ void std_sort_groups(uint32_t *key, uint32_t *idx, const uint32_t *gof, const ui
   const uint32_t nfin = nfin2[0] + nfin2[1];
   const uint32_t nh1 = e[3], max1 = e[1], n_big = e[4];  // heap segments of the level loop; those above HEAP_BIG_MIN
   const HeapSeg *hl = reinterpret_cast<const HeapSeg *>(heap_list);
-  static const bool dbg = getenv("BK_DEBUG_SORT") != nullptr;
+  static const bool dbg = bk_debug("sort");
   hent *hscratch = nullptr;
   uint32_t *scratch32 = nullptr, *scratch32b = nullptr;
   unsigned long long *rka = nullptr, *rkb = nullptr;  // scratch of the ranking inside the big heaps' own workgroups (wg_ranked_entries)

@@ -921,7 +921,6 @@ void launch_stream(const StreamArgs &a, hipStream_t st)
     HIP_CHECK(hipGetDevice(&dev));
     HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, 256, 0));
-    if (getenv("BK_STREAM_BPC")) per_cu = atoi(getenv("BK_STREAM_BPC"));
     resident = (unsigned) (per_cu < 1 ? 1 : per_cu) * (unsigned) prop.multiProcessorCount;
   }
   if (blocks > resident) blocks = resident;

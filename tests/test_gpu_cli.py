@@ -37,7 +37,7 @@ def test_cli_txt_outputs_match_reference(golden_dir, name, mode):
         side = synth.write_side_files(ds, tmp, refgene_lines=refgene)
         prefix = os.path.join(tmp, "out")
         cmd = [BIN, "-i", bam, "-o", prefix, "-n", side["nib"], "-all"] + (["-fast"] if mode == "fast" else [])
-        env = dict(os.environ, BREAKID_INSTALLDIR=side["install"], BREAKID_FEED_STATS="1")
+        env = dict(os.environ, BREAKID_INSTALLDIR=side["install"], BK_DEBUG="feed")
         if host:
             env["BREAKID_HOST_DECODE"] = "1"
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)

@@ -293,15 +293,9 @@ def test_device_decode_in_chunks_equals_one_chunk():
         p = os.path.join(t, "a.bam")
         ds.write_bam(p, aligned=True)
         size = os.path.getsize(p)
-        # (chunk size, slots, lag, emit by block, staging out of the mapping): the default, a fifth of the file, a few blocks per chunk;
-        # eight slots with the driver six chunks ahead (what the command line runs with); the one-lane-per-block emit and the staging
-        # threads copying out of the mapping (both kept for comparison; more than three chunks, so that the staging pool runs)
-        for mb, slots, lag, by_block, from_map in ((None, None, None, False, False), (size / 5 / 1048576.0, None, None, False, False), (0.07, None, None, False, False),
-                                                   (0.07, 8, 6, False, False), (0.07, 3, 1, False, False), (size / 5 / 1048576.0, None, None, True, False),
-                                                   (size / 9 / 1048576.0, None, None, False, True)):
-            env = {"BREAKID_FEED_CHUNK_MB": None if mb is None else repr(mb), "BREAKID_FEED_SLOTS": None if slots is None else str(slots),
-                   "BREAKID_FEED_LAG": None if lag is None else str(lag), "BREAKID_FEED_EMIT_BY_BLOCK": "1" if by_block else None,
-                   "BREAKID_FEED_STAGE_MMAP": "1" if from_map else None}
+        # chunk size: the default, a fifth and a ninth of the file (more than three chunks: the staging pool runs), a few blocks per chunk
+        for mb in (None, size / 5 / 1048576.0, size / 9 / 1048576.0, 0.07):
+            env = {"BREAKID_FEED_CHUNK_MB": None if mb is None else repr(mb)}
             for k, v in env.items():
                 if v is None:
                     os.environ.pop(k, None)
@@ -315,7 +309,7 @@ def test_device_decode_in_chunks_equals_one_chunk():
             got = _device_cols(table)
             assert table.contigs == contigs
             for k, _ in abi.SOA_COLS_ALL:
-                assert np.array_equal(got[k], ref[k]), (mb, slots, lag, k)
+                assert np.array_equal(got[k], ref[k]), (mb, k)
             table.close()
 
 
@@ -459,7 +453,7 @@ def test_stream_pass_overlapped_with_the_feed_matches_oracle(monkeypatch, capfd,
     ds = synth.make_cfg(31, contigs, 400_000, 60, 40, 600, jitter=250, read_len=100)
     ref = ds.to_soa()
     monkeypatch.setenv("BREAKID_FEED_CHUNK_MB", chunk_mb)
-    monkeypatch.setenv("BREAKID_FEED_STATS", "1")
+    monkeypatch.setenv("BK_DEBUG", "feed")
     with tempfile.TemporaryDirectory() as t:
         p = os.path.join(t, "a.bam")
         ds.write_bam(p, aligned=True)

@@ -502,12 +502,14 @@ def test_other_mapq_thresholds(golden_dir, qual):
     o.close()
 
 
-@pytest.mark.parametrize("lanes,solo,adapt", [(2, 0, 0), (2, 1, 0), (3, 1, 0), (4, 2, 0), (2, 0, 1), (3, 0, 1)])
-def test_lanes_of_groups_match_the_single_pass_and_the_oracle(lanes, solo, adapt):
-    """BREAKID_GROUP_LANES=K (bench.py and the command line run with it): the chromosome-pair groups are masked and clustered
-    in K disjoint sets on K streams / host threads (BREAKID_LANE_SOLO of the largest groups alone in a lane; BREAKID_LANE_ADAPT=1:
-    re-split after the second sort on the heap segments observed so far) and merged back into group order - every stage array must be the same as the oracle's.  Own process: the runtime reads GPU_MAX_HW_QUEUES
-    when it starts."""
+@pytest.mark.parametrize("lanes,service,hw_queues", [(2, 0, 16), (3, 0, 16), (4, 0, 16), (12, 1, 16), (3, 1, 16), (12, 1, 2)])
+def test_lanes_of_groups_match_the_single_pass_and_the_oracle(lanes, service, hw_queues):
+    """BREAKID_GROUP_LANES=K: the chromosome-pair groups are masked and clustered in K disjoint sets on K host threads and merged
+    back into group order - every stage array must be the same as the oracle's.  service = 0: every std::sort replay as launches on
+    the lane's stream (lanes dealt again on the heap segments observed after the third sort); 1: the sorts as jobs of the resident
+    sort service (the default).  (12, 1, 2): the process has two hardware queues, so the service's persistent kernels share one
+    with a lane's stream - the stage must notice (its probe), say so once and sort by launches.  Own process: the runtime reads
+    GPU_MAX_HW_QUEUES when it starts."""
     import subprocess
     import sys
     code = """
@@ -534,15 +536,18 @@ for st in (abi.STAGE_GROUP_KEYS, abi.STAGE_SCAN, abi.STAGE_ISO, abi.STAGE_CLUSTE
     if ao is not None: assert np.array_equal(ao, bo), st
 print("LANES_OK", nv)
 """ % ROOT_DIR
-    env = dict(os.environ, BREAKID_GROUP_LANES=str(lanes), BREAKID_LANE_SOLO=str(solo), BREAKID_LANE_ADAPT=str(adapt), GPU_MAX_HW_QUEUES="16", BREAKID_LANES_MIN_PAIRS="1000")
+    env = dict(os.environ, BREAKID_GROUP_LANES=str(lanes), BREAKID_SORT_SERVICE=str(service), GPU_MAX_HW_QUEUES=str(hw_queues), BREAKID_LANES_MIN_PAIRS="1000")
+    env.pop("BREAKID_QUIET", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LANES_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert ("shares a hardware queue" in r.stderr) == (hw_queues < 8 and service == 1), r.stderr[-1500:]
 
 
-@pytest.mark.parametrize("switch", ["BK_SORT_OLD_LEVELS", "BK_SORT_NO_BATCH", "BK_SORT_NO_TAIL", "BK_SORT_NO_TAIL=1,BK_SORT_PERSIST_TILES=64", "BK_SORT_TAIL_LEVEL=0,BK_SORT_TAIL_WIDE=5", "BK_SORT_TAIL_LEVEL=0", "BK_HEAP_RANK_PRE", "BK_HEAP_NO_Q", "BK_HEAP_CXX", "BK_HEAP_NO_RANKED", "BK_FAST_JUMP_GLOBAL", "BK_JOIN_FULL_SORT", "BK_JOIN_ORDERED", "BREAKID_NO_SIDE"])
+@pytest.mark.parametrize("switch", ["BREAKID_SORT_SERVICE=0", "BREAKID_SORT_SERVICE=0,BK_SORT_NO_TAIL=1", "BK_HEAP_NO_Q", "BREAKID_SORT_SERVICE=0,BK_HEAP_NO_Q=1", "BK_JOIN_ATTEMPT=1", "BK_JOIN_ATTEMPT=2", "BREAKID_NO_SIDE"])
 def test_earlier_statements_of_the_same_computation_still_agree(switch):
-    """the library keeps the earlier forms of the partition level, the pop loop, the anchored windows and the candidate sort
-    behind environment switches (comparison / debugging): each must give the reference's order and the oracle's stages.
+    """the behavioural switches the library keeps (INTEGRATION.md section 5): the std::sort replay as launches instead of jobs of
+    the resident service, its level loop without the tail rounds, the pop loop's earlier form, the mate join's fallback attempts,
+    the four candidate columns instead of the side rows - each must give the reference's order and the oracle's stages.
     Own process: the switches are read once."""
     import subprocess
     import sys

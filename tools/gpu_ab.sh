@@ -5,7 +5,7 @@ IFS="|"
 for v in ${VARIANTS:-"BK_NOP=1"}; do
   IFS=" "
   echo "== $v"
-  env $v BK_DEBUG_LANES=1 timeout -k 10 300 python3 bench.py --steps ${STEPS:-10} --warmup 1 --cpu-sample 0 --from-bam 0 > gpurun_out/ab/b.log 2> gpurun_out/ab/b.err || { tail -5 gpurun_out/ab/b.err; exit 1; }
+  env $v BK_DEBUG=lanes timeout -k 10 300 python3 bench.py --steps ${STEPS:-10} --warmup 1 --cpu-sample 0 --from-bam 0 > gpurun_out/ab/b.log 2> gpurun_out/ab/b.err || { tail -5 gpurun_out/ab/b.err; exit 1; }
   python3 -c "
 import json
 l=json.loads(open('gpurun_out/ab/b.log').read().strip().split('\n')[-1])

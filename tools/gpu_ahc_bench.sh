@@ -3,7 +3,7 @@
 # configs[1] itself; kernel summary of the 20 M run
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=16 BK_DEBUG_AHC=1
+export GPU_MAX_HW_QUEUES=16 BK_DEBUG=ahc
 O=gpurun_out/ahc
 mkdir -p $O
 timeout -k 10 200 python bench.py --mode ahc --records 1000000 --steps 5 --warmup 1 --from-bam 0 --cpu-sample 0 > $O/bench_1M_ahc.json 2> $O/bench_1M_ahc.err; echo "1M rc=$?"

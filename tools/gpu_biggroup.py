@@ -1,5 +1,5 @@
 """Run time of the hot path when the discordant pairs fall into few, large chr-pair groups (GPU box).
-usage: gpu_biggroup.py <records> <number of hg19 contigs>; BK_DEBUG_SORT=1 prints the sort emulation's per-sort statistics,
+usage: gpu_biggroup.py <records> <number of hg19 contigs>; BK_DEBUG=sort prints the sort emulation's per-sort statistics,
 BK_DEBUG_SORT_DUMP=<prefix> writes the keys and group offsets of the first five sorts."""
 import sys, time, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))

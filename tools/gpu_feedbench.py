@@ -71,7 +71,7 @@ if __name__ == "__main__":
             os.environ["BREAKID_THREADS"] = threads
         else:
             os.environ.pop("BREAKID_THREADS", None)
-        os.environ["BREAKID_FEED_STATS"] = "1"
+        os.environ["BK_DEBUG"] = "feed"
         t0 = time.perf_counter()
         contigs, cols, handle = capi.decode_bam(path, keep=True)
         t1 = time.perf_counter()

@@ -13,7 +13,7 @@ if __name__ == "__main__":
     else:
         import torch
         from breakid_amd import capi
-        os.environ["BREAKID_FEED_STATS"] = "1"
+        os.environ["BK_DEBUG"] = "feed"
         reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
         for rep in range(reps):
             torch.cuda.synchronize()

@@ -14,7 +14,7 @@ if __name__ == "__main__":
     else:
         import torch
         from breakid_amd import capi
-        os.environ["BREAKID_FEED_STATS"] = "1"
+        os.environ["BK_DEBUG"] = "feed"
         reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
         for mode in ("batch", "chunks"):
             if mode == "chunks":

@@ -1,5 +1,5 @@
 """Repeats one saved case of tools/gpu_sortfuzz.py (an .npz with key / off / exp): python tools/gpu_sortrepro.py <npz> [reps]
-BK_SORT_CHECK=1 makes std_sort_groups say after which phase the payloads stop being a permutation."""
+BK_DEBUG=sortcheck makes std_sort_groups say after which phase the payloads stop being a permutation."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

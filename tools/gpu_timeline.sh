@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 D=gpurun_out/timeline
 mkdir -p $D
-BK_DEBUG_LANES=1 BREAKID_GROUP_LANES=${LANES:-4} BREAKID_LANE_BULK=${BULK:-0} timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $D/raw -o tl -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > $D/bench.log 2> $D/bench.err
+BK_DEBUG=lanes BREAKID_GROUP_LANES=${LANES:-12} timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $D/raw -o tl -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > $D/bench.log 2> $D/bench.err
 cp $(find $D/raw -name "*kernel_trace.csv" | head -n 1) $D/kernel_trace.csv
 rm -rf $D/raw
 python3 - <<'PY'
