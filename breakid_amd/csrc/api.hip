@@ -8,6 +8,7 @@
 #include <chrono>
 
 #include "bk_common.h"
+#include <dirent.h>
 #include "prims.h"
 #include "stream.h"
 #include "join.h"
@@ -693,6 +694,73 @@ static bool sort_service_on()
 // by launches), and (b) probes every stream it is going to use after the kernels have started: an empty kernel that has not run
 // after 50 ms sends the whole stage back to the launch path (the service stops, the stream drains).
 __global__ void k_svc_probe() {}
+// Compute queues that exist on the device right now, over ALL processes (the kernel driver's sysfs: /sys/class/kfd/kfd/proc/<pid>/
+// queues/<n>/{gpuid,type}); -1 when that cannot be told.  Measured on MI355X: beyond 24 compute queues on a device - this process's
+// 16-17 plus a second process holding 8 or more - the driver maps the queues in turns, and persistent kernels whose submitters wait
+// for their turn leave jobs unfinished for seconds (tools/gpu_hold_queues.py: 4 streams held by a second process are fine, 8 are
+// not).  The service runs only while the census stays at or below that.
+static int kfd_compute_queues(int device)
+{
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int) sizeof bus, device) != hipSuccess) return -1;
+  unsigned dom = 0, b = 0, d = 0, f = 0;
+  if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return -1;
+  const unsigned long want_loc = (b << 8) | (d << 3) | f;
+  auto read_file = [](const std::string &path, std::string &out) {
+    FILE *fp = fopen(path.c_str(), "r");
+    if (!fp) return false;
+    char buf[4096];
+    const size_t n = fread(buf, 1, sizeof buf - 1, fp);
+    fclose(fp);
+    buf[n] = 0;
+    out = buf;
+    return true;
+  };
+  auto list_dir = [](const std::string &path, std::vector<std::string> &names) {
+    DIR *dp = opendir(path.c_str());
+    if (!dp) return false;
+    while (dirent *e = readdir(dp))
+      if (e->d_name[0] != '.') names.push_back(e->d_name);
+    closedir(dp);
+    return true;
+  };
+  // the device's gpu_id: the topology node with its PCI location
+  unsigned long gpu_id = 0;
+  {
+    std::vector<std::string> nodes;
+    if (!list_dir("/sys/class/kfd/kfd/topology/nodes", nodes)) return -1;
+    for (const std::string &n : nodes)
+    {
+      std::string props, id;
+      const std::string base = "/sys/class/kfd/kfd/topology/nodes/" + n;
+      if (!read_file(base + "/properties", props) || !read_file(base + "/gpu_id", id)) continue;
+      unsigned long loc = ~0ul, domain = ~0ul;
+      size_t p = props.find("location_id ");
+      if (p != std::string::npos) loc = strtoul(props.c_str() + p + 12, nullptr, 10);
+      p = props.find("domain ");
+      if (p != std::string::npos) domain = strtoul(props.c_str() + p + 7, nullptr, 10);
+      if (loc == want_loc && (domain == ~0ul || domain == dom) && strtoul(id.c_str(), nullptr, 10) != 0) gpu_id = strtoul(id.c_str(), nullptr, 10);
+    }
+  }
+  if (!gpu_id) return -1;
+  std::vector<std::string> procs;
+  if (!list_dir("/sys/class/kfd/kfd/proc", procs)) return -1;
+  int total = 0;
+  for (const std::string &pid : procs)
+  {
+    std::vector<std::string> qs;
+    const std::string qdir = "/sys/class/kfd/kfd/proc/" + pid + "/queues";
+    if (!list_dir(qdir, qs)) continue;  // (another user's process: not readable - and not on a GPU this process may use either)
+    for (const std::string &q : qs)
+    {
+      std::string g, t;
+      if (!read_file(qdir + "/" + q + "/gpuid", g) || !read_file(qdir + "/" + q + "/type", t)) continue;
+      if (strtoul(g.c_str(), nullptr, 10) == gpu_id && strtoul(t.c_str(), nullptr, 10) == 0) ++total;
+    }
+  }
+  return total;
+}
+constexpr int SVC_MAX_DEVICE_QUEUES = 24;
 static std::mutex g_svc_device_m[64];
 struct SvcStage
 {
@@ -708,7 +776,9 @@ struct SvcStage
     }
     if (!on) return;
     ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
-    if (!reachable(streams))
+    const int census = kfd_compute_queues(ctx->device);
+    if (bk_debug("lanes")) fprintf(stderr, "[lanes] compute queues on the device (all processes): %d\n", census);
+    if (census > SVC_MAX_DEVICE_QUEUES || !ctx->svc.narrow_running(0.05) || !reachable(streams))
     {
       ctx->svc.stop();
       on = false;
@@ -717,7 +787,7 @@ struct SvcStage
       if (!told && !getenv("BREAKID_QUIET"))
       {
         told = true;
-        fprintf(stderr, "[breakid] the resident sort service shares a hardware queue with a stream of its own stage (GPU_MAX_HW_QUEUES too low for the streams of this process): sorting by launches instead\n");
+        fprintf(stderr, "[breakid] the resident sort service shares a hardware queue with a stream of its own stage (GPU_MAX_HW_QUEUES too low for the streams of this process), or other processes hold hardware queues on this device: sorting by launches instead\n");
       }
       return;
     }
@@ -737,15 +807,27 @@ struct SvcStage
       HIP_CHECK(hipEventRecord(ctx->svc_probe[k], streams[k]));
     }
     const auto t0 = std::chrono::steady_clock::now();
-    for (size_t k = 0; k < streams.size(); ++k)
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    bool ok = true;
+    for (size_t k = 0; k < streams.size() && ok; ++k)
       for (;;)
       {
         const hipError_t e = hipEventQuery(ctx->svc_probe[k]);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) throw bk_error(BK_ERR_HIP, std::string("sort service probe: ") + hipGetErrorString(e));
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) return false;
+        if (since() > 0.05)
+        {
+          ok = false;
+          break;
+        }
       }
-    return true;
+    // An empty kernel per stream comes back within ~0.1-0.3 ms.  Milliseconds mean that the device's hardware queues are
+    // oversubscribed (other processes hold queues too: the scheduler then maps the queues in turns, and persistent kernels whose
+    // submitters wait for their turn crawl - measured with a second process holding 16 queues: the stage 3-6 times slower or a job
+    // that never finished) - no service then either.
+    const double took = since();
+    if (bk_debug("lanes")) fprintf(stderr, "[lanes] sort service probe: %zu streams in %.3f ms%s\n", streams.size(), took * 1e3, ok ? "" : " (gave up)");
+    return ok && took < 0.003;
   }
   void set(SortService *s)
   {

@@ -12,7 +12,7 @@ struct SortService
   DevBuf ctl, slots[2], seq[2], jobs, dbg, pos[2];
   uint32_t pos_cap[2] = {0, 0};
   uint32_t cap[2] = {0, 0};
-  hipStream_t st[2] = {nullptr, nullptr}, st_ctl = nullptr;
+  hipStream_t st[2] = {nullptr, nullptr}, quit_stream = nullptr;
   uint32_t *quit_host = nullptr;  // mapped host memory the workgroups poll
   uint32_t *quit_dev = nullptr;
   uint32_t cap32 = 0;
@@ -24,6 +24,9 @@ struct SortService
   // n_bound = elements of all lists that will be sorted while the service runs (sizes the task rings), max_group = the largest
   // group among them
   void start(uint64_t n_bound, uint64_t max_group, hipStream_t after);
+  // has a narrow workgroup started within `seconds`?  (No: the narrow kernel's stream shares its hardware queue with the wide
+  // kernel's and will wait behind it for ever.)
+  bool narrow_running(double seconds) const;
   // ends the kernels; throws when a task reported an error
   void stop();
   uint32_t new_slot() { return next_slot.fetch_add(1u); }

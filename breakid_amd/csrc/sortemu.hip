@@ -2474,6 +2474,7 @@ static SvcParams svc_params(SortService &S)
 void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
 {
   if (running) return;
+  quit_stream = after;  // (a stream of the stage that the stage probes: the word that ends the service is written by a kernel on it)
   int dev = 0, cus = 0;
   HIP_CHECK(hipGetDevice(&dev));
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2485,7 +2486,6 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&quit_host), SVC_H_WORDS * 4, hipHostMallocMapped));  // SvcParams::host
     HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&quit_dev), quit_host, 0));
     for (int k = 0; k < 2; ++k) HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&st_ctl, hipStreamNonBlocking));
     hipFuncAttributes fa;
     HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sort_service<true>)));
     // all of a CU's 160 KB but the kernel's static LDS; the ranked entries that fit (+ slot 0 and two zero slots), an odd count
@@ -2548,13 +2548,19 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   hipLaunchKernelGGL(k_sort_service<false>, dim3(n_narrow), dim3(256), SVC_NARROW_LDS, st[1], P);
   HIP_CHECK(hipGetLastError());
 }
+bool SortService::narrow_running(double seconds) const
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  volatile const uint32_t *flag = quit_host + SVC_H_NARROW;
+  while (*flag == 0u)
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+  return true;
+}
 void SortService::stop()
 {
   if (!running) return;
   running = false;
-  __atomic_store_n(quit_host, quit_word, __ATOMIC_SEQ_CST);
-  HIP_CHECK(hipMemcpyAsync(ctl.get<uint32_t>() + 192, quit_host, 4, hipMemcpyHostToDevice, st_ctl));
-  HIP_CHECK(hipStreamSynchronize(st_ctl));
+  hipLaunchKernelGGL(k_svc_quit, dim3(1), dim3(1), 0, quit_stream, ctl.get<uint32_t>() + 192, quit_word);
   HIP_CHECK(hipStreamSynchronize(st[0]));
   HIP_CHECK(hipStreamSynchronize(st[1]));
   uint32_t h[40] = {};
@@ -2613,15 +2619,13 @@ SortService::~SortService()
   if (running)
   {
     running = false;
-    if (quit_host) __atomic_store_n(quit_host, quit_word, __ATOMIC_SEQ_CST);
-    if (quit_host && st_ctl) (void) hipMemcpyAsync(ctl.get<uint32_t>() + 192, quit_host, 4, hipMemcpyHostToDevice, st_ctl);
+    if (quit_stream) hipLaunchKernelGGL(k_svc_quit, dim3(1), dim3(1), 0, quit_stream, ctl.get<uint32_t>() + 192, quit_word);
     for (int k = 0; k < 2; ++k)
       if (st[k]) (void) hipStreamSynchronize(st[k]);
     DeferredFrees::end();
   }
   for (int k = 0; k < 2; ++k)
     if (st[k]) (void) hipStreamDestroy(st[k]);
-  if (st_ctl) (void) hipStreamDestroy(st_ctl);
   if (quit_host) (void) hipHostFree(quit_host);
 }
 

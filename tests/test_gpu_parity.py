@@ -540,7 +540,12 @@ print("LANES_OK", nv)
     env.pop("BREAKID_QUIET", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LANES_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
-    assert ("shares a hardware queue" in r.stderr) == (hw_queues < 8 and service == 1), r.stderr[-1500:]
+    # (with 16 queues the stage may still decline the service - the test runner's own process holds hardware queues on the device
+    # too, and the stage counts them; without the service nothing is said)
+    if service == 0:
+        assert "shares a hardware queue" not in r.stderr, r.stderr[-1500:]
+    elif hw_queues < 8:
+        assert "shares a hardware queue" in r.stderr, r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("switch", ["BREAKID_SORT_SERVICE=0", "BREAKID_SORT_SERVICE=0,BK_SORT_NO_TAIL=1", "BK_HEAP_NO_Q", "BREAKID_SORT_SERVICE=0,BK_HEAP_NO_Q=1", "BK_JOIN_ATTEMPT=1", "BK_JOIN_ATTEMPT=2", "BREAKID_NO_SIDE"])
