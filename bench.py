@@ -73,8 +73,27 @@ def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: N fresh rank processes over RCCL on this node."""
     import socket
     import subprocess
-    import torch  # device_count() does not initialise the GPU (it must not: the children are started from here)
-    have = torch.cuda.device_count()
+    # The launcher does not touch the GPU runtime (it stays alive for the whole run beside the ranks it starts as fresh children):
+    # the devices are counted from the kernel driver's topology, narrowed by the *_VISIBLE_DEVICES variables.  Every rank checks
+    # again with its own runtime and refuses fewer devices than ranks.
+    have = 0
+    try:
+        for node in os.listdir("/sys/class/kfd/kfd/topology/nodes"):
+            try:
+                have += 1 if int(open("/sys/class/kfd/kfd/topology/nodes/%s/gpu_id" % node).read().strip() or "0") != 0 else 0
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        have = 0  # (no kernel driver: no GPU)
+    try:
+        usable = len([d for d in os.listdir("/dev/dri") if d.startswith("renderD") and os.access("/dev/dri/" + d, os.R_OK | os.W_OK)])
+        have = min(have, usable)  # (a container sees the whole topology but only its own devices' nodes)
+    except OSError:
+        have = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
     if have < n:
         sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node: refusing to run (a line with fewer ranks "
                          "than asked for would be mislabelled)\n" % (n, have))
@@ -131,7 +150,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     if torch.cuda.device_count() < world:
-        raise SystemExit("bench.py: %d ranks asked for, %d GPU(s) visible: one rank per GPU, no rank shares a device" % (world, torch.cuda.device_count()))
+        raise SystemExit("bench.py: %d ranks asked for, %d GPU(s) visible: refusing to run (one rank per GPU, no rank shares a device)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_shards = args.sharded == 1 or (args.sharded < 0 and world > 1)
@@ -254,7 +273,7 @@ def main():
         out = {
             "metric": "M reads/s clustered+split-scanned", "value": round(value, 3), "unit": "M records/s",
             "n_gpus": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "int32/u8 (+f64 sd replay)",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else None, "vs_baseline": None, "dtype": "int32/u8 (+f64 sd replay)",
             "data": "synthetic",
             "config": {"workload": (("configs[2]: the " if use_shards and args.scaling == "strong" and world > 1 else "configs[1]: ") + "30x WGS-shape synthetic table, hg19, 2x150bp, 5%% discordant, -%s clustering" if args.workload == "wgs" else
                                     "configs[3]: targeted-panel shape, 500 fusion loci x 2000x, 20%% split reads, 10%% discordant, -%s clustering") % args.mode,

@@ -34,13 +34,62 @@ struct Transport
 {
   int rank = 0, world = 1;
   virtual ~Transport() {}
+  // what this rank sent to the other ranks / took in from them, per kind of exchange (BK_DEBUG=multi prints it against DESIGN section
+  // 6's table: every per-record and per-pair stage is O(n / W) per rank)
+  struct Tally
+  {
+    uint64_t calls = 0, sent = 0, received = 0;
+  };
+  Tally tally[4];  // 0 host metadata (all-gather), 1 all-gather of device tables, 2 all-to-all, 3 all-reduce
+  std::map<std::string, Tally> by_step;
+  const char *step = "";
+  void count(int kind, uint64_t sent, uint64_t received)
+  {
+    tally[kind].calls += 1;
+    tally[kind].sent += sent;
+    tally[kind].received += received;
+    Tally &t = by_step[step];
+    t.calls += 1;
+    t.sent += sent;
+    t.received += received;
+  }
   // small host metadata: `bytes` from every rank, concatenated in rank order
-  virtual void allgather_host(const void *in, size_t bytes, void *out, hipStream_t st) = 0;
+  void allgather_host(const void *in, size_t bytes, void *out, hipStream_t st)
+  {
+    count(0, bytes * (size_t) (world - 1), bytes * (size_t) (world - 1));
+    do_allgather_host(in, bytes, out, st);
+  }
   // device buffers of rank-dependent size -> concatenation in rank order at recv (sizes[r] bytes from rank r)
-  virtual void allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) = 0;
+  void allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st)
+  {
+    uint64_t total = 0;
+    for (size_t v : sizes) total += v;
+    count(1, (uint64_t) sizes[rank] * (uint64_t) (world - 1), total - sizes[rank]);
+    do_allgatherv(send, recv, sizes, st);
+  }
   // send = world blocks (sb[d] bytes for rank d, back to back); recv = what every rank sent here, in rank order
-  virtual void alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) = 0;
-  virtual void allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) = 0;
+  void alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st)
+  {
+    uint64_t so = 0, ro = 0;
+    for (int r = 0; r < world; ++r)
+      if (r != rank)
+      {
+        so += sb[r];
+        ro += rb[r];
+      }
+    count(2, so, ro);
+    do_alltoallv(send, sb, recv, rb, st);
+  }
+  void allreduce_sum_u32(uint32_t *buf, size_t n, hipStream_t st)
+  {
+    const uint64_t ring = world > 1 ? 2ull * (uint64_t) (world - 1) * (n * 4ull) / (uint64_t) world : 0ull;  // what a ring moves per rank
+    count(3, ring, ring);
+    do_allreduce_sum_u32(buf, n, st);
+  }
+  virtual void do_allgather_host(const void *in, size_t bytes, void *out, hipStream_t st) = 0;
+  virtual void do_allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) = 0;
+  virtual void do_alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) = 0;
+  virtual void do_allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) = 0;
 };
 
 // ---- the rank threads of this process meet here: before every exchange (both transports), so that a rank that failed on its own
@@ -54,6 +103,7 @@ struct LocalHub
   int waiting = 0;
   uint64_t generation = 0;
   bool failed = false;
+  std::atomic<bool> failed_flag{false};  // the same, for the owners of communicators to poll without the lock
   std::vector<const void *> ptr;
   std::vector<std::vector<size_t>> blocks;  // alltoallv: blocks[r][d] = bytes rank r sends to rank d
   std::vector<std::vector<uint8_t>> host;
@@ -77,6 +127,7 @@ struct LocalHub
   {
     std::lock_guard<std::mutex> l(m);
     failed = true;
+    failed_flag.store(true);
     cv.notify_all();
   }
 };
@@ -91,22 +142,41 @@ struct RcclTransport : Transport
   {
     if (comm && !aborted.exchange(true)) (void) ncclCommDestroy(comm);
   }
-  // a collective is only queued when every rank thread has arrived in front of it in good health (LocalHub::barrier throws on
-  // all of them otherwise); what is left is a failure INSIDE a librccl call, for which the failing rank aborts every communicator
-  void abort_comm()
+  // A collective is only queued when every rank thread has arrived in front of it in good health (LocalHub::barrier throws on all
+  // of them otherwise).  What is left is a rank that fails AFTER that meeting (inside a librccl call, or between two meetings): it
+  // raises the hub's flag and nothing else - a communicator is only ever touched by the thread that owns it.  Every owner waits
+  // for the collective it has queued HERE, polling its stream and that flag, and aborts its own communicator when the flag goes up
+  // (the collective would wait for the failed rank for ever otherwise).  A rank inside ncclCommInitRank cannot be reached that way
+  // (blocking initialisation; the unique id is only handed out when every rank thread exists).
+  void abort_own()
   {
     if (comm && !aborted.exchange(true)) (void) ncclCommAbort(comm);
   }
-  void allgather_host(const void *in, size_t bytes, void *out, hipStream_t st) override
+  void finish(hipStream_t st)
+  {
+    for (uint32_t spins = 0;; ++spins)
+    {
+      const hipError_t e = hipStreamQuery(st);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) throw bk_error(BK_ERR_HIP, std::string("RCCL exchange: ") + hipGetErrorString(e));
+      if (hub->failed_flag.load())
+      {
+        abort_own();
+        throw bk_error(BK_ERR_HIP, "another rank failed");
+      }
+      if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  void do_allgather_host(const void *in, size_t bytes, void *out, hipStream_t st) override
   {
     hub->barrier();
     void *di = sin.ensure(bytes + 16), *dout = sout.ensure(bytes * world + 16);
     HIP_CHECK(hipMemcpyAsync(di, in, bytes, hipMemcpyHostToDevice, st));
     NCCL_CHECK(ncclAllGather(di, dout, bytes, ncclChar, comm, st));
     HIP_CHECK(hipMemcpyAsync(out, dout, bytes * world, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    finish(st);
   }
-  void allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) override
+  void do_allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) override
   {
     // one broadcast per root inside a group: no padding to the largest rank, no staging copy
     hub->barrier();
@@ -122,8 +192,9 @@ struct RcclTransport : Transport
       off += sizes[r];
     }
     NCCL_CHECK(ncclGroupEnd());
+    finish(st);
   }
-  void alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) override
+  void do_alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) override
   {
     hub->barrier();
     size_t so = 0, ro = 0;
@@ -136,11 +207,13 @@ struct RcclTransport : Transport
       ro += rb[r];
     }
     NCCL_CHECK(ncclGroupEnd());
+    finish(st);
   }
-  void allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) override
+  void do_allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) override
   {
     hub->barrier();
     if (count) NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclUint32, ncclSum, comm, st));
+    finish(st);
   }
 };
 
@@ -148,14 +221,14 @@ struct RcclTransport : Transport
 struct LocalTransport : Transport
 {
   LocalHub *hub = nullptr;
-  void allgather_host(const void *in, size_t bytes, void *out, hipStream_t) override
+  void do_allgather_host(const void *in, size_t bytes, void *out, hipStream_t) override
   {
     hub->host[rank].assign((const uint8_t *) in, (const uint8_t *) in + bytes);
     hub->barrier();
     for (int r = 0; r < world; ++r) memcpy((char *) out + (size_t) r * bytes, hub->host[r].data(), bytes);
     hub->barrier();
   }
-  void allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) override
+  void do_allgatherv(const void *send, void *recv, const std::vector<size_t> &sizes, hipStream_t st) override
   {
     HIP_CHECK(hipStreamSynchronize(st));  // the peers read this rank's buffer with their own streams
     hub->ptr[rank] = send;
@@ -169,7 +242,7 @@ struct LocalTransport : Transport
     HIP_CHECK(hipStreamSynchronize(st));
     hub->barrier();
   }
-  void alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) override
+  void do_alltoallv(const void *send, const std::vector<size_t> &sb, void *recv, const std::vector<size_t> &rb, hipStream_t st) override
   {
     HIP_CHECK(hipStreamSynchronize(st));
     hub->ptr[rank] = send;
@@ -186,7 +259,7 @@ struct LocalTransport : Transport
     HIP_CHECK(hipStreamSynchronize(st));
     hub->barrier();
   }
-  void allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) override
+  void do_allreduce_sum_u32(uint32_t *buf, size_t count, hipStream_t st) override
   {
     hub->host[rank].resize(count * 4);
     if (count) HIP_CHECK(hipMemcpyAsync(hub->host[rank].data(), buf, count * 4, hipMemcpyDeviceToHost, st));
@@ -274,6 +347,7 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
   BK_CALL(bk_get_stream(ctx, &stv));
   hipStream_t st = (hipStream_t) stv;
   const int W = T.world;
+  T.step = "insert-size sums, spans";
   BK_CALL(bk_shard_begin(ctx, rec_base, qual));
   // insert-size sums / spans
   bk_shard_stats s;
@@ -297,6 +371,7 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
   {
     uint64_t lt = 0, nex = 0;
     void *exd = nullptr;
+  T.step = "bit-exact sd: exception lists";
     BK_CALL(bk_shard_sd_local(ctx, &lt, &exd, &nex));
     uint64_t mine[2] = {lt, nex};
     std::vector<uint64_t> per(2 * W);
@@ -327,6 +402,7 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
   {
     void *send = nullptr;
     const uint64_t *cnt = nullptr;
+  T.step = "mate join: candidates to the owner of their read name";
     BK_CALL(bk_shard_route_candidates(ctx, (uint32_t) W, &send, &cnt));
     void *dummy = nullptr;
     uint64_t n0 = 0;
@@ -381,6 +457,7 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
     for (uint32_t g = 0; g < ng; ++g) dest[g] = owner_of[keys[g]];
     void *send = nullptr;
     const uint64_t *cnt = nullptr;
+  T.step = "grouping: pairs to the owner of their group";
     BK_CALL(bk_shard_route_pairs(ctx, dest.data(), ng, (uint32_t) W, &send, &cnt));
     std::vector<uint64_t> mc(cnt, cnt + W), pc((size_t) W * W);
     T.allgather_host(mc.data(), 8 * W, pc.data(), st);
@@ -396,7 +473,11 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
     BK_CALL(bk_shard_group_pairs(ctx, recv, rtotal / sizeof(bk_pair), gkeys.data(), (uint32_t) gkeys.size()));
   }
   uint64_t n_clustered = 0;
+  T.step = "split evidence, cluster summaries";
+  const auto t_mc0 = std::chrono::steady_clock::now();
   BK_CALL(bk_mask_and_cluster(ctx, w, fast, &n_clustered));
+  HIP_CHECK(hipStreamSynchronize(st));
+  const double t_mc = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_mc0).count();
   BK_CALL(bk_cluster_summary(ctx, w, nullptr));
   {
     std::vector<uint64_t> all(W);
@@ -449,6 +530,7 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
   // breakpoints: coverage and depth are range counts over records, they add over the record shards
   void *p = nullptr;
   uint64_t n = 0;
+  T.step = "breakpoints: coverage counts, voted rows, depth counts";
   BK_CALL(bk_shard_bp_cov(ctx, w, &p, &n));
   T.allreduce_sum_u32((uint32_t *) p, n, st);
   if (W > 1)
@@ -476,6 +558,14 @@ void run_rank(bk_ctx *ctx, Transport &T, uint64_t rec_base, int qual, int fast, 
   T.allreduce_sum_u32((uint32_t *) p, n, st);
   BK_CALL(bk_shard_bp_finish(ctx, p));
   HIP_CHECK(hipStreamSynchronize(st));
+  if (bk_debug("multi"))
+  {
+    // what crossed the links, per step (sent to the other ranks / taken in from them), and this rank's mask + cluster time: the O(n / W)
+    // claim of DESIGN section 6 and the balance of the groups' ownership can be read off a one-GPU rehearsal (-comm local)
+    std::string o = "[multi] rank " + std::to_string(T.rank) + " of " + std::to_string(W) + ": mask + cluster " + std::to_string(t_mc) + " ms, " + std::to_string(n_clustered) + " pairs clustered here;";
+    for (const auto &kv : T.by_step) o += " [" + kv.first + ": " + std::to_string(kv.second.calls) + " exchanges, " + std::to_string(kv.second.sent) + " B sent, " + std::to_string(kv.second.received) + " B received]";
+    fprintf(stderr, "%s\n", o.c_str());
+  }
 }
 }  // namespace
 
@@ -532,14 +622,7 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
   LocalHub hub(W);
   std::vector<Keep> keeps(W);
   std::vector<RankSummary> sums(W);
-  std::vector<RcclTransport *> rccl(W, nullptr);
-  std::mutex rccl_m;
-  auto fail_all = [&] {
-    hub.fail();
-    std::lock_guard<std::mutex> l(rccl_m);
-    for (RcclTransport *t : rccl)
-      if (t) t->abort_comm();
-  };
+  auto fail_all = [&] { hub.fail(); };  // (the owners of the communicators see the flag: RcclTransport::finish)
   std::vector<std::thread> th;
   for (int r = 0; r < W; ++r)
     th.emplace_back([&, r] {
@@ -556,8 +639,6 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
           t->world = W;
           t->hub = &hub;
           NCCL_CHECK(ncclCommInitRank(&t->comm, W, id, r));
-          std::lock_guard<std::mutex> l(rccl_m);
-          rccl[r] = t;
         }
         else
         {
@@ -584,16 +665,14 @@ int multi_run_common(int n_gpus, int transport, int mapq_min, int fast, double *
         codes[r] = e.code;
         errs[r] = e.msg;
         fail_all();
+        if (auto *t = dynamic_cast<RcclTransport *>(T.get())) t->abort_own();  // (its own communicator, from its own thread)
       }
       catch (const std::exception &e)
       {
         codes[r] = BK_ERR_HIP;
         errs[r] = e.what();
         fail_all();
-      }
-      {
-        std::lock_guard<std::mutex> l(rccl_m);  // (the transport dies with this thread)
-        rccl[r] = nullptr;
+        if (auto *t = dynamic_cast<RcclTransport *>(T.get())) t->abort_own();
       }
     });
   for (auto &t : th) t.join();

@@ -209,7 +209,8 @@ int bk_timing_touched(bk_ctx *ctx, const uint64_t **touched, int *n);
  *   bk_shard_group_sizes -> owner per group -> bk_shard_own_groups; bk_mask_and_cluster; bk_cluster_summary
  *   BK_BUF_TUPLES, BK_BUF_CLUSTERS: gather as above
  *   bk_shard_bp_cov -> all-reduce(sum) -> bk_shard_bp_vote -> bk_shard_bp_depth -> all-reduce(sum) -> bk_shard_bp_finish
- * after which every context holds the complete cluster table (bk_fetch).  The whole sample must stay below 2^32 records. */
+ * after which every context holds the complete cluster table (bk_fetch).  One CONTEXT holds fewer than 2^32 records; the sample
+ * may hold more (record indices are 64-bit across the contexts: rec_base + i). */
 typedef struct bk_shard_stats {
   uint64_t isize_sum, isize_n;
   double sumsq;
