@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def from_bam_side_line(n_pairs, device, fast):
+def from_bam_side_line(n_pairs, device, fast, reps=5):
     """File -> calls, end to end (SURVEY 8(f2/f3)): the metric of the headline line is defined on the resident table; this is
     what a user of the command line sees.  Three timings of the same block-aligned BAM (page cache warm, best of 5): the GPU feed
     alone (file -> device table), the feed with the stream pass overlapped (file -> table + candidates + sums), and the rest
@@ -40,8 +40,19 @@ def from_bam_side_line(n_pairs, device, fast):
     from tools import gpu_feedbench
     path = "/tmp/bench_from_bam_%d.bam" % n_pairs
     n, raw, comp = gpu_feedbench.write_bam(path, n_pairs)
+    # what the link itself would take for the file's bytes: pinned host -> device copy rate, measured here
+    pin = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(256 << 20, dtype=torch.uint8, device=device)
+    dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = 4 * (256 << 20) / (time.perf_counter() - t0)
+    del pin, dst
     feed, over, rest, total = [], [], [], []
-    for rep in range(5):
+    for rep in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         table = capi.decode_bam_device(path, device)
@@ -62,7 +73,9 @@ def from_bam_side_line(n_pairs, device, fast):
         ctx.close()
         table.close()
     os.remove(path)
-    return {"records": n, "bam_MB": round(comp / 1e6, 1), "inflated_MB": round(raw / 1e6, 1),
+    return {"records": n, "bam_MB": round(comp / 1e6, 1), "inflated_MB": round(raw / 1e6, 1), "reps": reps,
+            "pinned_h2d_GBps": round(h2d / 1e9, 1), "h2d_bound_s": round(comp / h2d, 4),  # the file's bytes at the measured copy rate: the floor of any feed
+            "file_to_calls_steady_s": round(sorted(total)[len(total) // 2], 4),  # median of the calls (first call included when reps is small)
             "feed_first_call_s": round(feed[0], 4),  # the process's first file: staging buffers and feed slots are allocated and page-locked
             "feed_only_s": round(min(feed), 4), "feed_only_M_records_per_s": round(n / min(feed) / 1e6, 1),
             "feed_plus_stream_pass_overlapped_s": round(min(over), 4), "feed_plus_stream_pass_M_records_per_s": round(n / min(over) / 1e6, 1),
@@ -123,6 +136,8 @@ def main():
                     help="side measurement (N=1, 0 = skip): write a synthetic BAM of PAIRS read pairs and time file -> calls end to end: GPU feed alone, feed "
                          "with the stream pass overlapped (bk_bam_decode_device_ctx), rest of the hot path; reported as `from_bam` beside the headline line "
                          "(the metric itself is defined on the resident table)")
+    ap.add_argument("--from-bam-big", type=int, default=0, metavar="PAIRS",
+                    help="a second file -> calls leg on a file of this many pairs (32 000 000 = 64 M records = 8 GB: a file that does not fit a burst); 0 = skip")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = configs[2], the --records sample sharded over the ranks (default); weak = one sample of N x --records")
     ap.add_argument("--sharded", type=int, default=-1, help="1: one sample sharded over the ranks (default when --gpus > 1), 0: plain single-table run")
@@ -323,6 +338,8 @@ def main():
             o.close()
         if world == 1 and not use_shards and args.from_bam > 0:
             out["from_bam"] = from_bam_side_line(args.from_bam, local_rank, fast)
+        if world == 1 and not use_shards and args.from_bam_big > 0:
+            out["from_bam_big"] = from_bam_side_line(args.from_bam_big, local_rank, fast, reps=3)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist.is_initialized():
