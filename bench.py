@@ -263,7 +263,7 @@ def main():
         # HBM traffic of the launch: NOT measured in this run - rocprofv3 --pmc passes cannot share a process with the timed region -
         # but read from the committed counter summary of the same table (matched by the SURVEY-formula bytes of the launch)
         traffic, traffic_src = None, None
-        for pm_name in ("r03_pmc_k_stream.json", "r02_pmc_k_stream.json", "r01_pmc_k_stream.json"):
+        for pm_name in ("r04_pmc_k_stream.json", "r03_pmc_k_stream.json", "r02_pmc_k_stream.json", "r01_pmc_k_stream.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
                 if abs(pm["algorithmic_bytes_per_launch"] - ks[1] / launches) < 0.02 * pm["algorithmic_bytes_per_launch"]:

@@ -25,6 +25,18 @@ def test_oracle_matches_reference_on_large_inputs(name, mode):
     o.close()
 
 
+@pytest.mark.skipif(not os.environ.get("BREAKID_BIG_TESTS"), reason="100 M records on the CPU: ~7 minutes and ~20 GB here; BREAKID_BIG_TESTS=1 asks for it (run and logged once per round: profiles/r04_wgs100_oracle_cpu.log)")
+def test_oracle_matches_reference_on_the_100M_record_wgs_table():
+    """configs[1]'s shape at 100 M records (`wgs100`): the oracle port against the REAL reference's stages and calls of all 300 groups"""
+    fx, meta = bigcases.load("wgs100")
+    o = pyoracle.Oracle(fx.contigs, fx.cols)
+    mean, sd = o.isize_stats()
+    w, rc = o.run(20, fast=True)
+    assert rc == 0
+    assert bigcases.check("wgs100", "fast", o.fetch, mean, sd, w) == "digest+calls"
+    o.close()
+
+
 def test_deep_inputs_really_reach_the_heapsort_branch():
     """The point of `deep`/`deepw`: libstdc++'s introsort runs out of depth on them (replayed with the library's own
     partition step inside the oracle), in every heap size class of the product's sort emulation."""

@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-D=gpurun_out/prof_r03
+D=gpurun_out/prof_r04
 mkdir -p $D
 python bench.py > $D/bench_final.log 2> $D/bench_final.err
 echo bench done
