@@ -427,11 +427,12 @@ __global__ __launch_bounds__(64) void k_bam_guess(const uint8_t *__restrict__ da
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   if (b >= nblk) return;
   const BgzfBlock bb = blk[b];
-  if (b <= first_blk)
+  if (b < first_blk || (b == first_blk && first_off != 0xFFFFFFFFu))
   {
     if (lane == 0) entry[b] = b == first_blk ? first_off : bb.isize;  // the header's blocks; the first record is known
     return;
   }
+  // (first_off = 0xFFFFFFFF: a part of a file - its first block has to guess like the others, decode_packed_part)
   uint32_t found = bb.isize;
   for (uint32_t base = 0; base < bb.isize; base += 64)
   {
@@ -1408,6 +1409,161 @@ static void decode_packed(const MappedFile &file, int device, bk_bam_dev *h, bk_
             (unsigned long long) n, file.size() / 1e6, nblk, now_s2() - t0);
 }
 
+// One rank's part of such a file (bk_bam_decode_device_part: the blocks that start in the part-th of `parts` equal byte ranges).
+// The part's blocks are inflated into one contiguous stream together with the blocks BEHIND the part that hold up to
+// PACKED_PART_EXT more bytes: the last record that starts in the part ends there.  Every block of a part behind the first guesses its
+// first record boundary, the part's very first block included; the walks are verified to chain up to the first record of the
+// blocks behind the part.  That block is the first block of the NEXT part, where the same bytes give the same guess: the first
+// boundary of part 0 is known (the header), its chain ends at part 1's guess, which is therefore a real boundary, and so on - no
+// rank needs another rank's answer, and a part whose chain does not close is an error (the caller takes the host decoder), never a
+// wrong table.  A rank takes the records that START in its blocks.
+constexpr uint64_t PACKED_PART_EXT = 8u << 20;
+static void decode_packed_part(const MappedFile &file, int device, bk_bam_dev *h, bk_soa *cols, int part, int parts)
+{
+  (void) device;
+  const double t0 = now_s2();
+  uint32_t n_ref = 0, hdr_first_off = 0;
+  uint64_t hdr_first_in_off = 0;
+  parse_bam_header_of_file(file.data(), file.size(), h, n_ref, hdr_first_in_off, hdr_first_off);
+  uint64_t b_lo = 0, b_hi = file.size();
+  {
+    uint64_t o = 0;
+    bgzf_hop_to(file.data(), file.size(), o, (uint64_t) ((unsigned __int128) file.size() * (unsigned) part / (unsigned) parts));
+    b_lo = o;
+    if (part + 1 < parts) bgzf_hop_to(file.data(), file.size(), o, (uint64_t) ((unsigned __int128) file.size() * (unsigned) (part + 1) / (unsigned) parts));
+    b_hi = part + 1 < parts ? o : file.size();
+  }
+  std::vector<BgzfBlock> blocks;
+  uint64_t total = 0, off = b_lo;
+  std::string why;
+  if (b_hi > b_lo && !bgzf_scan_range(file.data(), file.size(), off, b_hi - b_lo, blocks, total, why, 1)) throw bk_error(BK_ERR_IO, why);
+  if (off != b_hi) throw bk_error(BK_ERR_IO, "BGZF blocks do not end where the part ends");
+  const uint32_t nown = (uint32_t) blocks.size();
+  const uint64_t total_own = total;
+  // the blocks behind the part, until PACKED_PART_EXT bytes of their stream are at hand (or the file ends)
+  while (nown && off < file.size() && total - total_own < PACKED_PART_EXT)
+    if (!bgzf_scan_range(file.data(), file.size(), off, 1u << 20, blocks, total, why, 1)) throw bk_error(BK_ERR_IO, why);
+  const bool to_eof = off >= file.size();
+  const uint64_t b_end = off;
+  const uint32_t nblk = (uint32_t) blocks.size();
+  // the part's first record: known for the part that holds the header's end, guessed otherwise
+  uint32_t first_blk = 0, first_off = 0xFFFFFFFFu;
+  if (nown && hdr_first_in_off >= blocks[0].in_off)
+  {
+    while (first_blk < nblk && blocks[first_blk].in_off < hdr_first_in_off) ++first_blk;
+    first_off = hdr_first_off;
+    if (first_blk >= nown) first_blk = nown;  // (the header runs beyond this part: no record starts here)
+  }
+  uint64_t tot[3] = {0, 0, 0};
+  BamCols c = {};
+  DevBuf dfile, dblk, ddata, derr, dcnt, dnr, dnc, dna, dscan, dslab, dentry, dnext, dindex;
+  hipStream_t st = nullptr;
+  if (nown && first_blk < nown)
+  {
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    if ((double) (b_end - b_lo) + (double) total * 1.3 + (double) bgzf_scratch_bytes(nblk) > 0.8 * (double) free_b)
+      throw bk_error(BK_ERR_LIMIT, "this part of a BAM with records across BGZF blocks is too large for the GPU decoder (use bk_bam_open / bk_bam_decode)");
+    for (BgzfBlock &b : blocks) b.in_off -= b_lo;  // offsets into the part's image
+    uint8_t *df = dfile.as<uint8_t>(b_end - b_lo + 8);
+    BgzfBlock *db = dblk.as<BgzfBlock>((uint64_t) nblk + 1);
+    uint8_t *dd = ddata.as<uint8_t>(total + 64);
+    uint32_t *de = derr.as<uint32_t>(1);
+    uint8_t *slab = dslab.as<uint8_t>(bgzf_scratch_bytes(nblk));
+    uint32_t *entry = dentry.as<uint32_t>((uint64_t) nblk + 1);
+    uint64_t *next_abs = dnext.as<uint64_t>((uint64_t) nblk + 1);
+    BlockCount *dc = dcnt.as<BlockCount>((uint64_t) nblk + 1);
+    uint64_t *nr = dnr.as<uint64_t>((uint64_t) nblk + 1), *nc = dnc.as<uint64_t>((uint64_t) nblk + 1), *na = dna.as<uint64_t>((uint64_t) nblk + 1);
+    HIP_CHECK(hipMemcpy(df, file.data() + b_lo, b_end - b_lo, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(db, blocks.data(), (size_t) nblk * sizeof(BgzfBlock), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(de, 0, 4));
+    HIP_CHECK(hipMemset(dd + total, 0, 64));
+    launch_bgzf_inflate(df, db, nblk, dd, slab, de, st);
+    const int allow_tail = to_eof ? 0 : 1;  // (the stream is cut behind the extension: its last walk stops at a record that does not fit)
+    BamCols none = {};
+    hipLaunchKernelGGL(k_bam_guess, dim3(nblk), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, total, entry);
+    hipLaunchKernelGGL(k_bam_blocks<false>, dim3(cdiv(nblk, 64)), dim3(64), 0, st, dd, db, nblk, first_blk, first_off, (int32_t) n_ref, dc, nullptr, nullptr, nullptr, 0ull, 0ull, 0ull, none, entry,
+                       total, next_abs, allow_tail);
+    // counts and columns of the part's OWN blocks; the chain is verified over the blocks behind it as well
+    hipLaunchKernelGGL(k_bam_count_split, dim3(cdiv(nown, 256)), dim3(256), 0, st, dc, nown, nr, nc, na, de);
+    hipLaunchKernelGGL(k_bam_verify, dim3(cdiv(nblk, 256)), dim3(256), 0, st, db, nblk, first_blk, entry, next_abs, total, de, allow_tail, (unsigned long long *) nullptr);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) nr, (unsigned long long *) nr, nown, dscan, st);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) nc, (unsigned long long *) nc, nown, dscan, st);
+    prims::exclusive_scan<unsigned long long>((unsigned long long *) na, (unsigned long long *) na, nown, dscan, st);
+    uint32_t he = 0, e0 = 0;
+    HIP_CHECK(hipMemcpyAsync(&tot[0], nr + nown, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&tot[1], nc + nown, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&tot[2], na + nown, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&he, de, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&e0, entry + first_blk, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (he & 1u) throw bk_error(BK_ERR_IO, "inflate failed");
+    if (he & 2u) throw bk_error(BK_ERR_IO, "corrupt BAM record");
+    if (he & 4u) throw bk_error(BK_ERR_IO, "the record boundaries of this part of the BAM could not be established on the GPU: use the host decoder");
+    // the blocks behind the part must hold the end of its last record: a walk of an own block that ran out of stream would have
+    // been counted as "does not fit" (allow_tail) - its record is longer than the extension
+    if (!to_eof)
+    {
+      std::vector<uint64_t> na_h(nown);
+      HIP_CHECK(hipMemcpy(na_h.data(), next_abs, (size_t) nown * 8, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> en(nown);
+      HIP_CHECK(hipMemcpy(en.data(), entry, (size_t) nown * 4, hipMemcpyDeviceToHost));
+      for (uint32_t b = first_blk; b < nown; ++b)
+        if (en[b] < blocks[b].isize && na_h[b] < blocks[b].out_off + blocks[b].isize)
+          throw bk_error(BK_ERR_LIMIT, "a record at the end of this part of the BAM is longer than the 8 MiB behind the part: use the host decoder");
+    }
+    (void) e0;
+    const uint64_t n = tot[0];
+    if (n >= 0xFFFFFFF0ull || tot[1] >= 0xFFFFFFF0ull || tot[2] >= 0xFFFFFFF0ull) throw bk_error(BK_ERR_LIMIT, "more than 2^32 records / CIGAR words / SA bytes in one part of a BAM");
+    c.tid = h->tid.as<int32_t>(n + 4);
+    c.pos = h->pos.as<int32_t>(n + 4);
+    c.mtid = h->mtid.as<int32_t>(n + 4);
+    c.mpos = h->mpos.as<int32_t>(n + 4);
+    c.isize = h->isize.as<int32_t>(n + 4);
+    c.flag = h->flag.as<uint16_t>(n + 4);
+    c.mapq = h->mapq.as<uint8_t>(n + 4);
+    c.qhash = h->qhash.as<uint64_t>(n + 4);
+    c.qcheck = h->qcheck.as<uint32_t>(n + 4);
+    c.cigar_off = h->cigar_off.as<uint32_t>(n + 4);
+    c.aux_off = h->aux_off.as<uint32_t>(n + 4);
+    c.cigar = h->cigar.as<uint32_t>(tot[1] + 4);
+    c.aux = h->aux.as<uint8_t>(tot[2] + 4);
+    if (n) launch_emit(dd, db, nown, first_blk, first_off, (int32_t) n_ref, dc, nr, nc, na, 0ull, 0ull, 0ull, c, entry, total, allow_tail, n, dindex, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  else
+  {
+    // no record starts in this part: the columns exist all the same, with their end entries
+    c.tid = h->tid.as<int32_t>(4);
+    c.pos = h->pos.as<int32_t>(4);
+    c.mtid = h->mtid.as<int32_t>(4);
+    c.mpos = h->mpos.as<int32_t>(4);
+    c.isize = h->isize.as<int32_t>(4);
+    c.flag = h->flag.as<uint16_t>(4);
+    c.mapq = h->mapq.as<uint8_t>(4);
+    c.qhash = h->qhash.as<uint64_t>(4);
+    c.qcheck = h->qcheck.as<uint32_t>(4);
+    c.cigar_off = h->cigar_off.as<uint32_t>(4);
+    c.aux_off = h->aux_off.as<uint32_t>(4);
+    c.cigar = h->cigar.as<uint32_t>(4);
+    c.aux = h->aux.as<uint8_t>(4);
+  }
+  const uint64_t n = tot[0];
+  const uint32_t ends[2] = {(uint32_t) tot[1], (uint32_t) tot[2]};
+  HIP_CHECK(hipMemcpy(c.cigar_off + n, &ends[0], 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(c.aux_off + n, &ends[1], 4, hipMemcpyHostToDevice));
+  memset(cols, 0, sizeof *cols);
+  cols->n = n;
+  cols->tid = c.tid; cols->pos = c.pos; cols->mtid = c.mtid; cols->mpos = c.mpos; cols->isize = c.isize;
+  cols->flag = c.flag; cols->mapq = c.mapq; cols->qhash = c.qhash; cols->qcheck = c.qcheck;
+  cols->cigar_off = c.cigar_off; cols->cigar = c.cigar; cols->aux_off = c.aux_off; cols->aux = c.aux;
+  cols->n_cigar_words = (uint32_t) tot[1];
+  cols->n_aux_bytes = (uint32_t) tot[2];
+  if (bk_debug("feed"))
+    fprintf(stderr, "[feed/gpu] part %d of %d: %llu records from %u BGZF blocks (+ %u behind the part), records across blocks (boundaries guessed and verified): file -> device table %.3f s\n", part, parts,
+            (unsigned long long) n, nown, nblk - nown, now_s2() - t0);
+}
+
 // Growing device columns of the record table.
 struct ColumnSink
 {
@@ -1755,8 +1911,6 @@ int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_so
     h = new bk_bam_dev();
     if (parts < 1 || part < 0 || part >= parts) throw bk_error(BK_ERR_ARG, "bk_bam_decode_device_part: part must lie in [0, parts)");
     bool packed = !first_block_is_record_aligned(file);
-    // a part of a file can only be cut at BGZF blocks that start with a record
-    if (packed && parts > 1) throw bk_error(BK_ERR_IO, "records run across BGZF blocks: a part of this file cannot be decoded on its own (use the host decoder)");
     if (!packed)
     {
       try
@@ -1765,7 +1919,6 @@ int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_so
       }
       catch (const not_block_aligned &)
       {
-        if (parts > 1) throw bk_error(BK_ERR_IO, "records run across BGZF blocks: a part of this file cannot be decoded on its own (use the host decoder)");
         HIP_CHECK(hipDeviceSynchronize());
         if (fc && fc->on_reset) fc->on_reset(fc->user);
         delete h;
@@ -1773,7 +1926,9 @@ int bam_decode_device_impl(const char *path, int device, bk_bam_dev **out, bk_so
         packed = true;
       }
     }
-    if (packed)
+    if (packed && parts > 1)
+      decode_packed_part(file, device, h, cols, part, parts);  // (one batch per part: a rank's part of a file fits its GPU)
+    else if (packed)
     {
       // in chunks (the faster variant since its inflates run ahead of the record phases: 75-93 ms against 170 for the 1 GB test
       // file); as one batch - file image + inflated stream in HBM - when a record longer than the 8 MiB reserve crosses a chunk

@@ -2518,8 +2518,8 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
   (void) pos[1].as<uint32_t>(2ull * pos_cap[1] * (uint64_t) n_narrow);
   if (bk_debug("svc"))
   {
-    (void) dbg.as<uint32_t>(12 * 8192 + 32);
-    HIP_CHECK(hipMemsetAsync(dbg.p, 0, (12 * 8192 + 32) * 4, after));
+    (void) dbg.as<uint32_t>(12 * 8192 + 48);
+    HIP_CHECK(hipMemsetAsync(dbg.p, 0, (12 * 8192 + 48) * 4, after));
   }
   __atomic_store_n(quit_host, 0u, __ATOMIC_SEQ_CST);
   quit_word = 0xC0DE0000u | (++starts & 0xFFFFu);
@@ -2575,8 +2575,14 @@ void SortService::stop()
     HIP_CHECK(hipMemcpy(&j0, jobs.get<SvcJob>(), sizeof j0, hipMemcpyDeviceToHost));
     if (dbg.p)
     {
-      std::vector<uint32_t> d(12 * 8192 + 32);
+      std::vector<uint32_t> d(12 * 8192 + 48);
       HIP_CHECK(hipMemcpy(d.data(), dbg.p, d.size() * 4, hipMemcpyDeviceToHost));
+      {
+        const uint32_t *ph = d.data() + 12 * 8192 + 32;
+        const double lv = ph[7] ? (double) ph[7] : 1.0;
+        fprintf(stderr, "[svc]   wide partition nodes: %u levels; per level: count pass %.2f us, place pass %.2f us, swaps + drain %.2f us, cut, release, pushes and the next pivot %.2f us\n", ph[7], ph[0] * 1e-2 / lv,
+                ph[1] * 1e-2 / lv, ph[2] * 1e-2 / lv, ph[3] * 1e-2 / lv);
+      }
       for (int kind = 0; kind < 2; ++kind)
       {
         fprintf(stderr, "[svc]   %s tasks by size (2^k ..):", kind ? "narrow heap" : "finisher");

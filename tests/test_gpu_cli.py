@@ -85,7 +85,7 @@ def test_cli_sharded_run_from_cpp_matches_reference(golden_dir, name, mode, rank
     slices) against the reference's txt files.  feed: "gpu" = every rank decodes its part of the file on the GPU
     (bk_multi_run_bam / bk_bam_decode_device_part; "-small-chunks": several feed chunks per part), "host" = the host decoder's
     table cut into record ranges (bk_multi_run, BREAKID_HOST_DECODE=1), "across" = a file whose records run across BGZF blocks:
-    the GPU feed cannot cut it into parts and the command line falls back to the host decoder by itself."""
+    every rank decodes its part on the GPU all the same (round 4: boundaries guessed per part and verified into the next part)."""
     ds, refgene = _dataset(name)
     with tempfile.TemporaryDirectory() as tmp:
         bam = os.path.join(tmp, name + ".bam")
