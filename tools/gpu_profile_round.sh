@@ -2,6 +2,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 D=gpurun_out/prof_r04
 mkdir -p $D
+export GPU_MAX_HW_QUEUES=16
 python bench.py > $D/bench_final.log 2> $D/bench_final.err
 echo bench done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/ks_raw -o ks -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --from-bam 0 > $D/ks.log 2>&1
