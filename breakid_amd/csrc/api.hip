@@ -328,7 +328,8 @@ void stream_rare_path(bk_ctx *c)
   {
     c->timers.back().bytes += 32ull * c->hc.n_cand + 4ull * c->hc.n_sa;
     // what k_stream itself moves: tid, pos, isize, flag, mapq, cigar_off, aux_off of every record (23 B), the CIGAR words (span bound),
-    // qhash + mtid + mpos (+ qcheck) only of the candidates (16-20 B read) + the 40-byte candidate written, 4 B per SA-bearing record index
+    // qhash + mtid + mpos (+ qcheck) only of the candidates (16-20 B read; with the bk_side rows the kernel asks for the whole 32-byte row -
+    // the model keeps the 16-20 bytes it needs, i.e. it does not credit the row's padding) + the 40-byte candidate written, 4 B per SA-bearing record index
     c->timers.back().touched = 23ull * n + 4ull * c->rec.n_cigar_words + (c->rec.qcheck ? 60ull : 56ull) * c->hc.n_cand + 4ull * c->hc.n_sa;
   }
   if (c->hc.unsorted) throw bk_error(BK_ERR_UNSORTED, "records are not coordinate sorted (the reference requires an indexed, sorted BAM)");
