@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a)
     // ---- flush bins that are at least half full (or on the last iteration); looked at every other iteration ----
     const bool last_iter = q + stride >= q_round;  // uniform per block: all lanes share the iteration index
     ++iter_no;
-    if (!(last_iter || (iter_no & 1u) == 0)) continue;
+    if (!(last_iter || (iter_no & 3u) == 0)) continue;
     __syncthreads();
     const unsigned int nc = min(s_ncand, (unsigned int) ST_CAND_CAP), ns = min(s_nsa, (unsigned int) ST_SA_CAP);
     const bool flush_c = nc && (nc >= ST_CAND_CAP / 2 || last_iter), flush_s = ns && (ns >= ST_SA_CAP / 2 || last_iter);
