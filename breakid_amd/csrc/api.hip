@@ -381,8 +381,9 @@ void ensure_splits_sorted(bk_ctx *c)
   if (c->splits_sorted) return;
   Scope s(c, "split_sort");
   bk_split *sorted = c->d_split.as<bk_split>(c->hc.n_split + 1);
-  // tuples of this table carry its own record indices; a sharded sample's carry rec_base + i of every rank (64 bits)
-  int bits = 64;
+  // tuples of this table carry its own record indices; a sharded sample's carry rec_base + i of every rank: the passes of the sort
+  // follow the largest index among the tuples then (bits = 0: sort_splits looks)
+  int bits = 0;
   if (!c->ext_split && c->rec_base == 0)
   {
     bits = 1;

@@ -30,7 +30,7 @@ struct BpWork
 
 struct BpBufs
 {
-  DevBuf samp, key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted, nvalid;
+  DevBuf samp, key, val, kmax, slotbase, an, as1, as2, amin1, amax1, amin2, amax2, atype, keep, off, tmpc, work, nmatch, moff, err, emit, ecount, scan_tmp, cov, depth, voted, nvalid, maxrec;
   prims::RadixBufs radix;
 };
 

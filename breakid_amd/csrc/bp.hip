@@ -657,13 +657,24 @@ __global__ __launch_bounds__(256) void k_bp_finish(bk_cluster *__restrict__ cl, 
   cl[c].flags |= 2u;
 }
 
-__global__ __launch_bounds__(256) void k_split_keys(const bk_split *__restrict__ sp, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+__global__ __launch_bounds__(256) void k_split_keys(const bk_split *__restrict__ sp, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val, unsigned long long *__restrict__ max_rec)
 {
   uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long r = 0;
   if (i < n)
   {
-    key[i] = sp[i].rec;
+    r = sp[i].rec;
+    key[i] = r;
     val[i] = (uint32_t) i;
+  }
+  if (max_rec)  // (a sharded sample: the record indices are the whole sample's, the sort takes its passes from the largest one)
+  {
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+      const unsigned long long o = __shfl_xor(r, d, 64);
+      r = o > r ? o : r;
+    }
+    if ((threadIdx.x & 63) == 0 && r) atomicMax(max_rec, r);
   }
 }
 __global__ __launch_bounds__(256) void k_split_gather(const bk_split *__restrict__ in, const uint32_t *__restrict__ perm, uint64_t n, bk_split *__restrict__ out)
@@ -680,7 +691,21 @@ void sort_splits(bk_split *unsorted, uint64_t n, bk_split *sorted, BpBufs &b, hi
   if (n == 0) return;
   uint64_t *key = b.key.as<uint64_t>(n);
   uint32_t *val = b.val.as<uint32_t>(n);
-  hipLaunchKernelGGL(k_split_keys, dim3(nb(n)), dim3(256), 0, st, unsorted, n, key, val);
+  unsigned long long *mx = nullptr;
+  if (rec_bits <= 0)
+  {
+    mx = b.maxrec.as<unsigned long long>(2);
+    HIP_CHECK(hipMemsetAsync(mx, 0, 8, st));
+  }
+  hipLaunchKernelGGL(k_split_keys, dim3(nb(n)), dim3(256), 0, st, unsorted, n, key, val, mx);
+  if (mx)
+  {
+    unsigned long long h = 0;
+    HIP_CHECK(hipMemcpyAsync(&h, mx, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    rec_bits = 1;
+    while (rec_bits < 64 && (h >> rec_bits) != 0ull) ++rec_bits;
+  }
   uint64_t *ks;
   uint32_t *vs;
   prims::radix_sort_pairs(key, val, n, 0, rec_bits, b.radix, st, &ks, &vs);
