@@ -23,7 +23,7 @@ import time
 # the lanes of chromosome-pair groups in bk_mask_and_cluster (csrc/api.hip; the library's default) need more hardware queues than
 # ROCm's default of 4 (every lane's heap kernels sit on side streams); the runtime reads this when it starts, i.e. before torch
 # touches the GPU (importing breakid_amd.capi sets it as well)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -16,7 +16,7 @@ from . import abi
 
 # the lanes of bk_mask_and_cluster and the chunk streams of the GPU feed want more hardware queues than ROCm's default of 4; the HIP
 # runtime reads the variable when it starts, i.e. at the process's first GPU call - importing this module before that is enough
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbreakid_hip.so")

@@ -106,6 +106,7 @@ struct bk_ctx
   // mask + cluster
   SortService svc;  // resident sort service of the stage (sortsvc.inc)
   std::vector<hipEvent_t> svc_probe;
+  bool svc_refused = false;  // a stage of this context found the service out of reach once (shared hardware queue, crowded device): not tried again
   ClusterBufs cb;
   PairList list;
   DevBuf iso_idx, iso_goff, d_cluster;
@@ -406,7 +407,7 @@ void bk_prepare_process()
     g_hw_queues_at_init = q ? atoi(q) : 4;
     if (!q)
     {
-      setenv("GPU_MAX_HW_QUEUES", "16", 0);
+      setenv("GPU_MAX_HW_QUEUES", "20", 0);
       g_hw_queues_set_here = true;
     }
   });
@@ -769,7 +770,7 @@ struct SvcStage
   bk_ctx *ctx;
   bool on;
   std::unique_lock<std::mutex> device_turn;
-  SvcStage(bk_ctx *c, bool want, uint64_t n_bound, uint64_t max_group, const std::vector<hipStream_t> &streams) : ctx(c), on(want && sort_service_on())
+  SvcStage(bk_ctx *c, bool want, uint64_t n_bound, uint64_t max_group, const std::vector<hipStream_t> &streams) : ctx(c), on(want && sort_service_on() && !c->svc_refused)
   {
     if (on && ctx->device >= 0 && ctx->device < 64)
     {
@@ -780,10 +781,11 @@ struct SvcStage
     ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
     const int census = kfd_compute_queues(ctx->device);
     if (bk_debug("lanes")) fprintf(stderr, "[lanes] compute queues on the device (all processes): %d\n", census);
-    if (census > SVC_MAX_DEVICE_QUEUES || !ctx->svc.narrow_running(0.05) || !reachable(streams))
+    if (census > SVC_MAX_DEVICE_QUEUES || !ctx->svc.narrow_running(0.01) || !reachable(streams))
     {
       ctx->svc.stop();
       on = false;
+      ctx->svc_refused = true;
       device_turn.unlock();
       static bool told = false;
       if (!told && !getenv("BREAKID_QUIET"))

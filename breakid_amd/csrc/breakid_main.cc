@@ -380,7 +380,7 @@ int main(int argc, char *argv[])
   clock_t start = clock();
   // two lanes of chromosome-pair groups (csrc/api.hip: bk_mask_and_cluster) need more hardware queues than ROCm's default 4;
   // both are read when the runtime starts / at the first stage call, so they are set before anything touches the GPU
-  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  setenv("GPU_MAX_HW_QUEUES", "20", 0);
   static struct option longopts[] = {{"help", 0, 0, 'h'}, {"i", 1, 0, 1}, {"o", 1, 0, 2}, {"q", 1, 0, 3}, {"n", 1, 0, 4},
                                      {"fast", 0, 0, 5},   {"t", 0, 0, 6}, {"all", 0, 0, 7}, {"gpu", 1, 0, 8}, {"gpus", 1, 0, 9},
                                      {"comm", 1, 0, 10},  {0, 0, 0, 0}};

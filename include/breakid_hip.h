@@ -144,7 +144,7 @@ typedef struct bk_cluster {
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* Replaces: samopen + header parsing (BreakID.cc:1391,1410).  target_name[i] NUL-terminated. */
 int bk_init(int device, const uint32_t *target_len, const char *const *target_name, int n_targets, bk_ctx **out);
-/* Optional, once per process and before its first HIP call: sets GPU_MAX_HW_QUEUES=16 when the environment does not say (the lanes
+/* Optional, once per process and before its first HIP call: sets GPU_MAX_HW_QUEUES=20 when the environment does not say (the lanes
    of bk_mask_and_cluster, the resident sort service and the GPU feed each want a hardware queue of their own; the runtime reads the
    variable when it starts).  bk_init calls it; a caller with threads of its own calls it before it starts them. */
 void bk_prepare_process(void);
