@@ -1005,10 +1005,12 @@ static LanePlan plan_observed(const std::vector<uint64_t> &sizes, const std::vec
 static void group_lanes(bk_ctx *ctx, double w, int fast)
 {
   const uint32_t ng = ctx->jr.n_groups;
-  // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), so more lanes
-  // than streams are possible: the lanes share S streams (at most twelve; measured worse than a stream each as soon as two
-  // lanes' other kernels queue behind each other: 12 lanes on 12 / 4 / 3 / 2 streams 31.6 / 31.2 / 35.0 / 40.2 ms).
-  constexpr int lane_streams_max = 12;
+  // With the resident sort service a lane's stream is idle most of the time (its thread waits for the sort's job), so the twelve
+  // lanes share FOUR streams: measured 12 lanes on 12 / 8 / 4 streams 44.5-44.8 / 44.4-44.7 / 44.5-45.2 ms per step (6 streams, two
+  // heavy lanes per stream: 46.7-47.4; round-4 start, with waiting kernels on the streams: 12 / 4 / 3 / 2 streams 31.6 / 31.2 / 35.0 /
+  // 40.2 ms for the stage).  Fewer streams = fewer hardware queues: the stage then needs 4 + 2 of them, and a second process on the
+  // device (a test runner's parent, another sample) leaves the device's queues uncrowded (SVC_MAX_DEVICE_QUEUES).
+  constexpr int lane_streams_max = 4;
   auto make_lanes = [&](int K, int S) {
     while ((int) ctx->lanes.size() < K - 1)
     {
