@@ -781,7 +781,7 @@ struct SvcStage
     ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
     const int census = kfd_compute_queues(ctx->device);
     if (bk_debug("lanes")) fprintf(stderr, "[lanes] compute queues on the device (all processes): %d\n", census);
-    if ((census > SVC_MAX_DEVICE_QUEUES && !bk_debug("nocensus")) || !ctx->svc.narrow_running(0.01) || !reachable(streams))
+    if ((census > SVC_MAX_DEVICE_QUEUES && !bk_debug("nocensus")) || !reachable(streams) || !ctx->svc.narrow_running(0.03))
     {
       ctx->svc.stop();
       on = false;

@@ -12,7 +12,7 @@ struct SortService
   DevBuf ctl, slots[2], seq[2], jobs, dbg, pos[2];
   uint32_t pos_cap[2] = {0, 0};
   uint32_t cap[2] = {0, 0};
-  hipStream_t st[2] = {nullptr, nullptr}, quit_stream = nullptr;
+  hipStream_t st[2] = {nullptr, nullptr}, quit_stream = nullptr, st_copy = nullptr;
   uint32_t *quit_host = nullptr;  // mapped host memory the workgroups poll
   uint32_t *quit_dev = nullptr;
   uint32_t cap32 = 0;

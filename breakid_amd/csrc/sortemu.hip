@@ -2486,6 +2486,7 @@ void SortService::start(uint64_t n_bound, uint64_t max_group, hipStream_t after)
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&quit_host), SVC_H_WORDS * 4, hipHostMallocMapped));  // SvcParams::host
     HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&quit_dev), quit_host, 0));
     for (int k = 0; k < 2; ++k) HIP_CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking));
     hipFuncAttributes fa;
     HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_sort_service<true>)));
     // all of a CU's 160 KB but the kernel's static LDS; the ranked entries that fit (+ slot 0 and two zero slots), an odd count
@@ -2560,6 +2561,11 @@ void SortService::stop()
 {
   if (!running) return;
   running = false;
+  // the word that ends the service, two ways: a kernel on a stream of the stage (the stage has probed it) and a copy from page-locked
+  // memory on a stream of its own (a DMA engine's business, not a compute queue's) - whichever arrives first; a stage that gives
+  // the service up BECAUSE one of its streams sits behind a persistent kernel's queue must not wait for that very stream
+  __atomic_store_n(quit_host, quit_word, __ATOMIC_SEQ_CST);
+  (void) hipMemcpyAsync(ctl.get<uint32_t>() + 192, quit_host, 4, hipMemcpyHostToDevice, st_copy);
   hipLaunchKernelGGL(k_svc_quit, dim3(1), dim3(1), 0, quit_stream, ctl.get<uint32_t>() + 192, quit_word);
   HIP_CHECK(hipStreamSynchronize(st[0]));
   HIP_CHECK(hipStreamSynchronize(st[1]));
@@ -2625,6 +2631,11 @@ SortService::~SortService()
   if (running)
   {
     running = false;
+    if (quit_host && st_copy)
+    {
+      __atomic_store_n(quit_host, quit_word, __ATOMIC_SEQ_CST);
+      (void) hipMemcpyAsync(ctl.get<uint32_t>() + 192, quit_host, 4, hipMemcpyHostToDevice, st_copy);
+    }
     if (quit_stream) hipLaunchKernelGGL(k_svc_quit, dim3(1), dim3(1), 0, quit_stream, ctl.get<uint32_t>() + 192, quit_word);
     for (int k = 0; k < 2; ++k)
       if (st[k]) (void) hipStreamSynchronize(st[k]);
@@ -2632,6 +2643,7 @@ SortService::~SortService()
   }
   for (int k = 0; k < 2; ++k)
     if (st[k]) (void) hipStreamDestroy(st[k]);
+  if (st_copy) (void) hipStreamDestroy(st_copy);
   if (quit_host) (void) hipHostFree(quit_host);
 }
 
