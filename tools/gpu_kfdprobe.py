@@ -1,3 +1,5 @@
+"""What the kernel driver says about compute queues per process (/sys/class/kfd/kfd/proc/<pid>/queues/<n>/{gpuid,type,size}): the layout
+api.hip: kfd_compute_queues reads for its census of a device's queues."""
 import os, torch, glob
 streams=[torch.cuda.Stream() for _ in range(6)]
 for s in streams:
