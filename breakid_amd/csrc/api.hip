@@ -115,7 +115,7 @@ struct bk_ctx
   {
     ClusterBufs cb;
     PairList list, iso;
-    DevBuf d_cluster, d_drop;
+    DevBuf d_cluster;
     hipStream_t st = nullptr;
     ~Lane()
     {
@@ -1041,18 +1041,17 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   auto lane_list = [&](int l) -> PairList & { return l == 0 ? ctx->listA : ctx->lanes[l - 1]->list; };
   auto lane_iso = [&](int l) -> PairList & { return l == 0 ? ctx->isoA : ctx->lanes[l - 1]->iso; };
   auto lane_cl = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_clusterA : ctx->lanes[l - 1]->d_cluster; };
-  auto lane_drop = [&](int l) -> DevBuf & { return l == 0 ? ctx->d_dropA : ctx->lanes[l - 1]->d_drop; };
+  uint32_t *drop_base = nullptr;  // the lanes' plans, one row of ng + 1 words each, uploaded in one copy
+  auto lane_drop = [&](int l) { return drop_base + (size_t) l * ((size_t) ng + 1); };
   std::vector<std::vector<uint8_t>> keep(K, std::vector<uint8_t>(ng, 0));  // keep[l][g]: lane l owns group g (host copy of the plan)
   auto upload_plan = [&](const LanePlan &p) {
     for (int l = 0; l < K; ++l)
       for (uint32_t g = 0; g < ng; ++g) keep[l][g] = p.lane_of[g] == l ? 1 : 0;
-    std::vector<std::vector<uint32_t>> drop(K, std::vector<uint32_t>(ng));
+    std::vector<uint32_t> drop((size_t) K * ((size_t) ng + 1), 0u);
     for (int l = 0; l < K; ++l)
-    {
-      for (uint32_t g = 0; g < ng; ++g) drop[l][g] = p.lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
-      uint32_t *d = lane_drop(l).as<uint32_t>((uint64_t) ng + 1);
-      HIP_CHECK(hipMemcpyAsync(d, drop[l].data(), ng * 4, hipMemcpyHostToDevice, ctx->st));
-    }
+      for (uint32_t g = 0; g < ng; ++g) drop[(size_t) l * ((size_t) ng + 1) + g] = p.lane_of[g] == l ? 0u : 1u;  // a lane drops what the others own
+    drop_base = ctx->d_dropA.as<uint32_t>(drop.size() + 1);
+    HIP_CHECK(hipMemcpyAsync(drop_base, drop.data(), drop.size() * 4, hipMemcpyHostToDevice, ctx->st));
     HIP_CHECK(hipStreamSynchronize(ctx->st));  // (the pair table and the masks are ready for all lanes)
   };
   // runs body(l) for every lane, lane 0 on this thread; the lanes' streams are synchronised when this returns
@@ -1108,7 +1107,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
   phase("service started");
   if (!adapt)
   {
-    in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l).get<uint32_t>(), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l), ctx->gstart_host.data(), keep[l].data()); });
+    in_lanes([&](int l) { run_lane(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, fast, lane_drop(l), lane_list(l), lane_iso(l), lane_cl(l), lane_cb(l), ctx->ab, lane_st(l), ctx->gstart_host.data(), keep[l].data()); });
   }
   else
   {
@@ -1122,7 +1121,7 @@ static void group_lanes(bk_ctx *ctx, double w, int fast)
       cb.heavy_y.assign(ng, 0u);
       cb.observe = true;
       cb.se.heavy_all = false;
-      remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l).get<uint32_t>(), ctx->gstart_host.data(), keep[l].data());
+      remove_isolated_begin(pairs, ctx->jr.gof, ctx->jr.gstart, ng, ctx->jr.n_pairs, w, lane_list(l), cb, lane_st(l), lane_drop(l), ctx->gstart_host.data(), keep[l].data());
       if (!split_early)
       {
         cb.heavy_x.assign(ng, 0u);  // the third sort (by x, on the masked list) is the one that tells about the fifth
