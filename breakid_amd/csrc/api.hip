@@ -778,9 +778,30 @@ struct SvcStage
       on = device_turn.owns_lock();
     }
     if (!on) return;
+    const auto ts0 = std::chrono::steady_clock::now();
     ctx->svc.start(n_bound, max_group + 2, ctx->st);  // (+2: a mask may emit one element twice)
-    const int census = kfd_compute_queues(ctx->device);
-    if (bk_debug("lanes")) fprintf(stderr, "[lanes] compute queues on the device (all processes): %d\n", census);
+    const auto ts1 = std::chrono::steady_clock::now();
+    // (the count is kept for a quarter of a second per device: reading it is ~0.5 ms of sysfs, and a sample's stages - or a bench's
+    // steps - follow each other faster than processes come and go)
+    int census;
+    {
+      static std::mutex cm;
+      static std::chrono::steady_clock::time_point when[64];
+      static int last[64];
+      static bool have[64] = {};
+      std::lock_guard<std::mutex> l(cm);
+      const int d = ctx->device & 63;
+      if (!have[d] || std::chrono::duration<double>(ts1 - when[d]).count() > 0.25)
+      {
+        last[d] = kfd_compute_queues(ctx->device);
+        when[d] = std::chrono::steady_clock::now();
+        have[d] = true;
+      }
+      census = last[d];
+    }
+    if (bk_debug("lanes"))
+      fprintf(stderr, "[lanes] sort service started in %.3f ms; compute queues on the device (all processes): %d (counted in %.3f ms)\n", std::chrono::duration<double, std::milli>(ts1 - ts0).count(), census,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
     if ((census > SVC_MAX_DEVICE_QUEUES && !bk_debug("nocensus")) || !reachable(streams) || !ctx->svc.narrow_running(0.03))
     {
       ctx->svc.stop();
