@@ -106,6 +106,7 @@ struct bk_ctx
   // mask + cluster
   SortService svc;  // resident sort service of the stage (sortsvc.inc)
   std::vector<hipEvent_t> svc_probe;
+  int svc_late = 0;
   bool svc_refused = false;  // a stage of this context found the service out of reach once (shared hardware queue, crowded device): not tried again
   ClusterBufs cb;
   PairList list;
@@ -802,11 +803,16 @@ struct SvcStage
     if (bk_debug("lanes"))
       fprintf(stderr, "[lanes] sort service started in %.3f ms; compute queues on the device (all processes): %d (counted in %.3f ms)\n", std::chrono::duration<double, std::milli>(ts1 - ts0).count(), census,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
-    if ((census > SVC_MAX_DEVICE_QUEUES && !bk_debug("nocensus")) || !reachable(streams) || !ctx->svc.narrow_running(0.03))
+    const bool crowded = census > SVC_MAX_DEVICE_QUEUES && !bk_debug("nocensus");
+    const bool behind = !crowded && !reachable(streams);
+    const bool late = !crowded && !behind && !ctx->svc.narrow_running(0.03);
+    if (crowded || behind || late)
     {
       ctx->svc.stop();
       on = false;
-      ctx->svc_refused = true;
+      // a stream behind a persistent kernel's queue or a crowded device stay that way: this context does not try again; a narrow
+      // kernel that was merely late (a busy device) gets a second chance
+      if (crowded || behind || ++ctx->svc_late >= 2) ctx->svc_refused = true;
       device_turn.unlock();
       static bool told = false;
       if (!told && !getenv("BREAKID_QUIET"))
@@ -816,6 +822,7 @@ struct SvcStage
       }
       return;
     }
+    ctx->svc_late = 0;
     set(&ctx->svc);
   }
   bool reachable(const std::vector<hipStream_t> &streams)
