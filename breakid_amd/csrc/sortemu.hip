@@ -2453,7 +2453,7 @@ static SvcParams svc_params(SortService &S)
     P.q[k].slots = S.slots[k].get<SvcTask>();
     P.q[k].seq = S.seq[k].get<uint32_t>();
     P.q[k].mask = S.cap[k] - 1;
-    P.q[k].pad = 1u;  // an agent-scope release in front of every push (sortsvc.inc, visibility)
+    P.q[k].release = 1u;  // an agent-scope release in front of every push (sortsvc.inc, visibility)
   }
   P.error = ctl + 128;
   P.stats = ctl + 160;
